@@ -1,0 +1,252 @@
+/*
+ * rtpt.h — C ABI of the MI355X-native hot path (G-buffer -> temporal gradient -> 1-spp path
+ * trace -> N edge-stopping a-trous passes with reprojection + temporal blend).
+ *
+ * The reference (OnurBasci/Real_Time_Path_Tracing_With_SpatioTemporal_Filtering) has no FFI:
+ * its seam is the Vulkan compute dispatch (pipeline + descriptor set + 112-byte push
+ * constants + grid).  Every entry point below replaces one such dispatch site (or the
+ * resource/scene call that feeds it) and cites it as `file:line` relative to the reference
+ * tree.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 (RTPT_OK) or a negative RTPT_E_* code; the message is
+ *     available from rtpt_last_error().  No exception crosses the ABI.
+ *     (reference: NVVK_CHECK aborts / std::runtime_error never caught, main.cpp:99-111,:1532)
+ *   - all work is enqueued on ONE HIP stream per context in program order, which gives the
+ *     same observable ordering as the reference's vkQueueWaitIdle after each dispatch
+ *     (main.cpp:110-111) without the waits.  rtpt_sync / rtpt_readback are the blocking calls.
+ *   - a context is not thread-safe; distinct contexts (one per GPU) are independent.
+ *   - images are linear row-major, element (x,y) of a plane at index (y-row_begin)*width+x.
+ */
+#ifndef RTPT_H
+#define RTPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTPT_ABI_VERSION 1
+
+/* ---- status codes -------------------------------------------------------------------- */
+#define RTPT_OK 0
+#define RTPT_E_INVALID (-1)  /* bad argument / bad call order */
+#define RTPT_E_NOMEM (-2)    /* host or device allocation failed */
+#define RTPT_E_DEVICE (-3)   /* HIP runtime error (message in rtpt_last_error) */
+#define RTPT_E_NO_SCENE (-4) /* a pass needs rtpt_scene_upload first */
+#define RTPT_E_NO_GPU (-5)   /* no HIP device visible: the product path never falls back to CPU */
+
+/* ---- structs shared with the reference host -------------------------------------------- */
+
+/* PushConstants — main.cpp:35-49, raytrace.comp.glsl:9-23 (identical copies in
+ * temporalGradient.comp.glsl:11-25 and temporalFiltering.comp.glsl:11-25).
+ * Offsets 0,4,16,32,48,64,80,92,96, sizeof 112 (verified against the three .spv). */
+typedef struct rtpt_push_constants {
+  uint32_t sample_batch;        /* @0  */
+  uint32_t frameNumber;         /* @4  */
+  uint32_t _pad0[2];
+  float cameraPos[3];           /* @16 */
+  float _pad1;
+  float lightPos[3];            /* @32 */
+  float _pad2;
+  float lightPosPrev[3];        /* @48 */
+  float _pad3;
+  float currentCameraColor[3];  /* @64 */
+  float _pad4;
+  float previousCameraColor[3]; /* @80 */
+  int32_t waveletIteration;     /* @92 */
+  int32_t maxWaveletIteration;  /* @96 */
+  uint32_t _pad5[3];
+} rtpt_push_constants;
+
+/* UniformBufferObject — main.cpp:82-90, temporalFiltering.comp.glsl:43-51,
+ * visibility.vert.glsl:3-11.  Six column-major mat4 (m[col][row]) @0,64,...,320. */
+typedef struct rtpt_ubo {
+  float model[16];
+  float view[16];
+  float proj[16];
+  float modelPrev[16];
+  float viewPrev[16];
+  float projPrev[16];
+} rtpt_ubo;
+
+/* VisibilityData — temporalGradient.comp.glsl:5-9 (std430: vec3 padded to 16, stride 48).
+ * LUT[t+1] holds the world-space vertices of triangle t; LUT[0] is the background slot
+ * (visibility.geom.glsl:56-59). */
+typedef struct rtpt_visibility_data {
+  float v1[3];
+  float _p1;
+  float v2[3];
+  float _p2;
+  float v3[3];
+  float _p3;
+} rtpt_visibility_data;
+
+/* ---- configuration: the reference's compile-time constants made explicit ---------------- */
+#define RTPT_FLAG_REDUNDANT_HALO 0x1u /* informational: host computes halo rows redundantly */
+
+typedef struct rtpt_config {
+  uint32_t struct_size;          /* = sizeof(rtpt_config), ABI guard */
+  uint32_t width, height;        /* full frame; main.cpp:52-53 (1000x800) */
+  uint32_t row_begin, row_end;   /* rows stored by this context (0,height on one GPU);
+                                    multi-GPU strips allocate strip +- halo rows */
+  uint32_t max_segments;         /* raytrace.comp.glsl:204 (32) */
+  uint32_t samples_per_pixel;    /* raytrace.comp.glsl:306 (1) */
+  int32_t sigma_n;               /* temporalFiltering.comp.glsl:203 (128; integer exponent) */
+  float sigma_z;                 /* :204 (1.0) */
+  float sigma_l;                 /* :205 (4.0) */
+  float alpha;                   /* :243 (0.3) */
+  float light_radius;            /* raytrace.comp.glsl:280 (0.20) */
+  float light_intensity;         /* :281 (30) */
+  float first_hit_light_divisor; /* :229 (5.0) */
+  float fov_slope;               /* tan(FOV), common.h:16, raytrace.comp.glsl:300 (0.20271003) */
+  float pixel_jitter;            /* :314 (0.375) */
+  float ray_offset;              /* :250 (1e-4) */
+  float ray_tmax;                /* :216 (10000) */
+  uint32_t flags;
+  int32_t device;                /* HIP device ordinal, -1 = current device */
+} rtpt_config;
+
+/* planes = the reference's images/buffers (createBuffers main.cpp:357-407) */
+typedef enum rtpt_plane {
+  RTPT_PLANE_IMAGE = 0,     /* `image`              RGBA32F  main.cpp:359 */
+  RTPT_PLANE_FILTERED = 1,  /* `filteredImageBuffer` RGBA32F  main.cpp:400 */
+  RTPT_PLANE_PREVIOUS = 2,  /* `previousImage`      RGBA32F  main.cpp:365 */
+  RTPT_PLANE_WORLDPOS = 3,  /* `positionBuffer`     RGBA32F  main.cpp:383 */
+  RTPT_PLANE_GRADIENT = 4,  /* `temporalGradientBuffer` RGBA32F main.cpp:397 */
+  RTPT_PLANE_DEPTH = 5,     /* `depthImage`         f32 (D32F read as .r, D8) main.cpp:378 */
+  RTPT_PLANE_VIS_ID = 6,    /* `visibilityBuffer`   u32 (reference: R16F, D9) main.cpp:371 */
+  RTPT_PLANE_PREV_VIS_ID = 7, /* `previousVisibilityBuffer` u32 main.cpp:375 */
+  RTPT_PLANE_LUT = 8,       /* `visibilityLUT`  (T+1) x rtpt_visibility_data main.cpp:390 */
+  RTPT_PLANE_LUT_PREV = 9,  /* `visibilityLUTprevious` main.cpp:395 */
+  RTPT_PLANE_PREV_PIXEL = 10, /* build-only observable: reprojected pixel (int32 x,y) written
+                                 by the final filter pass; temporalFiltering.comp.glsl:238 */
+  RTPT_PLANE_RAYCOUNT = 11, /* build-only: u64[1] closest-hit queries issued by rtpt_raytrace
+                               since rtpt_reset_counters (SURVEY 8d "ray") */
+  RTPT_PLANE_HIT_ID = 12,   /* build-only observable (debug): u32 first-hit primitive id+1 of the
+                               jittered primary ray of rtpt_raytrace, only if enabled */
+  RTPT_PLANE_COUNT = 13
+} rtpt_plane;
+
+typedef struct rtpt_ctx rtpt_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+
+/* fills the reference's constants (citations on rtpt_config) for a width x height frame */
+int rtpt_config_default(rtpt_config* cfg, uint32_t width, uint32_t height);
+
+/* createBuffers (main.cpp:357-407) + createCommandPool/Context init: allocates every plane on
+ * the device and one stream.  Returns RTPT_E_NO_GPU when no HIP device is present. */
+int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out);
+/* freeRessources (main.cpp:1477-1528) */
+int rtpt_destroy(rtpt_ctx* ctx);
+/* last error message of this thread's most recent failing call (ctx may be NULL) */
+const char* rtpt_last_error(const rtpt_ctx* ctx);
+
+/* run subsequent passes on a caller-owned hipStream_t (e.g. the stream RCCL halo exchanges are
+ * ordered on).  NULL restores the context's own stream. */
+int rtpt_set_stream(rtpt_ctx* ctx, void* hip_stream);
+
+/* Bind caller-owned device memory as the storage of one colour/guide plane, like the reference
+ * app owning every VkImage bound into the descriptor sets (createAndBindDescriptorSet,
+ * main.cpp:744-908).  bytes must be >= rtpt_plane_bytes.  NULL returns to context-owned memory. */
+int rtpt_bind_plane(rtpt_ctx* ctx, rtpt_plane which, void* device_ptr, size_t bytes);
+/* current device pointer playing the role `which` (roles rotate at the final filter pass and at
+ * rtpt_end_frame — re-query after those calls) */
+int rtpt_plane_ptr(rtpt_ctx* ctx, rtpt_plane which, void** device_ptr);
+int rtpt_plane_bytes(const rtpt_ctx* ctx, rtpt_plane which, size_t* bytes);
+
+/* ---- scene ---------------------------------------------------------------------------- */
+
+/* loadMesh's RT arrays (main.cpp:416-428: objVertices tightly packed xyz, objIndices u32) +
+ * buildAccelerationStructure (main.cpp:687-742: one BLAS, instances with 3x4 row-major
+ * transforms; NULL/0 = the reference's single identity instance).  Builds the flattened
+ * world-space triangle set, the BVH and sizes the LUTs.  Triangle id = instance*n_tris + t. */
+int rtpt_scene_upload(rtpt_ctx* ctx, const float* xyz, uint32_t n_verts, const uint32_t* idx,
+                      uint32_t n_tris, const float* instance_xforms, uint32_t n_instances);
+
+/* ---- per-frame passes, one call per reference dispatch ----------------------------------- */
+
+/* drawVisbilityBuffer (main.cpp:1187-1199; visibility.{vert,geom,frag}.glsl): id, world
+ * position, NDC depth planes + LUT for all triangles.  Rows [y0,y1) of the frame (clamped to
+ * the stored rows); y0=y1=0 means all stored rows. */
+int rtpt_gbuffer(rtpt_ctx* ctx, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1);
+/* computeTemporalGradient (main.cpp:1201-1220; temporalGradient.comp.glsl:104-172) */
+int rtpt_temporal_gradient(rtpt_ctx* ctx, const rtpt_push_constants* pc, uint32_t y0, uint32_t y1);
+/* drawSceneToImage (main.cpp:1222-1253; raytrace.comp.glsl:273-344) */
+int rtpt_raytrace(rtpt_ctx* ctx, const rtpt_push_constants* pc, uint32_t y0, uint32_t y1);
+/* one iteration of applyTemporalFiltering's loop body (main.cpp:1259-1305;
+ * temporalFiltering.comp.glsl:191-265).  The host loops k = 1..maxWaveletIteration exactly
+ * like main.cpp:1259.  Odd k reads IMAGE and writes FILTERED, even k the reverse
+ * (main.cpp:1264-1281).  On k == max (odd) the fused reprojection + blend result becomes
+ * IMAGE (D1: taps read the pre-pass snapshot).  ubo supplies viewPrev/projPrev and may be
+ * NULL when k < max. */
+int rtpt_temporal_filter(rtpt_ctx* ctx, const rtpt_push_constants* pc, const rtpt_ubo* ubo,
+                         uint32_t y0, uint32_t y1);
+/* history hand-over of copyImageToSwapChainsCurrentImage (main.cpp:1364-1372):
+ * previousImage <- image, previousVisibilityBuffer <- visibilityBuffer, LUTprev <- LUT,
+ * done by rotating plane roles (no copy kernels). */
+int rtpt_end_frame(rtpt_ctx* ctx);
+
+/* ---- synchronisation / data movement ---------------------------------------------------- */
+int rtpt_sync(rtpt_ctx* ctx);
+/* blocking copy of a whole plane (stored rows) to host memory */
+int rtpt_readback(rtpt_ctx* ctx, rtpt_plane which, void* dst, size_t bytes);
+/* blocking upload of a whole plane from host memory (inject fixtures / history; SURVEY 5
+ * "checkpoint/resume": the only cross-frame state is PREVIOUS, PREV_VIS_ID, LUT_PREV) */
+int rtpt_set_plane(rtpt_ctx* ctx, rtpt_plane which, const void* src, size_t bytes);
+int rtpt_reset_counters(rtpt_ctx* ctx);
+/* enable/disable the debug HIT_ID plane (off by default: costs 4 B/px of stores) */
+int rtpt_enable_hit_id(rtpt_ctx* ctx, int enable);
+
+/* per-kernel timing hooks for bench.py: HIP events recorded on the stream the kernel runs on.
+ * rtpt_timing_enable(1) makes every pass record a start/stop event pair; rtpt_timing_collect
+ * blocks, sums the durations per kernel since the last collect and returns them. */
+typedef enum rtpt_kernel_id {
+  RTPT_K_GBUFFER = 0,
+  RTPT_K_LUT = 1,
+  RTPT_K_GRADIENT = 2,
+  RTPT_K_PATHTRACE = 3,
+  RTPT_K_ATROUS = 4,
+  RTPT_K_ATROUS_FINAL = 5,
+  RTPT_K_COUNT = 6
+} rtpt_kernel_id;
+int rtpt_timing_enable(rtpt_ctx* ctx, int enable);
+int rtpt_timing_collect(rtpt_ctx* ctx, double ms_sum[RTPT_K_COUNT], uint32_t launches[RTPT_K_COUNT]);
+const char* rtpt_kernel_name(rtpt_kernel_id k);
+
+/* device-side evaluation of the deterministic math used on bit-exact paths, for parity tests
+ * against the oracle: op 0 log, 1 sin(2*pi*u), 2 cos(2*pi*u), 3 sqrt, 4 1/x, 5 exp (filter
+ * fast path), 6 pcg step float.  in/out are host arrays of n floats (u32 bits for op 6). */
+int rtpt_selftest_math(rtpt_ctx* ctx, int op, const float* in, float* out, size_t n);
+/* closest-hit of arbitrary rays through the product's traversal (parity vs the oracle's brute
+ * force): rays = n x {ox,oy,oz,dx,dy,dz}; out_id[n] = primitive id+1 or 0; out_t[n] may be NULL */
+int rtpt_selftest_trace(rtpt_ctx* ctx, const float* rays, size_t n, uint32_t* out_id, float* out_t);
+
+/* ---- host-side helpers shared by the C++ and Python hosts -------------------------------- */
+/* glm::lookAt / glm::perspective as used at main.cpp:482-484,:1470-1472 (right-handed,
+ * zero-to-one depth — D6; the caller applies proj[1][1] *= -1 like the reference does). */
+void rtpt_util_look_at(const float eye[3], const float center[3], const float up[3], float out[16]);
+void rtpt_util_perspective(float fovy, float aspect, float z_near, float z_far, float out[16]);
+/* minimal OBJ reader standing in for tinyobjloader at main.cpp:416-428: `v` and `f` records,
+ * polygons fan-triangulated (0,1,2),(0,2,3) in file order (D5).  Two-call pattern: pass NULL
+ * arrays to obtain counts. */
+int rtpt_util_load_obj(const char* path, float* xyz, uint32_t* n_verts, uint32_t* idx, uint32_t* n_tris);
+
+#ifdef __cplusplus
+}
+static_assert(sizeof(rtpt_push_constants) == 112, "PushConstants is 112 bytes (main.cpp:35-49)");
+static_assert(offsetof(rtpt_push_constants, cameraPos) == 16, "cameraPos@16");
+static_assert(offsetof(rtpt_push_constants, lightPos) == 32, "lightPos@32");
+static_assert(offsetof(rtpt_push_constants, lightPosPrev) == 48, "lightPosPrev@48");
+static_assert(offsetof(rtpt_push_constants, currentCameraColor) == 64, "currentCameraColor@64");
+static_assert(offsetof(rtpt_push_constants, previousCameraColor) == 80, "previousCameraColor@80");
+static_assert(offsetof(rtpt_push_constants, waveletIteration) == 92, "waveletIteration@92");
+static_assert(offsetof(rtpt_push_constants, maxWaveletIteration) == 96, "maxWaveletIteration@96");
+static_assert(sizeof(rtpt_ubo) == 384, "UniformBufferObject is 384 bytes (main.cpp:82-90)");
+static_assert(sizeof(rtpt_visibility_data) == 48, "VisibilityData stride 48 (std430)");
+#endif
+
+#endif /* RTPT_H */

@@ -1,0 +1,577 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.  See rtpt_oracle.h / det_math.h for the contract.
+ * Plain C scalar restatement of the reference's compute chain; citations are file:line
+ * relative to the reference tree (shaders/ prefix omitted for *.glsl).
+ */
+#include "rtpt_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "det_math.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_threads = 1;
+void oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int oracle_get_threads(void) { return g_threads; }
+
+void oracle_config_default(oracle_config* c, uint32_t w, uint32_t h) {
+  memset(c, 0, sizeof(*c));
+  c->width = w;
+  c->height = h;
+  c->max_segments = 32;              /* raytrace.comp.glsl:204 */
+  c->samples_per_pixel = 1;          /* raytrace.comp.glsl:306 */
+  c->sigma_n = 128;                  /* temporalFiltering.comp.glsl:203 */
+  c->sigma_z = 1.0f;                 /* :204 */
+  c->sigma_l = 4.0f;                 /* :205 */
+  c->alpha = 0.3f;                   /* :243 */
+  c->light_radius = 0.20f;           /* raytrace.comp.glsl:280 */
+  c->light_intensity = 30.0f;        /* :281 */
+  c->first_hit_light_divisor = 5.0f; /* :229 */
+  c->fov_slope = 0.20271003f;        /* tan(FOV=0.20), common.h:16; constant folded in the .spv */
+  c->pixel_jitter = 0.375f;          /* :314 */
+  c->ray_offset = 0.0001f;           /* :250 */
+  c->ray_tmax = 10000.0f;            /* :216 */
+}
+
+/* ---------------------------------------------------------------- numerics exports */
+float oracle_log(float x) { return dm_log(x); }
+float oracle_sin2pi(float u) { float s, c; dm_sincos2pi(u, &s, &c); return s; }
+float oracle_cos2pi(float u) { float s, c; dm_sincos2pi(u, &s, &c); return c; }
+float oracle_exp(float x) { return dm_exp(x); }
+float oracle_sqrt(float x) { return dm_sqrt(x); }
+float oracle_rcp(float x) { return 1.0f / x; }
+float oracle_powi(float x, int n) { return dm_powi(x, n); }
+
+uint32_t oracle_rng_seed(uint32_t px, uint32_t py, uint32_t frame, uint32_t batch) {
+  /* raytrace.comp.glsl:297 — uint32 wrap-around arithmetic */
+  return (px * 3266489917u + py * 668265263u) ^ (frame * 374761393u) ^ (batch * 2654435761u);
+}
+
+uint32_t oracle_rng_step(uint32_t* state, float* f) {
+  /* raytrace.comp.glsl:71-78 (pcg_output_rxs_m_xs_32_32) */
+  uint32_t s = *state * 747796405u + 1u;
+  *state = s;
+  uint32_t word = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+  word = (word >> 22) ^ word;
+  /* :77 — 4294967295.0f rounds to 2^32 in binary32, so this is float(word) * 2^-32 exactly */
+  if (f) *f = (float)word / 4294967295.0f;
+  return word;
+}
+
+static inline float rng_float(uint32_t* state) {
+  float f;
+  oracle_rng_step(state, &f);
+  return f;
+}
+
+void oracle_math_array(int op, const float* in, float* out, uint64_t n) {
+  for (uint64_t i = 0; i < n; i++) {
+    float x = in[i], r;
+    switch (op) {
+      case 0: r = dm_log(x); break;
+      case 1: r = oracle_sin2pi(x); break;
+      case 2: r = oracle_cos2pi(x); break;
+      case 3: r = dm_sqrt(x); break;
+      case 4: r = 1.0f / x; break;
+      case 5: r = dm_exp(x); break;
+      case 6: { uint32_t s = dm_bits(x); r = rng_float(&s); break; }
+      default: r = 0.0f;
+    }
+    out[i] = r;
+  }
+}
+
+/* ---------------------------------------------------------------- host helpers */
+void oracle_look_at(const float eye[3], const float center[3], const float up[3], float m[16]) {
+  /* glm::lookAtRH as used at main.cpp:482,:1470 (host arithmetic, plain float ops) */
+  vec3 e = v3(eye[0], eye[1], eye[2]);
+  vec3 f = v3_normalize(v3_sub(v3(center[0], center[1], center[2]), e));
+  vec3 s = v3_normalize(v3_cross(f, v3(up[0], up[1], up[2])));
+  vec3 u = v3_cross(s, f);
+  memset(m, 0, 16 * sizeof(float));
+  m[0] = s.x; m[4] = s.y; m[8] = s.z;
+  m[1] = u.x; m[5] = u.y; m[9] = u.z;
+  m[2] = -f.x; m[6] = -f.y; m[10] = -f.z;
+  m[12] = -v3_dot(s, e);
+  m[13] = -v3_dot(u, e);
+  m[14] = v3_dot(f, e);
+  m[15] = 1.0f;
+}
+
+void oracle_perspective(float fovy, float aspect, float zn, float zf, float m[16]) {
+  /* glm::perspectiveRH_ZO (D6), main.cpp:483,:1471; the caller flips m[5] (main.cpp:484) */
+  float t = (float)tan((double)fovy * 0.5);
+  memset(m, 0, 16 * sizeof(float));
+  m[0] = 1.0f / (aspect * t);
+  m[5] = 1.0f / t;
+  m[10] = zf / (zn - zf);
+  m[11] = -1.0f;
+  m[14] = -(zf * zn) / (zf - zn);
+}
+
+/* C = A * B, column-major; C[c][r] = fma(a3,b3, fma(a2,b2, fma(a1,b1, a0*b0))) */
+static void mat4_mul(const float* A, const float* B, float* C) {
+  for (int c = 0; c < 4; c++)
+    for (int r = 0; r < 4; r++) {
+      float acc = A[0 * 4 + r] * B[c * 4 + 0];
+      acc = dm_fma(A[1 * 4 + r], B[c * 4 + 1], acc);
+      acc = dm_fma(A[2 * 4 + r], B[c * 4 + 2], acc);
+      acc = dm_fma(A[3 * 4 + r], B[c * 4 + 3], acc);
+      C[c * 4 + r] = acc;
+    }
+}
+
+/* (M * vec4(p,1))[i] = fma(m2i,z, fma(m1i,y, m0i*x)) + m3i */
+static inline float mat4_row_point(const float* M, int i, vec3 p) {
+  return dm_fma(M[8 + i], p.z, dm_fma(M[4 + i], p.y, M[i] * p.x)) + M[12 + i];
+}
+
+/* ---------------------------------------------------------------- scene */
+int oracle_load_obj(const char* path, float* xyz, uint32_t* n_verts, uint32_t* idx, uint32_t* n_tris) {
+  FILE* fp = fopen(path, "r");
+  if (!fp) return -1;
+  char line[1024];
+  uint32_t nv = 0, nt = 0;
+  while (fgets(line, sizeof line, fp)) {
+    if (line[0] == 'v' && (line[1] == ' ' || line[1] == '\t')) {
+      float x, y, z;
+      if (sscanf(line + 2, "%f %f %f", &x, &y, &z) == 3) {
+        if (xyz) { xyz[3 * nv] = x; xyz[3 * nv + 1] = y; xyz[3 * nv + 2] = z; }
+        nv++;
+      }
+    } else if (line[0] == 'f' && (line[1] == ' ' || line[1] == '\t')) {
+      long poly[64];
+      int np = 0;
+      char* p = line + 2;
+      while (*p && np < 64) {
+        while (*p == ' ' || *p == '\t') p++;
+        if (*p == '\0' || *p == '\n' || *p == '\r') break;
+        char* end;
+        long v = strtol(p, &end, 10);
+        if (end == p) break;
+        poly[np++] = v > 0 ? v - 1 : (long)nv + v; /* OBJ: 1-based, negative = relative */
+        p = end;
+        while (*p && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r') p++; /* skip /vt/vn */
+      }
+      for (int k = 1; k + 1 < np; k++) { /* D5: fan (0,k,k+1) in file order */
+        if (idx) { idx[3 * nt] = (uint32_t)poly[0]; idx[3 * nt + 1] = (uint32_t)poly[k]; idx[3 * nt + 2] = (uint32_t)poly[k + 1]; }
+        nt++;
+      }
+    }
+  }
+  fclose(fp);
+  *n_verts = nv;
+  *n_tris = nt;
+  return 0;
+}
+
+void oracle_flatten(const float* xyz, const uint32_t* idx, uint32_t n_tris, const float* xf,
+                    uint32_t n_inst, float* tris) {
+  uint32_t ni = (xf && n_inst) ? n_inst : 1;
+  for (uint32_t inst = 0; inst < ni; inst++)
+    for (uint32_t t = 0; t < n_tris; t++)
+      for (int k = 0; k < 3; k++) {
+        const float* v = xyz + 3 * idx[3 * t + k];
+        float* o = tris + 9 * ((uint64_t)inst * n_tris + t) + 3 * k;
+        if (xf && n_inst) {
+          const float* m = xf + 12 * inst; /* 3x4 row-major */
+          for (int r = 0; r < 3; r++)
+            o[r] = dm_fma(m[4 * r + 2], v[2], dm_fma(m[4 * r + 1], v[1], m[4 * r] * v[0])) + m[4 * r + 3];
+        } else {
+          o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+        }
+      }
+}
+
+/* One ray-triangle routine shared by every closest-hit query (D4).  Moller-Trumbore with the
+ * division deferred: returns 1 and (t, b1, b2) when the ray o + t d, 0 < t < tmax, meets the
+ * triangle (both faces; raytrace.comp.glsl:209-216: opaque, no culling, tmin 0, tmax 1e4). */
+static inline int tri_hit(vec3 o, vec3 d, const float* tri, float tmax, float* t, float* b1, float* b2) {
+  vec3 v0 = v3(tri[0], tri[1], tri[2]);
+  vec3 e1 = v3(tri[3] - tri[0], tri[4] - tri[1], tri[5] - tri[2]);
+  vec3 e2 = v3(tri[6] - tri[0], tri[7] - tri[1], tri[8] - tri[2]);
+  vec3 p = v3_cross(d, e2);
+  float det = v3_dot(e1, p);
+  vec3 tv = v3_sub(o, v0);
+  float u = v3_dot(tv, p);
+  vec3 q = v3_cross(tv, e1);
+  float v = v3_dot(d, q);
+  float tt = v3_dot(e2, q);
+  float ad = fabsf(det);
+  if (!(ad > 0.0f)) return 0; /* det == 0 or NaN */
+  if (det < 0.0f) { u = -u; v = -v; tt = -tt; }
+  if (!(u >= 0.0f) || !(v >= 0.0f) || !(u + v <= ad) || !(tt > 0.0f)) return 0;
+  float th = tt / ad;
+  if (!(th < tmax)) return 0;
+  *t = th;
+  *b1 = u / ad;
+  *b2 = v / ad;
+  return 1;
+}
+
+uint32_t oracle_closest_hit(const float* tris, uint32_t n, const float o_[3], const float d_[3],
+                            float tmax, float* t_out, float* b1_out, float* b2_out) {
+  vec3 o = v3(o_[0], o_[1], o_[2]), d = v3(d_[0], d_[1], d_[2]);
+  uint32_t best = 0;
+  float bt = 0.f, bb1 = 0.f, bb2 = 0.f;
+  for (uint32_t i = 0; i < n; i++) {
+    float t, b1, b2;
+    if (tri_hit(o, d, tris + 9 * (uint64_t)i, tmax, &t, &b1, &b2)) {
+      if (best == 0 || t < bt) { best = i + 1; bt = t; bb1 = b1; bb2 = b2; } /* ascending id: ties keep lower id */
+    }
+  }
+  if (best) {
+    if (t_out) *t_out = bt;
+    if (b1_out) *b1_out = bb1;
+    if (b2_out) *b2_out = bb2;
+  }
+  return best;
+}
+
+void oracle_trace_rays(const float* tris, uint32_t n, const float* rays, uint64_t n_rays, float tmax,
+                       uint32_t* out_id, float* out_t) {
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 64)
+  for (int64_t i = 0; i < (int64_t)n_rays; i++) {
+    float t = 0.f;
+    out_id[i] = oracle_closest_hit(tris, n, rays + 6 * i, rays + 6 * i + 3, tmax, &t, NULL, NULL);
+    if (out_t) out_t[i] = out_id[i] ? t : 0.0f;
+  }
+}
+
+/* v0*b.x + v1*b.y + v2*b.z (raytrace.comp.glsl:137) := fma(v2,b2, fma(v1,b1, v0*b0)) */
+static inline vec3 bary_point(const float* tri, float b0, float b1, float b2) {
+  return v3(dm_fma(tri[6], b2, dm_fma(tri[3], b1, tri[0] * b0)),
+            dm_fma(tri[7], b2, dm_fma(tri[4], b1, tri[1] * b0)),
+            dm_fma(tri[8], b2, dm_fma(tri[5], b1, tri[2] * b0)));
+}
+
+/* ---------------------------------------------------------------- K0 */
+void oracle_lut(const float* tris, uint32_t n, const float model[16], float* lut) {
+  /* visibility.vert.glsl:24 worldPos = (model * vec4(p,1)).rgb; visibility.geom.glsl:57-59 */
+  memset(lut, 0, 12 * sizeof(float));
+  for (uint32_t t = 0; t < n; t++)
+    for (int k = 0; k < 3; k++) {
+      vec3 p = v3(tris[9 * (uint64_t)t + 3 * k], tris[9 * (uint64_t)t + 3 * k + 1], tris[9 * (uint64_t)t + 3 * k + 2]);
+      float* o = lut + 12 * ((uint64_t)t + 1) + 4 * k;
+      o[0] = mat4_row_point(model, 0, p);
+      o[1] = mat4_row_point(model, 1, p);
+      o[2] = mat4_row_point(model, 2, p);
+      o[3] = 0.0f;
+    }
+}
+
+void oracle_gbuffer(const oracle_config* cfg, const float* tris, uint32_t n, const oracle_ubo* ubo,
+                    uint32_t y0, uint32_t y1, uint32_t* vis, float* worldpos, float* depth) {
+  const int W = (int)cfg->width, H = (int)cfg->height;
+  const float* V = ubo->view;
+  /* camera origin = -R^T t, ray basis = columns of R (view = [R t]) */
+  vec3 tcol = v3(V[12], V[13], V[14]);
+  vec3 c0 = v3(V[0], V[1], V[2]), c1 = v3(V[4], V[5], V[6]), c2 = v3(V[8], V[9], V[10]);
+  vec3 org = v3(-v3_dot(c0, tcol), -v3_dot(c1, tcol), -v3_dot(c2, tcol));
+  float PV[16];
+  mat4_mul(ubo->proj, ubo->view, PV); /* visibility.vert.glsl:22 proj * view (* model = I) */
+  const float p00 = ubo->proj[0], p11 = ubo->proj[5];
+  const float fw = (float)W, fh = (float)H;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
+  for (int y = (int)y0; y < (int)y1; y++)
+    for (int x = 0; x < W; x++) {
+      /* pixel-centre sample: ndc = (2(x+.5) - W)/W ; view-space direction (ndc.x/P00, ndc.y/P11, -1) */
+      float nx = dm_fma(2.0f, (float)x + 0.5f, -fw) / fw;
+      float ny = dm_fma(2.0f, (float)y + 0.5f, -fh) / fh;
+      vec3 dv = v3(nx / p00, ny / p11, -1.0f);
+      vec3 d = v3_normalize(v3(v3_dot(c0, dv), v3_dot(c1, dv), v3_dot(c2, dv)));
+      float t, b1, b2;
+      float oo[3] = {org.x, org.y, org.z}, dd[3] = {d.x, d.y, d.z};
+      uint32_t id = oracle_closest_hit(tris, n, oo, dd, cfg->ray_tmax, &t, &b1, &b2);
+      uint64_t i = (uint64_t)y * W + x;
+      vis[i] = id; /* visibility.frag.glsl:23 primitiveID+1, clear 0 (main.cpp:1419) */
+      if (id) {
+        float b0 = 1.0f - b1 - b2;
+        vec3 wp = bary_point(tris + 9 * (uint64_t)(id - 1), b0, b1, b2);
+        worldpos[4 * i] = wp.x; worldpos[4 * i + 1] = wp.y; worldpos[4 * i + 2] = wp.z; worldpos[4 * i + 3] = 1.0f;
+        float cz = mat4_row_point(PV, 2, wp), cw = mat4_row_point(PV, 3, wp);
+        depth[i] = cz / cw;
+      } else {
+        worldpos[4 * i] = 0.f; worldpos[4 * i + 1] = 0.f; worldpos[4 * i + 2] = 0.f; worldpos[4 * i + 3] = 1.0f; /* main.cpp:1420 */
+        depth[i] = 1.0f; /* main.cpp:1421 */
+      }
+    }
+}
+
+/* ---------------------------------------------------------------- K1 */
+static inline vec3 lut_v(const float* lut, uint32_t id, int k) {
+  const float* p = lut + 12 * (uint64_t)id + 4 * k;
+  return v3(p[0], p[1], p[2]);
+}
+
+/* temporalGradient.comp.glsl:50-55 / temporalFiltering.comp.glsl:157-162 */
+static inline float tri_area(vec3 a, vec3 b, vec3 c) {
+  return v3_length(v3_cross(v3_sub(b, a), v3_sub(c, a))) * 0.5f;
+}
+/* temporalGradient.comp.glsl:57-69 / temporalFiltering.comp.glsl:164-176 */
+static inline vec3 bary_coords(vec3 p, vec3 a, vec3 b, vec3 c) {
+  float at = tri_area(a, b, c);
+  return v3(tri_area(p, b, c) / at, tri_area(a, p, c) / at, tri_area(a, b, p) / at);
+}
+static inline vec3 bary_mix(vec3 bc, vec3 a, vec3 b, vec3 c) {
+  /* barCoord.x * v1p + barCoord.y * v2p + barCoord.z * v3p */
+  return v3(dm_fma(bc.z, c.x, dm_fma(bc.y, b.x, bc.x * a.x)), dm_fma(bc.z, c.y, dm_fma(bc.y, b.y, bc.x * a.y)),
+            dm_fma(bc.z, c.z, dm_fma(bc.y, b.z, bc.x * a.z)));
+}
+
+/* temporalGradient.comp.glsl:71-101 */
+static vec3 phong(vec3 p, vec3 n, vec3 cam, vec3 lpos, vec3 lcol, int shininess) {
+  vec3 ldir = v3_normalize(v3_sub(lpos, p));
+  vec3 ambient = v3_scale(lcol, 0.1f);
+  float diff = dm_max(v3_dot(n, ldir), 0.0f);
+  vec3 diffuse = v3_scale(lcol, diff);
+  vec3 vdir = v3_normalize(v3_sub(cam, p));
+  vec3 I = v3_neg(ldir);
+  float two_ndi = 2.0f * v3_dot(n, I); /* reflect(I,N) = I - 2 dot(N,I) N */
+  vec3 rdir = v3(dm_fma(-two_ndi, n.x, I.x), dm_fma(-two_ndi, n.y, I.y), dm_fma(-two_ndi, n.z, I.z));
+  float spec = dm_powi(dm_max(v3_dot(vdir, rdir), 0.0f), shininess);
+  float ss = 0.5f * spec;
+  vec3 specular = v3_scale(lcol, ss);
+  vec3 sum = v3_add(v3_add(ambient, diffuse), specular);
+  return v3_scale(sum, 0.7f); /* attenuation 1.0 (exact), objectColor 0.7 */
+}
+
+void oracle_temporal_gradient(const oracle_config* cfg, const oracle_push_constants* pc,
+                              const uint32_t* vis, const float* worldpos, const float* lut,
+                              const float* lut_prev, uint32_t y0, uint32_t y1, float* grad) {
+  const int W = (int)cfg->width;
+  vec3 cam = v3(pc->cameraPos[0], pc->cameraPos[1], pc->cameraPos[2]);
+  vec3 lp = v3(pc->lightPos[0], pc->lightPos[1], pc->lightPos[2]);
+  vec3 lpp = v3(pc->lightPosPrev[0], pc->lightPosPrev[1], pc->lightPosPrev[2]);
+  vec3 lc = v3(pc->currentCameraColor[0], pc->currentCameraColor[1], pc->currentCameraColor[2]);
+  vec3 lcp = v3(pc->previousCameraColor[0], pc->previousCameraColor[1], pc->previousCameraColor[2]);
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
+  for (int y = (int)y0; y < (int)y1; y++)
+    for (int x = 0; x < W; x++) {
+      uint64_t i = (uint64_t)y * W + x;
+      float* g = grad + 4 * i;
+      g[0] = g[1] = g[2] = g[3] = 0.0f; /* :119 */
+      uint32_t id = vis[i];
+      if (id == 0) continue; /* :131 */
+      vec3 wp = v3(worldpos[4 * i], worldpos[4 * i + 1], worldpos[4 * i + 2]);
+      vec3 a = lut_v(lut, id, 0), b = lut_v(lut, id, 1), c = lut_v(lut, id, 2);
+      vec3 nrm = v3_normalize(v3_cross(v3_sub(b, a), v3_sub(c, a))); /* :142 */
+      vec3 bc = bary_coords(wp, a, b, c);                            /* :143 */
+      vec3 ap = lut_v(lut_prev, id, 0), bp = lut_v(lut_prev, id, 1), cp = lut_v(lut_prev, id, 2);
+      vec3 wpp = bary_mix(bc, ap, bp, cp);                           /* :153 */
+      vec3 cur = phong(wp, nrm, cam, lp, lc, 128);                   /* :158 */
+      vec3 prv = phong(wpp, nrm, cam, lpp, lcp, 128);                /* :161 (current normal!) */
+      vec3 tg = v3_sub(cur, prv);
+      float delta = dm_max(v3_length(cur), v3_length(prv));          /* :166 */
+      float lam = dm_min(1.0f, v3_length(tg) / delta);               /* :167 */
+      g[0] = g[1] = g[2] = lam;
+      g[3] = 0.0f; /* :170 */
+    }
+}
+
+/* ---------------------------------------------------------------- K2 */
+/* raytrace.comp.glsl:84-92 */
+static inline void random_gaussian(uint32_t* rng, float* gx, float* gy) {
+  float u1 = dm_max(1e-38f, rng_float(rng));
+  float u2 = rng_float(rng);
+  float r = dm_sqrt(-2.0f * dm_log(u1));
+  float s, c;
+  dm_sincos2pi(u2, &s, &c); /* theta = 2*k_pi*u2 */
+  *gx = r * c;
+  *gy = r * s;
+}
+
+/* raytrace.comp.glsl:95-107; mix(x,y,a) = x*(1-a) + y*a := fma(y,a, x*(1-a)) */
+static inline vec3 sky_color(vec3 d) {
+  if (d.y > 0.0f) {
+    float a = d.y, ia = 1.0f - a;
+    return v3(dm_fma(0.25f, a, 1.0f * ia), dm_fma(0.5f, a, 1.0f * ia), dm_fma(1.0f, a, 1.0f * ia));
+  }
+  return v3(0.03f, 0.03f, 0.03f);
+}
+
+/* raytrace.comp.glsl:168-198 — only the boolean is consumed (:226) */
+static inline int ray_hits_light(vec3 o, vec3 d, vec3 center, float radius) {
+  vec3 oc = v3_sub(o, center);
+  float a = v3_dot(d, d);
+  float b = 2.0f * v3_dot(oc, d);
+  float c = v3_dot(oc, oc) - radius * radius;
+  float disc = dm_fma(b, b, -((4.0f * a) * c));
+  if (disc < 0.0f) return 0;
+  float sq = dm_sqrt(disc);
+  float t1 = (-b - sq) / (2.0f * a);
+  float t2 = (-b + sq) / (2.0f * a);
+  if (t1 > 0.0f) return 1;
+  if (t2 > 0.0f) return 1;
+  return 0;
+}
+
+void oracle_raytrace(const oracle_config* cfg, const oracle_push_constants* pc, const float* tris,
+                     uint32_t n, uint32_t y0, uint32_t y1, float* image, uint64_t* raycount,
+                     uint32_t* hit_id) {
+  const int W = (int)cfg->width, H = (int)cfg->height;
+  vec3 light_c = v3(pc->lightPos[0], pc->lightPos[1], pc->lightPos[2]); /* :279 */
+  vec3 light_col = v3(pc->currentCameraColor[0] * cfg->light_intensity, pc->currentCameraColor[1] * cfg->light_intensity,
+                      pc->currentCameraColor[2] * cfg->light_intensity); /* :281 */
+  vec3 cam = v3(pc->cameraPos[0], pc->cameraPos[1], pc->cameraPos[2]);
+  const float slope = cfg->fov_slope;
+  const float fw = (float)W, fh = (float)H;
+  uint64_t rays_total = 0;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4) reduction(+ : rays_total)
+  for (int y = (int)y0; y < (int)y1; y++)
+    for (int x = 0; x < W; x++) {
+      uint32_t rng = oracle_rng_seed((uint32_t)x, (uint32_t)y, pc->frameNumber, pc->sample_batch); /* :297 */
+      vec3 sum = v3(0.f, 0.f, 0.f);
+      uint32_t first_id = 0;
+      for (uint32_t smp = 0; smp < cfg->samples_per_pixel; smp++) { /* :307 */
+        vec3 o = cam;
+        float gx, gy;
+        random_gaussian(&rng, &gx, &gy);
+        float cx = dm_fma(cfg->pixel_jitter, gx, (float)x + 0.5f); /* :314 */
+        float cy = dm_fma(cfg->pixel_jitter, gy, (float)y + 0.5f);
+        float ux = dm_fma(2.0f, cx, -fw) / fh;    /* :315 */
+        float uy = -(dm_fma(2.0f, cy, -fh) / fh); /* :316 */
+        vec3 d = v3_normalize(v3(slope * ux, slope * uy, -1.0f)); /* :319-320 */
+        vec3 acc = v3(1.f, 1.f, 1.f);                             /* :201 */
+        for (uint32_t seg = 0; seg < cfg->max_segments; seg++) {  /* :204 */
+          float t, b1, b2;
+          float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+          uint32_t id = oracle_closest_hit(tris, n, oo, dd, cfg->ray_tmax, &t, &b1, &b2); /* :208-222 */
+          rays_total++;
+          if (seg == 0 && smp == 0) first_id = id;
+          if (ray_hits_light(o, d, light_c, cfg->light_radius)) { /* :226 — not compared with t */
+            if (seg == 0) {
+              acc = v3_mul(acc, v3(light_col.x / cfg->first_hit_light_divisor, light_col.y / cfg->first_hit_light_divisor,
+                                   light_col.z / cfg->first_hit_light_divisor)); /* :229 */
+              break;
+            }
+            acc = v3_mul(acc, light_col); /* :233 */
+            break;
+          }
+          if (id) { /* :238 */
+            const float* tri = tris + 9 * (uint64_t)(id - 1);
+            float b0 = 1.0f - b1 - b2;           /* :134 */
+            vec3 pos = bary_point(tri, b0, b1, b2); /* :137 */
+            vec3 v0 = v3(tri[0], tri[1], tri[2]);
+            vec3 nrm = v3_normalize(v3_cross(v3_sub(v3(tri[3], tri[4], tri[5]), v0), v3_sub(v3(tri[6], tri[7], tri[8]), v0))); /* :150 */
+            vec3 alb;
+            if (nrm.x > 0.99f) alb = v3(1.f, 0.f, 0.f);        /* :155 dot(n,(1,0,0)) == n.x exactly */
+            else if (-nrm.x > 0.99f) alb = v3(0.f, 1.f, 0.f);  /* :158 */
+            else alb = v3(0.7f, 0.7f, 0.7f);                   /* :162 */
+            acc = v3_mul(acc, alb);                            /* :244 */
+            if (!(v3_dot(nrm, d) < 0.0f)) nrm = v3_neg(nrm);   /* :247 faceforward(N,I,Nref) */
+            o = v3(dm_fma(cfg->ray_offset, nrm.x, pos.x), dm_fma(cfg->ray_offset, nrm.y, pos.y), dm_fma(cfg->ray_offset, nrm.z, pos.z)); /* :250 */
+            float s, c;
+            dm_sincos2pi(rng_float(&rng), &s, &c);        /* :256 */
+            float u = dm_fma(2.0f, rng_float(&rng), -1.0f); /* :257 */
+            float r = dm_sqrt(dm_fma(-u, u, 1.0f));       /* :258 */
+            d = v3_normalize(v3(dm_fma(r, c, nrm.x), dm_fma(r, s, nrm.y), nrm.z + u)); /* :259-261 */
+          } else {
+            acc = v3_mul(acc, sky_color(d)); /* :266 */
+            break;
+          }
+        }
+        sum = v3_add(sum, acc); /* :325 */
+      }
+      float ns = (float)cfg->samples_per_pixel;
+      uint64_t i = (uint64_t)y * W + x;
+      image[4 * i] = sum.x / ns; /* :328 */
+      image[4 * i + 1] = sum.y / ns;
+      image[4 * i + 2] = sum.z / ns;
+      image[4 * i + 3] = 0.0f; /* :343 */
+      if (hit_id) hit_id[i] = first_id;
+    }
+  if (raycount) *raycount += rays_total;
+}
+
+/* ---------------------------------------------------------------- K3 */
+/* temporalFiltering.comp.glsl:80-91 */
+static inline vec3 normal_from_id(const float* lut, uint32_t id) {
+  if (id == 0) return v3(0.f, 0.f, 1.f);
+  vec3 a = lut_v(lut, id, 0), b = lut_v(lut, id, 1), c = lut_v(lut, id, 2);
+  return v3_normalize(v3_cross(v3_sub(b, a), v3_sub(c, a)));
+}
+
+void oracle_atrous(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
+                   const float* in, const float* depth, const uint32_t* vis, const float* lut,
+                   const float* lut_prev, const float* worldpos, const float* history,
+                   uint32_t y0, uint32_t y1, float* out, int32_t* prev_pixel) {
+  const int W = (int)cfg->width, H = (int)cfg->height;
+  const int k = pc->waveletIteration, max_it = pc->maxWaveletIteration; /* :208-209 */
+  /* main.cpp:1264-1281: on even k colorImage is filteredImageBuffer, so the blend of an even
+   * final pass lands in a buffer nothing reads ("must be an odd number", main.cpp:55) and
+   * `image` keeps the plain filtered colour: only an odd final pass blends observably. */
+  const int final_pass = (k == max_it) && (k & 1);
+  float PVp[16];
+  if (final_pass) mat4_mul(ubo->projPrev, ubo->viewPrev, PVp); /* :180 projMatrix * viewMatrix */
+  const float h = 1.0f / 9.0f;                    /* :145 */
+  const float one_minus_alpha = 1.0f - cfg->alpha; /* :254 */
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
+  for (int y = (int)y0; y < (int)y1; y++)
+    for (int x = 0; x < W; x++) {
+      uint64_t ip = (uint64_t)y * W + x;
+      vec3 cp = v3(in[4 * ip], in[4 * ip + 1], in[4 * ip + 2]); /* :122 */
+      float dp = depth[ip];                                    /* :123 */
+      vec3 np = normal_from_id(lut, vis[ip]);                  /* :125-127 */
+      vec3 num = v3(0.f, 0.f, 0.f);
+      float den = 0.f;
+      for (int i = -1; i < 2; i++)     /* :132 */
+        for (int j = -1; j < 2; j++) { /* :133 */
+          int qx = x + i * k, qy = y + j * k; /* :135 */
+          qx = qx < 0 ? 0 : (qx > W - 1 ? W - 1 : qx); /* :136 */
+          qy = qy < 0 ? 0 : (qy > H - 1 ? H - 1 : qy);
+          uint64_t iq = (uint64_t)qy * W + qx;
+          vec3 cq = v3(in[4 * iq], in[4 * iq + 1], in[4 * iq + 2]);
+          float dq = depth[iq];
+          vec3 nq = normal_from_id(lut, vis[iq]);
+          float wn = dm_powi(dm_max(0.0f, v3_dot(np, nq)), cfg->sigma_n);    /* :62 */
+          float wd = dm_exp(-fabsf(dp - dq) / cfg->sigma_z);                 /* :67-68 */
+          float wl = dm_exp(-v3_length(v3_sub(cp, cq)) / cfg->sigma_l);      /* :73 */
+          float w = (wn * wd) * wl;                                          /* :77 */
+          float hw = h * w;
+          num = v3(dm_fma(hw, cq.x, num.x), dm_fma(hw, cq.y, num.y), dm_fma(hw, cq.z, num.z)); /* :146 */
+          den = den + hw;                                                     /* :147 */
+        }
+      vec3 filtered = v3(num.x / den, num.y / den, num.z / den); /* :150 */
+      float* o = out + 4 * ip;
+      if (!final_pass) {
+        o[0] = filtered.x; o[1] = filtered.y; o[2] = filtered.z; o[3] = 0.0f; /* :152 */
+        continue;
+      }
+      /* :213-239 reprojection (evaluated by the reference on every iteration, consumed only here) */
+      uint32_t id = vis[ip];
+      int ppx = x, ppy = y;
+      if (!(id < 1)) {
+        vec3 wp = v3(worldpos[4 * ip], worldpos[4 * ip + 1], worldpos[4 * ip + 2]);
+        vec3 a = lut_v(lut_prev, id, 0), b = lut_v(lut_prev, id, 1), c = lut_v(lut_prev, id, 2); /* :223-233 */
+        vec3 bc = bary_coords(wp, a, b, c);
+        vec3 wpp = bary_mix(bc, a, b, c); /* :236 */
+        float clx = mat4_row_point(PVp, 0, wpp), cly = mat4_row_point(PVp, 1, wpp), clw = mat4_row_point(PVp, 3, wpp);
+        float ndx = clx / clw, ndy = cly / clw;                          /* :183 */
+        float sx = dm_fma(ndx, 0.5f, 0.5f) * (float)W;                   /* :186 */
+        float sy = dm_fma(ndy, 0.5f, 0.5f) * (float)H;
+        ppx = dm_f2i(sx); /* :238 ivec2() truncation */
+        ppy = dm_f2i(sy);
+      }
+      if (prev_pixel) { prev_pixel[2 * ip] = ppx; prev_pixel[2 * ip + 1] = ppy; }
+      vec3 blend;
+      if (pc->frameNumber > 0) { /* :251 */
+        vec3 hc = v3(0.f, 0.f, 0.f); /* D2: out-of-image history reads as 0 */
+        if (ppx >= 0 && ppx < W && ppy >= 0 && ppy < H) {
+          uint64_t ih = (uint64_t)ppy * W + ppx;
+          hc = v3(history[4 * ih], history[4 * ih + 1], history[4 * ih + 2]);
+        }
+        blend = v3(dm_fma(filtered.x, cfg->alpha, hc.x * one_minus_alpha), dm_fma(filtered.y, cfg->alpha, hc.y * one_minus_alpha),
+                   dm_fma(filtered.z, cfg->alpha, hc.z * one_minus_alpha)); /* :254 */
+      } else {
+        blend = filtered; /* :258 */
+      }
+      o[0] = blend.x; o[1] = blend.y; o[2] = blend.z; o[3] = 0.0f; /* :263 */
+    }
+}

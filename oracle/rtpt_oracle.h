@@ -1,0 +1,116 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see det_math.h).  CPU scalar restatement of the
+ * reference's per-frame compute chain, one function per shader, each citing the GLSL it
+ * follows.  PARITY UNPINNED by reference fixtures: the reference has no tests, golden images or
+ * runnable build in this environment; this oracle is pinned by the
+ * known-answer vectors derivable from the reference sources (tests/test_oracle_kat.py) and by
+ * line-by-line citation.
+ */
+#ifndef RTPT_ORACLE_H
+#define RTPT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_config {
+  uint32_t width, height;        /* main.cpp:52-53 */
+  uint32_t max_segments;         /* raytrace.comp.glsl:204 */
+  uint32_t samples_per_pixel;    /* raytrace.comp.glsl:306 */
+  int32_t sigma_n;               /* temporalFiltering.comp.glsl:203 */
+  float sigma_z, sigma_l;        /* :204-205 */
+  float alpha;                   /* :243 */
+  float light_radius;            /* raytrace.comp.glsl:280 */
+  float light_intensity;         /* :281 */
+  float first_hit_light_divisor; /* :229 */
+  float fov_slope;               /* :300 tan(FOV) */
+  float pixel_jitter;            /* :314 */
+  float ray_offset;              /* :250 */
+  float ray_tmax;                /* :216 */
+} oracle_config;
+
+/* PushConstants, main.cpp:35-49 (112 bytes, same layout as the shaders) */
+typedef struct oracle_push_constants {
+  uint32_t sample_batch, frameNumber, _pad0[2];
+  float cameraPos[3], _pad1;
+  float lightPos[3], _pad2;
+  float lightPosPrev[3], _pad3;
+  float currentCameraColor[3], _pad4;
+  float previousCameraColor[3];
+  int32_t waveletIteration;
+  int32_t maxWaveletIteration;
+  uint32_t _pad5[3];
+} oracle_push_constants;
+
+/* UniformBufferObject, main.cpp:82-90: six column-major mat4 */
+typedef struct oracle_ubo {
+  float model[16], view[16], proj[16], modelPrev[16], viewPrev[16], projPrev[16];
+} oracle_ubo;
+
+void oracle_config_default(oracle_config* cfg, uint32_t width, uint32_t height);
+/* number of worker threads for the row loops (OpenMP); 1 = scalar */
+void oracle_set_threads(int n);
+int oracle_get_threads(void);
+
+/* --- numerics contract, exported for bit-exact comparison with the device ---------------- */
+float oracle_log(float x);
+float oracle_sin2pi(float u);
+float oracle_cos2pi(float u);
+float oracle_exp(float x);
+float oracle_sqrt(float x);
+float oracle_rcp(float x);
+float oracle_powi(float x, int n);
+void oracle_math_array(int op, const float* in, float* out, uint64_t n);
+
+/* --- RNG (raytrace.comp.glsl:71-78, :297) -------------------------------------------------- */
+uint32_t oracle_rng_seed(uint32_t px, uint32_t py, uint32_t frame, uint32_t batch);
+/* steps the state, returns the output word; *f receives the float in [0,1] */
+uint32_t oracle_rng_step(uint32_t* state, float* f);
+
+/* --- host helpers (glm::lookAt / glm::perspective, zero-to-one depth, D6) ------------------ */
+void oracle_look_at(const float eye[3], const float center[3], const float up[3], float out[16]);
+void oracle_perspective(float fovy, float aspect, float z_near, float z_far, float out[16]);
+
+/* --- scene --------------------------------------------------------------------------------- */
+/* OBJ reader: `v` / `f` records, fan triangulation (0,1,2),(0,2,3) in file order (D5).
+ * Pass NULL arrays to get the counts. */
+int oracle_load_obj(const char* path, float* xyz, uint32_t* n_verts, uint32_t* idx, uint32_t* n_tris);
+/* world-space triangle soup: tris[9*(inst*n_tris+t)] = xform_inst * (v0,v1,v2); xforms 3x4
+ * row-major, NULL/0 = one identity instance (main.cpp:728-741) */
+void oracle_flatten(const float* xyz, const uint32_t* idx, uint32_t n_tris, const float* xforms,
+                    uint32_t n_inst, float* tris);
+/* closest hit (D4: min over (t, id)) by brute force over all triangles: returns id+1 or 0 */
+uint32_t oracle_closest_hit(const float* tris, uint32_t n, const float o[3], const float d[3],
+                            float tmax, float* t_out, float* b1_out, float* b2_out);
+void oracle_trace_rays(const float* tris, uint32_t n, const float* rays, uint64_t n_rays, float tmax,
+                       uint32_t* out_id, float* out_t);
+
+/* --- passes.  All image arrays are full-frame, index y*width+x; rows [y0,y1) are computed --- */
+/* visibility.geom.glsl:44-59: lut has (n+1)*12 floats (stride 48 B); slot 0 is zeroed */
+void oracle_lut(const float* tris, uint32_t n, const float model[16], float* lut);
+/* K0: visibility.{vert,geom,frag}.glsl as pixel-centre primary rays */
+void oracle_gbuffer(const oracle_config* cfg, const float* tris, uint32_t n, const oracle_ubo* ubo,
+                    uint32_t y0, uint32_t y1, uint32_t* vis, float* worldpos, float* depth);
+/* K1: temporalGradient.comp.glsl:104-172 */
+void oracle_temporal_gradient(const oracle_config* cfg, const oracle_push_constants* pc,
+                              const uint32_t* vis, const float* worldpos, const float* lut,
+                              const float* lut_prev, uint32_t y0, uint32_t y1, float* grad);
+/* K2: raytrace.comp.glsl:273-344.  raycount accumulates closest-hit queries; hit_id (nullable)
+ * receives the primary ray's primitive id+1 */
+void oracle_raytrace(const oracle_config* cfg, const oracle_push_constants* pc, const float* tris,
+                     uint32_t n, uint32_t y0, uint32_t y1, float* image, uint64_t* raycount,
+                     uint32_t* hit_id);
+/* K3: temporalFiltering.comp.glsl:191-265, one iteration.  `in` is the colorImage snapshot (D1),
+ * `out` receives the filtered colour (k < max) or the blend (k == max).  prev_pixel (nullable,
+ * 2 ints per pixel) receives previousPixelPos when k == max. */
+void oracle_atrous(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
+                   const float* in, const float* depth, const uint32_t* vis, const float* lut,
+                   const float* lut_prev, const float* worldpos, const float* history,
+                   uint32_t y0, uint32_t y1, float* out, int32_t* prev_pixel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
