@@ -85,7 +85,10 @@ typedef struct rtpt_visibility_data {
 } rtpt_visibility_data;
 
 /* ---- configuration: the reference's compile-time constants made explicit ---------------- */
-#define RTPT_FLAG_REDUNDANT_HALO 0x1u /* informational: host computes halo rows redundantly */
+#define RTPT_FLAG_EXACT_FILTER 0x1u /* strict-parity filter: contract exp/sqrt/div instead of the
+                                       hardware v_exp/v_sqrt/v_rcp (slower; bit-identical to the oracle) */
+#define RTPT_FLAG_FORCE_BVH 0x2u    /* traverse the BVH even for scenes small enough for the
+                                       wave-uniform brute-force path (<= 64 triangles) */
 
 typedef struct rtpt_config {
   uint32_t struct_size;          /* = sizeof(rtpt_config), ABI guard */
@@ -198,8 +201,10 @@ int rtpt_readback(rtpt_ctx* ctx, rtpt_plane which, void* dst, size_t bytes);
  * "checkpoint/resume": the only cross-frame state is PREVIOUS, PREV_VIS_ID, LUT_PREV) */
 int rtpt_set_plane(rtpt_ctx* ctx, rtpt_plane which, const void* src, size_t bytes);
 int rtpt_reset_counters(rtpt_ctx* ctx);
-/* enable/disable the debug HIT_ID plane (off by default: costs 4 B/px of stores) */
-int rtpt_enable_hit_id(rtpt_ctx* ctx, int enable);
+/* enable build-only observables (off by default: they cost extra stores per pixel) */
+#define RTPT_DEBUG_HIT_ID 0x1u     /* RTPT_PLANE_HIT_ID written by rtpt_raytrace */
+#define RTPT_DEBUG_PREV_PIXEL 0x2u /* RTPT_PLANE_PREV_PIXEL written by the final filter pass */
+int rtpt_enable_debug(rtpt_ctx* ctx, uint32_t mask);
 
 /* per-kernel timing hooks for bench.py: HIP events recorded on the stream the kernel runs on.
  * rtpt_timing_enable(1) makes every pass record a start/stop event pair; rtpt_timing_collect

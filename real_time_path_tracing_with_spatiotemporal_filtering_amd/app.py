@@ -1,0 +1,252 @@
+"""Headless Python mirror of the reference's ``PathTracingApplication`` (main.cpp:179-1529): the
+same method names, the same per-frame call order and push-constant/UBO update rules, driving the
+HIP hot path through the C ABI (``abi.Context``).  Window, swapchain and keyboard are out of
+scope; input is a scripted set of pressed keys per frame (the keys of main.cpp:1119-1168).
+
+The frame loop is written against a small *backend* protocol so that the multi-rank strip logic
+(``strips.py``) can be exercised on CPU with gloo in the tests; the product backend is
+``HipBackend`` below and nothing else ships.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .strips import StripPlan, exchange_halo
+
+FOV = 0.20                 # common.h:16
+SPEED = np.float32(0.1)    # main.cpp:68
+DEFAULT_SCENE = os.path.join(abi.PKG_DIR, "scenes", "CornellBox-Original-Merged.obj")
+
+
+def _np_dtype_to_torch(torch):
+    return {np.float32: torch.float32, np.uint32: torch.int32, np.int32: torch.int32}
+
+
+class HipBackend:
+    """abi.Context + (optionally) torch-owned colour planes so halo rows can be sent with RCCL."""
+
+    def __init__(self, width, height, plan: StripPlan | None = None, max_segments=32, flags=0, device=-1,
+                 torch_planes=False, debug_mask=0):
+        self.plan = plan or StripPlan(height, 1, 0, 1)
+        cfg = abi.config_default(width, height)
+        cfg.row_begin, cfg.row_end = self.plan.stored
+        cfg.max_segments = max_segments
+        cfg.flags = flags
+        cfg.device = device
+        self.ctx = abi.Context(cfg)
+        self.width, self.height = width, height
+        self._tensors = None
+        if debug_mask:
+            self.ctx.enable_debug(debug_mask)
+        if torch_planes:
+            import torch
+            dev = torch.device("cuda", torch.cuda.current_device())
+            rows = cfg.row_end - cfg.row_begin
+            self._tensors = [torch.zeros((rows, width, 4), dtype=torch.float32, device=dev) for _ in range(3)]
+            for role, t in zip((abi.PLANE_IMAGE, abi.PLANE_FILTERED, abi.PLANE_PREVIOUS), self._tensors):
+                self.ctx.bind_plane(role, t.data_ptr(), t.numel() * 4)
+            self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # passes ------------------------------------------------------------------------------
+    def scene_upload(self, xyz, idx, xforms=None):
+        self.ctx.scene_upload(xyz, idx, xforms)
+
+    def gbuffer(self, ubo, y0, y1):
+        self.ctx.gbuffer(ubo, y0, y1)
+
+    def temporal_gradient(self, pc, y0, y1):
+        self.ctx.temporal_gradient(pc, y0, y1)
+
+    def raytrace(self, pc, y0, y1):
+        self.ctx.raytrace(pc, y0, y1)
+
+    def temporal_filter(self, pc, ubo, y0, y1):
+        self.ctx.temporal_filter(pc, ubo, y0, y1)
+
+    def end_frame(self):
+        self.ctx.end_frame()
+
+    def sync(self):
+        self.ctx.sync()
+
+    # halo exchange support ---------------------------------------------------------------
+    def color_rows(self, plane: int, y0: int, y1: int):
+        """torch view of frame rows [y0,y1) of the buffer currently playing colour role `plane`."""
+        if self._tensors is None:
+            raise RuntimeError("HipBackend(torch_planes=True) is required for halo exchange")
+        ptr = self.ctx.plane_ptr(plane)
+        for t in self._tensors:
+            if t.data_ptr() == ptr:
+                base = self.ctx.cfg.row_begin
+                return t[y0 - base:y1 - base]
+        raise RuntimeError("colour plane is not one of the bound torch tensors")
+
+    def readback_rows(self, plane: int, y0: int, y1: int) -> np.ndarray:
+        base = self.ctx.cfg.row_begin
+        return self.ctx.readback(plane)[y0 - base:y1 - base]
+
+    def close(self):
+        self.ctx.close()
+
+
+class PathTracingApplication:
+    """main.cpp:179-1529, headless.  Method names follow the reference."""
+
+    def __init__(self, backend, width=1000, height=800, maxWaveletIteration=9, plan: StripPlan | None = None,
+                 cameraOrigin=(-0.001, 1.0, 6.0), lightPos=(1.0, 1.0, -0.4), lightColor=(0.5, 0.5, 0.5),
+                 group=None):
+        self.backend = backend
+        self.render_width, self.render_height = width, height          # main.cpp:52-53
+        self.maxWaveletIteration = maxWaveletIteration                 # main.cpp:55
+        self.plan = plan or StripPlan(height, 1, 0, maxWaveletIteration)
+        self.group = group
+        self.cameraOrigin = np.array(cameraOrigin, np.float32)         # main.cpp:65
+        self.lightPos = np.array(lightPos, np.float32)                 # main.cpp:70
+        self.lightColor = np.array(lightColor, np.float32)             # main.cpp:72
+        self.cameraMoved = False
+        self.frameCount = 0
+        self.pushConstants = abi.PushConstants()
+        self.ubo = abi.Ubo()
+        self._upload_initial_ubo()
+        self.initializeSceneConstants()
+
+    # ---- initVulkan() pieces -----------------------------------------------------------
+    def loadMesh(self, path: str = DEFAULT_SCENE):
+        """main.cpp:409-462 — objVertices / objIndices (the RT arrays)."""
+        self.objVertices, self.objIndices = abi.load_obj(path)
+        return self.objVertices, self.objIndices
+
+    def buildAccelerationStructure(self, instance_xforms=None):
+        """main.cpp:687-742 — one BLAS, identity instance unless transforms are given."""
+        self.backend.scene_upload(self.objVertices, self.objIndices, instance_xforms)
+
+    def _perspective(self):
+        proj = abi.perspective(np.float32(FOV) * 2, np.float32(self.render_width) / np.float32(self.render_height),
+                               0.1, 10.0)
+        proj[5] *= -1  # main.cpp:484
+        return proj
+
+    def _upload_initial_ubo(self):
+        """uploadBuffers main.cpp:481-489: the first view looks at (0,1,0)."""
+        u = self.ubo
+        u.model[:] = np.eye(4, dtype=np.float32).ravel()
+        u.view[:] = abi.look_at(self.cameraOrigin, (0.0, 1.0, 0.0), (0.0, 1.0, 0.0))
+        u.proj[:] = self._perspective()
+        u.modelPrev[:] = u.model[:]
+        u.viewPrev[:] = u.view[:]
+        u.projPrev[:] = u.proj[:]
+
+    def initializeSceneConstants(self):
+        """main.cpp:661-666 (lightPosPrev is a zero-initialised global at that point)."""
+        pc = self.pushConstants
+        pc.currentCameraColor[:] = self.lightColor
+        pc.lightPos[:] = self.lightPos
+        pc.lightPosPrev[:] = (0.0, 0.0, 0.0)
+
+    # ---- per frame -----------------------------------------------------------------------
+    def updateUBO(self):
+        """main.cpp:1463-1475."""
+        u = self.ubo
+        u.modelPrev[:] = u.model[:]
+        u.viewPrev[:] = u.view[:]
+        u.projPrev[:] = u.proj[:]
+        u.model[:] = np.eye(4, dtype=np.float32).ravel()
+        c = self.cameraOrigin
+        u.view[:] = abi.look_at(c, (c[0], c[1], np.float32(c[2] - np.float32(6.0))), (0.0, 1.0, 0.0))
+        u.proj[:] = self._perspective()
+
+    def updateScene(self, keys=()):
+        """main.cpp:1115-1185 with `keys` = the set of keys held this frame."""
+        keys = set(keys)
+        cam, lp = self.cameraOrigin, self.lightPos
+        for key, axis, sign in (("S", 2, +1), ("W", 2, -1), ("A", 0, -1), ("D", 0, +1), ("E", 1, +1), ("Q", 1, -1)):
+            if key in keys:
+                cam[axis] = np.float32(cam[axis] + sign * SPEED)
+                self.cameraMoved = True
+        if "I" in keys:
+            lp[2] = np.float32(lp[2] - SPEED)
+        if "K" in keys:
+            lp[2] = np.float32(lp[2] + SPEED)
+        if "L" in keys:
+            lp[0] = np.float32(lp[0] + SPEED)
+            if lp[0] > 2:
+                lp[0] = -20
+        if "J" in keys:
+            lp[0] = np.float32(lp[0] - SPEED)
+            if lp[0] < -20:
+                lp[0] = 2
+        if "O" in keys:
+            lp[1] = np.float32(lp[1] + SPEED)
+        if "U" in keys:
+            lp[1] = np.float32(lp[1] - SPEED)
+        pc = self.pushConstants
+        pc.frameNumber = self.frameCount                       # :1171
+        pc.previousCameraColor[:] = pc.currentCameraColor[:]   # :1173
+        pc.currentCameraColor[:] = self.lightColor             # :1175
+        pc.lightPosPrev[:] = pc.lightPos[:]                    # :1177
+        pc.lightPos[:] = lp                                    # :1178
+        self.updateUBO()                                       # :1180
+        if self.cameraMoved or self.frameCount == 0:           # :1181-1184
+            pc.cameraPos[:] = cam
+            self.cameraMoved = False
+
+    def drawVisbilityBuffer(self):
+        """main.cpp:1187-1199 (K0)."""
+        self.backend.gbuffer(self.ubo, *self.plan.gbuffer_rows())
+
+    def computeTemporalGradient(self):
+        """main.cpp:1201-1220 (K1)."""
+        self.backend.temporal_gradient(self.pushConstants, *self.plan.gradient_rows())
+
+    def drawSceneToImage(self):
+        """main.cpp:1222-1253 (K2), NUM_SAMPLE_BATCHES = 1."""
+        self.pushConstants.sample_batch = 0  # :1237
+        self.backend.raytrace(self.pushConstants, *self.plan.raytrace_rows())
+
+    def applyTemporalFiltering(self):
+        """main.cpp:1255-1306: k = 1..N, ping-pong by parity; one ABI call per iteration."""
+        pc = self.pushConstants
+        pc.maxWaveletIteration = self.maxWaveletIteration  # :1258
+        for k in range(1, self.maxWaveletIteration + 1):   # :1259
+            pc.waveletIteration = k
+            if self.plan.world > 1 and self.plan.mode == "exchange":
+                in_plane = abi.PLANE_IMAGE if (k & 1) else abi.PLANE_FILTERED
+                exchange_halo(self.plan, k, lambda a, b: self.backend.color_rows(in_plane, a, b), self.group)
+            self.backend.temporal_filter(pc, self.ubo, *self.plan.filter_rows(k))
+
+    def copyImageToSwapChainsCurrentImage(self):
+        """main.cpp:1308-1406 minus the swapchain: the history hand-over (:1364-1372)."""
+        self.backend.end_frame()
+
+    def drawScene(self, keys=()):
+        """main.cpp:1090-1113."""
+        self.updateScene(keys)
+        self.drawVisbilityBuffer()
+        self.computeTemporalGradient()
+        self.drawSceneToImage()
+        self.applyTemporalFiltering()
+        self.copyImageToSwapChainsCurrentImage()
+        self.frameCount += 1
+
+    def run(self, frames: int, script=None):
+        """mainLoop (main.cpp:301) for a fixed number of frames; script[f] = keys held on frame f."""
+        for f in range(frames):
+            self.drawScene(script[f] if script and f < len(script) else ())
+
+
+def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode="exchange", flags=0,
+             torch_planes=None, debug_mask=0, scene=DEFAULT_SCENE, instance_xforms=None, group=None, **app_kw):
+    """createBuffers + loadMesh + buildAccelerationStructure for one rank."""
+    plan = StripPlan(height, world, rank, iterations, mode)
+    if torch_planes is None:
+        torch_planes = world > 1 and mode == "exchange"
+    be = HipBackend(width, height, plan, max_segments=max_segments, flags=flags, torch_planes=torch_planes,
+                    debug_mask=debug_mask)
+    app = PathTracingApplication(be, width, height, iterations, plan, group=group, **app_kw)
+    app.loadMesh(scene)
+    app.buildAccelerationStructure(instance_xforms)
+    return app

@@ -1,0 +1,879 @@
+// api.hip — the C ABI of include/rtpt.h: context, plane roles, scene upload, one entry point per
+// reference dispatch.  Host code only (compiled by hipcc together with kernels.hip).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rtpt.h"
+#include "bvh.hpp"
+#include "kernels.hpp"
+#include "rtpt_math.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                 \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return fail(RTPT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+struct Buf {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  bool owned = false;
+};
+
+enum ColorRole { ROLE_IMAGE = 0, ROLE_FILTERED = 1, ROLE_PREVIOUS = 2 };
+
+struct TimedLaunch {
+  int kernel;
+  hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct rtpt_ctx {
+  rtpt_config cfg;
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+
+  Buf color[3];          // physical RGBA32F buffers
+  int color_of_role[3];  // role -> physical index
+  Buf vis[2];
+  int vis_cur = 0;  // vis[vis_cur] = VIS_ID, the other PREV_VIS_ID
+  Buf lut[2];
+  int lut_cur = 0;
+  Buf worldpos, gradient, depth, prev_pixel, hit_id, raycount, normal_tab;
+
+  // scene
+  uint32_t n_tris = 0;
+  Buf tris, leaf_order, isect_id, isect_leaf, shade, nodes;
+  bool use_bvh = false;
+  int bvh_depth = 0;
+
+  // frame state
+  bool lut_prev_valid = false;   // D3
+  bool final_swapped = false;    // the final filter pass already rotated IMAGE <-> FILTERED this frame
+  bool image_alias = false;      // between rtpt_end_frame and the next rtpt_raytrace IMAGE reads as PREVIOUS
+  int hist_y0 = 0, hist_y1 = 0;  // rows of PREVIOUS holding a valid previous frame
+  int final_y0 = 0, final_y1 = 0;
+  uint32_t debug_mask = 0;
+
+  // timing
+  bool timing = false;
+  std::vector<TimedLaunch> timed;
+  std::vector<hipEvent_t> event_pool;
+
+  uint32_t rows() const { return cfg.row_end - cfg.row_begin; }
+  size_t pixels() const { return static_cast<size_t>(rows()) * cfg.width; }
+};
+
+namespace {
+
+int alloc_buf(Buf& b, size_t bytes) {
+  if (b.owned && b.ptr) (void)hipFree(b.ptr);
+  b = Buf{};
+  if (bytes == 0) return RTPT_OK;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return fail(RTPT_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  b.ptr = p;
+  b.bytes = bytes;
+  b.owned = true;
+  return RTPT_OK;
+}
+
+void free_buf(Buf& b) {
+  if (b.owned && b.ptr) (void)hipFree(b.ptr);
+  b = Buf{};
+}
+
+Buf* plane_buf(rtpt_ctx* c, rtpt_plane which) {
+  switch (which) {
+    case RTPT_PLANE_IMAGE: return &c->color[c->color_of_role[ROLE_IMAGE]];
+    case RTPT_PLANE_FILTERED: return &c->color[c->color_of_role[ROLE_FILTERED]];
+    case RTPT_PLANE_PREVIOUS: return &c->color[c->color_of_role[ROLE_PREVIOUS]];
+    case RTPT_PLANE_WORLDPOS: return &c->worldpos;
+    case RTPT_PLANE_GRADIENT: return &c->gradient;
+    case RTPT_PLANE_DEPTH: return &c->depth;
+    case RTPT_PLANE_VIS_ID: return &c->vis[c->vis_cur];
+    case RTPT_PLANE_PREV_VIS_ID: return &c->vis[c->vis_cur ^ 1];
+    case RTPT_PLANE_LUT: return &c->lut[c->lut_cur];
+    case RTPT_PLANE_LUT_PREV: return &c->lut[c->lut_cur ^ 1];
+    case RTPT_PLANE_PREV_PIXEL: return &c->prev_pixel;
+    case RTPT_PLANE_RAYCOUNT: return &c->raycount;
+    case RTPT_PLANE_HIT_ID: return &c->hit_id;
+    default: return nullptr;
+  }
+}
+
+size_t plane_size(const rtpt_ctx* c, rtpt_plane which) {
+  const size_t px = c->pixels();
+  switch (which) {
+    case RTPT_PLANE_IMAGE:
+    case RTPT_PLANE_FILTERED:
+    case RTPT_PLANE_PREVIOUS:
+    case RTPT_PLANE_WORLDPOS:
+    case RTPT_PLANE_GRADIENT: return px * 16;
+    case RTPT_PLANE_DEPTH:
+    case RTPT_PLANE_VIS_ID:
+    case RTPT_PLANE_PREV_VIS_ID:
+    case RTPT_PLANE_HIT_ID: return px * 4;
+    case RTPT_PLANE_PREV_PIXEL: return px * 8;
+    case RTPT_PLANE_LUT:
+    case RTPT_PLANE_LUT_PREV: return (static_cast<size_t>(c->n_tris) + 1) * sizeof(rtpt_visibility_data);
+    case RTPT_PLANE_RAYCOUNT: return 8;
+    default: return 0;
+  }
+}
+
+struct Timer {
+  rtpt_ctx* c;
+  bool on;
+  TimedLaunch t;
+  Timer(rtpt_ctx* ctx, int kernel) : c(ctx), on(ctx->timing) {
+    if (!on) return;
+    t.kernel = kernel;
+    for (hipEvent_t* e : {&t.start, &t.stop}) {
+      if (!c->event_pool.empty()) {
+        *e = c->event_pool.back();
+        c->event_pool.pop_back();
+      } else if (hipEventCreate(e) != hipSuccess) {
+        on = false;
+        return;
+      }
+    }
+    (void)hipEventRecord(t.start, c->stream);
+  }
+  ~Timer() {
+    if (!on) return;
+    (void)hipEventRecord(t.stop, c->stream);
+    c->timed.push_back(t);
+  }
+};
+
+int check_rows(const rtpt_ctx* c, uint32_t& y0, uint32_t& y1) {
+  if (y0 == 0 && y1 == 0) {
+    y0 = c->cfg.row_begin;
+    y1 = c->cfg.row_end;
+  }
+  if (y0 > y1 || y0 < c->cfg.row_begin || y1 > c->cfg.row_end)
+    return fail(RTPT_E_INVALID, "row range [" + std::to_string(y0) + "," + std::to_string(y1) + ") outside stored rows [" +
+                                    std::to_string(c->cfg.row_begin) + "," + std::to_string(c->cfg.row_end) + ")");
+  return RTPT_OK;
+}
+
+rt::FrameGeom geom(const rtpt_ctx* c, uint32_t y0, uint32_t y1) {
+  rt::FrameGeom g;
+  g.W = static_cast<int32_t>(c->cfg.width);
+  g.H = static_cast<int32_t>(c->cfg.height);
+  g.row_base = static_cast<int32_t>(c->cfg.row_begin);
+  g.y0 = static_cast<int32_t>(y0);
+  g.y1 = static_cast<int32_t>(y1);
+  return g;
+}
+
+rt::SceneView scene_view(const rtpt_ctx* c) {
+  rt::SceneView s;
+  s.isect_id = static_cast<const float4*>(c->isect_id.ptr);
+  s.isect_leaf = static_cast<const float4*>(c->isect_leaf.ptr);
+  s.shade = static_cast<const float4*>(c->shade.ptr);
+  s.nodes = static_cast<const rt::BvhNode*>(c->nodes.ptr);
+  s.n_tris = c->n_tris;
+  s.use_bvh = c->use_bvh ? 1u : 0u;
+  return s;
+}
+
+bool is_identity(const float* m) {
+  for (int i = 0; i < 16; i++)
+    if (m[i] != ((i % 5 == 0) ? 1.0f : 0.0f)) return false;
+  return true;
+}
+
+int launch_check(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RTPT_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+  return RTPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtpt_last_error(const rtpt_ctx*) { return g_err.c_str(); }
+
+int rtpt_config_default(rtpt_config* cfg, uint32_t width, uint32_t height) {
+  if (!cfg) return fail(RTPT_E_INVALID, "cfg is NULL");
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->struct_size = sizeof(rtpt_config);
+  cfg->width = width;
+  cfg->height = height;
+  cfg->row_begin = 0;
+  cfg->row_end = height;
+  cfg->max_segments = 32;              // raytrace.comp.glsl:204
+  cfg->samples_per_pixel = 1;          // raytrace.comp.glsl:306
+  cfg->sigma_n = 128;                  // temporalFiltering.comp.glsl:203
+  cfg->sigma_z = 1.0f;                 // :204
+  cfg->sigma_l = 4.0f;                 // :205
+  cfg->alpha = 0.3f;                   // :243
+  cfg->light_radius = 0.20f;           // raytrace.comp.glsl:280
+  cfg->light_intensity = 30.0f;        // :281
+  cfg->first_hit_light_divisor = 5.0f; // :229
+  cfg->fov_slope = 0.20271003f;        // tan(FOV = 0.20), common.h:16 / raytrace.comp.glsl:300
+  cfg->pixel_jitter = 0.375f;          // :314
+  cfg->ray_offset = 0.0001f;           // :250
+  cfg->ray_tmax = 10000.0f;            // :216
+  cfg->flags = 0;
+  cfg->device = -1;
+  return RTPT_OK;
+}
+
+int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
+  if (!cfg || !out) return fail(RTPT_E_INVALID, "NULL argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(rtpt_config)) return fail(RTPT_E_INVALID, "rtpt_config.struct_size mismatch (ABI)");
+  if (cfg->width == 0 || cfg->height == 0 || cfg->row_begin >= cfg->row_end || cfg->row_end > cfg->height)
+    return fail(RTPT_E_INVALID, "bad frame / row range");
+  if (cfg->max_segments == 0 || cfg->samples_per_pixel == 0 || cfg->sigma_n < 1)
+    return fail(RTPT_E_INVALID, "max_segments, samples_per_pixel and sigma_n must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return fail(RTPT_E_NO_GPU, "no HIP device visible; this library has no CPU fallback");
+  }
+  int dev = cfg->device;
+  if (dev < 0) {
+    HIP_TRY(hipGetDevice(&dev));
+  } else {
+    if (dev >= ndev) return fail(RTPT_E_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(dev));
+  }
+  rtpt_ctx* c = new (std::nothrow) rtpt_ctx();
+  if (!c) return fail(RTPT_E_NOMEM, "host allocation failed");
+  c->cfg = *cfg;
+  c->device = dev;
+  for (int i = 0; i < 3; i++) c->color_of_role[i] = i;
+  hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(RTPT_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  }
+  c->stream = c->own_stream;
+  const size_t px = c->pixels();
+  int rc = RTPT_OK;
+  for (int i = 0; i < 3 && rc == RTPT_OK; i++) rc = alloc_buf(c->color[i], px * 16);
+  for (int i = 0; i < 2 && rc == RTPT_OK; i++) rc = alloc_buf(c->vis[i], px * 4);
+  if (rc == RTPT_OK) rc = alloc_buf(c->worldpos, px * 16);
+  if (rc == RTPT_OK) rc = alloc_buf(c->gradient, px * 16);
+  if (rc == RTPT_OK) rc = alloc_buf(c->depth, px * 4);
+  if (rc == RTPT_OK) rc = alloc_buf(c->raycount, 8);
+  if (rc != RTPT_OK) {
+    rtpt_destroy(c);
+    return rc;
+  }
+  // Vulkan images start undefined; zero them so readback before the first frame is defined
+  for (int i = 0; i < 3; i++) (void)hipMemsetAsync(c->color[i].ptr, 0, px * 16, c->stream);
+  for (int i = 0; i < 2; i++) (void)hipMemsetAsync(c->vis[i].ptr, 0, px * 4, c->stream);
+  (void)hipMemsetAsync(c->worldpos.ptr, 0, px * 16, c->stream);
+  (void)hipMemsetAsync(c->gradient.ptr, 0, px * 16, c->stream);
+  (void)hipMemsetAsync(c->depth.ptr, 0, px * 4, c->stream);
+  (void)hipMemsetAsync(c->raycount.ptr, 0, 8, c->stream);
+  e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
+    rtpt_destroy(c);
+    return fail(RTPT_E_DEVICE, std::string("initial clear: ") + hipGetErrorString(e));
+  }
+  *out = c;
+  return RTPT_OK;
+}
+
+int rtpt_destroy(rtpt_ctx* c) {
+  if (!c) return RTPT_OK;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  for (auto& t : c->timed) {
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  for (auto& e : c->event_pool) (void)hipEventDestroy(e);
+  for (auto& b : c->color) free_buf(b);
+  for (auto& b : c->vis) free_buf(b);
+  for (auto& b : c->lut) free_buf(b);
+  for (Buf* b : {&c->worldpos, &c->gradient, &c->depth, &c->prev_pixel, &c->hit_id, &c->raycount, &c->normal_tab, &c->tris,
+                 &c->leaf_order, &c->isect_id, &c->isect_leaf, &c->shade, &c->nodes})
+    free_buf(*b);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return RTPT_OK;
+}
+
+int rtpt_set_stream(rtpt_ctx* c, void* hip_stream) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return RTPT_OK;
+}
+
+int rtpt_plane_bytes(const rtpt_ctx* c, rtpt_plane which, size_t* bytes) {
+  if (!c || !bytes) return fail(RTPT_E_INVALID, "NULL argument");
+  if (which < 0 || which >= RTPT_PLANE_COUNT) return fail(RTPT_E_INVALID, "unknown plane");
+  *bytes = plane_size(c, which);
+  return RTPT_OK;
+}
+
+int rtpt_plane_ptr(rtpt_ctx* c, rtpt_plane which, void** device_ptr) {
+  if (!c || !device_ptr) return fail(RTPT_E_INVALID, "NULL argument");
+  Buf* b = plane_buf(c, which);
+  if (!b) return fail(RTPT_E_INVALID, "unknown plane");
+  *device_ptr = b->ptr;
+  return RTPT_OK;
+}
+
+int rtpt_bind_plane(rtpt_ctx* c, rtpt_plane which, void* device_ptr, size_t bytes) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  Buf* b = plane_buf(c, which);
+  if (!b || which == RTPT_PLANE_RAYCOUNT || which == RTPT_PLANE_LUT || which == RTPT_PLANE_LUT_PREV)
+    return fail(RTPT_E_INVALID, "plane cannot be bound");
+  const size_t need = plane_size(c, which);
+  if (device_ptr == nullptr) {
+    if (b->owned) return RTPT_OK;
+    return alloc_buf(*b, need);
+  }
+  if (bytes < need) return fail(RTPT_E_INVALID, "bound buffer too small");
+  if ((reinterpret_cast<uintptr_t>(device_ptr) & 15u) != 0) return fail(RTPT_E_INVALID, "bound buffer must be 16-byte aligned");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  free_buf(*b);
+  b->ptr = device_ptr;
+  b->bytes = bytes;
+  b->owned = false;
+  return RTPT_OK;
+}
+
+int rtpt_enable_debug(rtpt_ctx* c, uint32_t mask) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  if ((mask & RTPT_DEBUG_HIT_ID) && !c->hit_id.ptr) {
+    int rc = alloc_buf(c->hit_id, c->pixels() * 4);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->hit_id.ptr, 0, c->pixels() * 4, c->stream));
+  }
+  if ((mask & RTPT_DEBUG_PREV_PIXEL) && !c->prev_pixel.ptr) {
+    int rc = alloc_buf(c->prev_pixel, c->pixels() * 8);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->prev_pixel.ptr, 0, c->pixels() * 8, c->stream));
+  }
+  c->debug_mask = mask;
+  return RTPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ scene
+int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uint32_t* idx, uint32_t n_tris,
+                      const float* xf, uint32_t n_instances) {
+  if (!c || !xyz || !idx) return fail(RTPT_E_INVALID, "NULL argument");
+  if (n_tris == 0 || n_verts == 0) return fail(RTPT_E_INVALID, "empty mesh");
+  for (uint32_t i = 0; i < 3 * n_tris; i++)
+    if (idx[i] >= n_verts) return fail(RTPT_E_INVALID, "index out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  const uint32_t ni = (xf && n_instances) ? n_instances : 1;
+  const uint64_t total64 = static_cast<uint64_t>(ni) * n_tris;
+  if (total64 >= 0xFFFFFFF0ull) return fail(RTPT_E_INVALID, "too many triangles");
+  const uint32_t total = static_cast<uint32_t>(total64);
+  // flattened world-space triangle soup, id = instance * n_tris + t  (one identity instance in the
+  // reference, main.cpp:728-741)
+  std::vector<float> tris(static_cast<size_t>(total) * 9);
+  for (uint32_t inst = 0; inst < ni; inst++)
+    for (uint32_t t = 0; t < n_tris; t++)
+      for (int k = 0; k < 3; k++) {
+        const float* v = xyz + 3 * static_cast<size_t>(idx[3 * t + k]);
+        float* o = tris.data() + 9 * (static_cast<size_t>(inst) * n_tris + t) + 3 * k;
+        if (xf && n_instances) {
+          const float* m = xf + 12 * static_cast<size_t>(inst);
+          for (int r = 0; r < 3; r++)
+            o[r] = rt::fmaf_(m[4 * r + 2], v[2], rt::fmaf_(m[4 * r + 1], v[1], m[4 * r] * v[0])) + m[4 * r + 3];
+        } else {
+          o[0] = v[0];
+          o[1] = v[1];
+          o[2] = v[2];
+        }
+      }
+  rt::Bvh bvh;
+  rt::build_bvh(tris.data(), total, bvh);
+  if (bvh.max_depth >= rt::kBvhMaxDepth) return fail(RTPT_E_INVALID, "BVH deeper than the traversal stack");
+  if (bvh.leaf_order.size() != total) return fail(RTPT_E_INVALID, "internal: BVH lost triangles");
+
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int rc;
+  if ((rc = alloc_buf(c->tris, tris.size() * sizeof(float)))) return rc;
+  if ((rc = alloc_buf(c->leaf_order, static_cast<size_t>(total) * 4))) return rc;
+  if ((rc = alloc_buf(c->isect_id, static_cast<size_t>(total) * 48))) return rc;
+  if ((rc = alloc_buf(c->isect_leaf, static_cast<size_t>(total) * 48))) return rc;
+  if ((rc = alloc_buf(c->shade, static_cast<size_t>(total) * 48))) return rc;
+  if ((rc = alloc_buf(c->nodes, bvh.nodes.size() * sizeof(rt::BvhNode)))) return rc;
+  if ((rc = alloc_buf(c->normal_tab, (static_cast<size_t>(total) + 1) * 16))) return rc;
+  for (int i = 0; i < 2; i++)
+    if ((rc = alloc_buf(c->lut[i], (static_cast<size_t>(total) + 1) * sizeof(rtpt_visibility_data)))) return rc;
+  HIP_TRY(hipMemcpyAsync(c->tris.ptr, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->leaf_order.ptr, bvh.leaf_order.data(), static_cast<size_t>(total) * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->nodes.ptr, bvh.nodes.data(), bvh.nodes.size() * sizeof(rt::BvhNode), hipMemcpyHostToDevice, c->stream));
+  for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(c->lut[i].ptr, 0, c->lut[i].bytes, c->stream));
+  rt::ScenePrepArgs sp;
+  sp.n_tris = total;
+  sp.tris = static_cast<const float*>(c->tris.ptr);
+  sp.leaf_order = static_cast<const uint32_t*>(c->leaf_order.ptr);
+  sp.isect_id = static_cast<float4*>(c->isect_id.ptr);
+  sp.isect_leaf = static_cast<float4*>(c->isect_leaf.ptr);
+  sp.shade = static_cast<float4*>(c->shade.ptr);
+  rt::launch_scene_prepare(sp, c->stream);
+  if ((rc = launch_check("scene_prepare"))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // host staging vectors die at return
+  c->n_tris = total;
+  c->use_bvh = (total > 64) || (c->cfg.flags & RTPT_FLAG_FORCE_BVH);
+  c->bvh_depth = bvh.max_depth;
+  c->lut_prev_valid = false;
+  return RTPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ K0
+int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
+  if (!c || !ubo) return fail(RTPT_E_INVALID, "NULL argument");
+  if (!c->n_tris) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");
+  int rc = check_rows(c, y0, y1);
+  if (rc) return rc;
+  if (!is_identity(ubo->model))
+    return fail(RTPT_E_INVALID, "ubo.model must be identity (the reference's is, main.cpp:1469; animated models are out of scope)");
+  HIP_TRY(hipSetDevice(c->device));
+  {
+    Timer tm(c, RTPT_K_LUT);
+    rt::LutArgs la;
+    la.n_tris = c->n_tris;
+    la.shade = static_cast<const float4*>(c->shade.ptr);
+    std::memcpy(la.model, ubo->model, sizeof la.model);
+    la.lut = static_cast<float4*>(c->lut[c->lut_cur].ptr);
+    la.normal_tab = static_cast<float4*>(c->normal_tab.ptr);
+    la.sigma_n = c->cfg.sigma_n;
+    rt::launch_lut(la, c->stream);
+  }
+  if ((rc = launch_check("lut"))) return rc;
+  if (!c->lut_prev_valid) {
+    // D3: visibilityLUTprevious is read during frame 0 before anything wrote it; define it as LUT
+    HIP_TRY(hipMemcpyAsync(c->lut[c->lut_cur ^ 1].ptr, c->lut[c->lut_cur].ptr, c->lut[c->lut_cur].bytes, hipMemcpyDeviceToDevice,
+                           c->stream));
+    c->lut_prev_valid = true;
+  }
+  rt::GbufferArgs a;
+  a.g = geom(c, y0, y1);
+  a.scene = scene_view(c);
+  const float* V = ubo->view;
+  rt::f3 tcol{V[12], V[13], V[14]};
+  rt::f3 c0{V[0], V[1], V[2]}, c1{V[4], V[5], V[6]}, c2{V[8], V[9], V[10]};
+  a.org[0] = -rt::exact::dot(c0, tcol);
+  a.org[1] = -rt::exact::dot(c1, tcol);
+  a.org[2] = -rt::exact::dot(c2, tcol);
+  a.c0[0] = c0.x; a.c0[1] = c0.y; a.c0[2] = c0.z;
+  a.c1[0] = c1.x; a.c1[1] = c1.y; a.c1[2] = c1.z;
+  a.c2[0] = c2.x; a.c2[1] = c2.y; a.c2[2] = c2.z;
+  a.p00 = ubo->proj[0];
+  a.p11 = ubo->proj[5];
+  rt::exact::mat_mul(ubo->proj, ubo->view, a.PV);
+  a.tmax = c->cfg.ray_tmax;
+  a.vis = static_cast<uint32_t*>(c->vis[c->vis_cur].ptr);
+  a.worldpos = static_cast<float4*>(c->worldpos.ptr);
+  a.depth = static_cast<float*>(c->depth.ptr);
+  {
+    Timer tm(c, RTPT_K_GBUFFER);
+    rt::launch_gbuffer(a, c->stream);
+  }
+  return launch_check("gbuffer");
+}
+
+// ------------------------------------------------------------------------------------------ K1
+int rtpt_temporal_gradient(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint32_t y1) {
+  if (!c || !pc) return fail(RTPT_E_INVALID, "NULL argument");
+  if (!c->n_tris) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");
+  int rc = check_rows(c, y0, y1);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  rt::GradientArgs a;
+  a.g = geom(c, y0, y1);
+  for (int i = 0; i < 3; i++) {
+    a.cam[i] = pc->cameraPos[i];
+    a.light[i] = pc->lightPos[i];
+    a.light_prev[i] = pc->lightPosPrev[i];
+    a.color[i] = pc->currentCameraColor[i];
+    a.color_prev[i] = pc->previousCameraColor[i];
+  }
+  a.vis = static_cast<const uint32_t*>(c->vis[c->vis_cur].ptr);
+  a.worldpos = static_cast<const float4*>(c->worldpos.ptr);
+  a.lut = static_cast<const float4*>(c->lut[c->lut_cur].ptr);
+  a.lut_prev = static_cast<const float4*>(c->lut[c->lut_cur ^ 1].ptr);
+  a.grad = static_cast<float4*>(c->gradient.ptr);
+  {
+    Timer tm(c, RTPT_K_GRADIENT);
+    rt::launch_gradient(a, c->stream);
+  }
+  return launch_check("temporal_gradient");
+}
+
+// ------------------------------------------------------------------------------------------ K2
+int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint32_t y1) {
+  if (!c || !pc) return fail(RTPT_E_INVALID, "NULL argument");
+  if (!c->n_tris) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");
+  int rc = check_rows(c, y0, y1);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  rt::PathtraceArgs a;
+  a.g = geom(c, y0, y1);
+  a.scene = scene_view(c);
+  a.frame = pc->frameNumber;
+  a.batch = pc->sample_batch;
+  a.max_segments = c->cfg.max_segments;
+  a.spp = c->cfg.samples_per_pixel;
+  for (int i = 0; i < 3; i++) {
+    a.cam[i] = pc->cameraPos[i];
+    a.light_c[i] = pc->lightPos[i];                                          // raytrace.comp.glsl:279
+    a.light_col[i] = pc->currentCameraColor[i] * c->cfg.light_intensity;     // :281
+    a.light_col_first[i] = a.light_col[i] / c->cfg.first_hit_light_divisor;  // :229
+  }
+  a.light_r2 = c->cfg.light_radius * c->cfg.light_radius;  // :173
+  a.slope = c->cfg.fov_slope;
+  a.jitter = c->cfg.pixel_jitter;
+  a.ray_offset = c->cfg.ray_offset;
+  a.tmax = c->cfg.ray_tmax;
+  a.image = static_cast<float4*>(c->color[c->color_of_role[ROLE_IMAGE]].ptr);
+  a.hit_id = (c->debug_mask & RTPT_DEBUG_HIT_ID) ? static_cast<uint32_t*>(c->hit_id.ptr) : nullptr;
+  a.raycount = static_cast<unsigned long long*>(c->raycount.ptr);
+  c->final_swapped = false;
+  c->image_alias = false;
+  {
+    Timer tm(c, RTPT_K_PATHTRACE);
+    rt::launch_pathtrace(a, c->stream);
+  }
+  return launch_check("raytrace");
+}
+
+// ------------------------------------------------------------------------------------------ K3
+int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
+  if (!c || !pc) return fail(RTPT_E_INVALID, "NULL argument");
+  if (!c->n_tris) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");
+  int rc = check_rows(c, y0, y1);
+  if (rc) return rc;
+  const int k = pc->waveletIteration, max_it = pc->maxWaveletIteration;
+  if (k < 1 || max_it < 1 || k > max_it) return fail(RTPT_E_INVALID, "need 1 <= waveletIteration <= maxWaveletIteration");
+  // taps reach rows y +- k (clamped to the frame, temporalFiltering.comp.glsl:135-136): they must be stored here
+  {
+    const int64_t lo = std::max<int64_t>(0, static_cast<int64_t>(y0) - k);
+    const int64_t hi = std::min<int64_t>(c->cfg.height, static_cast<int64_t>(y1) + k);
+    if (y1 > y0 && (lo < c->cfg.row_begin || hi > c->cfg.row_end))
+      return fail(RTPT_E_INVALID, "filter taps at stride " + std::to_string(k) + " leave the stored rows (missing halo)");
+  }
+  // main.cpp:1264-1281: odd k reads `image`, writes `filteredImageBuffer`; even k the reverse.
+  // An even final pass blends into a buffer nothing reads (main.cpp:55 "must be an odd number"),
+  // so only an odd final pass is a FINAL launch.
+  const bool final_pass = (k == max_it) && (k & 1);
+  if (final_pass && !ubo) return fail(RTPT_E_INVALID, "the final pass needs the UBO (viewPrev/projPrev)");
+  HIP_TRY(hipSetDevice(c->device));
+  int in_role = (k & 1) ? ROLE_IMAGE : ROLE_FILTERED;
+  int out_role = (k & 1) ? ROLE_FILTERED : ROLE_IMAGE;
+  if (final_pass && c->final_swapped) std::swap(in_role, out_role);  // a second row range of the same final pass
+  rt::AtrousArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.g = geom(c, y0, y1);
+  a.k = k;
+  a.exact = (c->cfg.flags & RTPT_FLAG_EXACT_FILTER) ? 1 : 0;
+  a.sigma_n = c->cfg.sigma_n;
+  a.sigma_z = c->cfg.sigma_z;
+  a.sigma_l = c->cfg.sigma_l;
+  a.inv_sigma_z = 1.0f / c->cfg.sigma_z;
+  a.inv_sigma_l = 1.0f / c->cfg.sigma_l;
+  a.in = static_cast<const float4*>(c->color[c->color_of_role[in_role]].ptr);
+  a.out = static_cast<float4*>(c->color[c->color_of_role[out_role]].ptr);
+  a.depth = static_cast<const float*>(c->depth.ptr);
+  a.vis = static_cast<const uint32_t*>(c->vis[c->vis_cur].ptr);
+  a.normal_tab = static_cast<const float4*>(c->normal_tab.ptr);
+  if (final_pass) {
+    a.frame = pc->frameNumber;
+    a.alpha = c->cfg.alpha;
+    a.worldpos = static_cast<const float4*>(c->worldpos.ptr);
+    a.history = static_cast<const float4*>(c->color[c->color_of_role[ROLE_PREVIOUS]].ptr);
+    a.lut_prev = static_cast<const float4*>(c->lut[c->lut_cur ^ 1].ptr);
+    rt::exact::mat_mul(ubo->projPrev, ubo->viewPrev, a.PVprev);  // temporalFiltering.comp.glsl:180
+    a.prev_pixel = (c->debug_mask & RTPT_DEBUG_PREV_PIXEL) ? static_cast<int2*>(c->prev_pixel.ptr) : nullptr;
+    a.hist_row_base = static_cast<int32_t>(c->cfg.row_begin);
+    a.hist_y0 = c->hist_y0;
+    a.hist_y1 = c->hist_y1;
+  }
+  {
+    Timer tm(c, final_pass ? RTPT_K_ATROUS_FINAL : RTPT_K_ATROUS);
+    rt::launch_atrous(a, final_pass, c->stream);
+  }
+  if ((rc = launch_check("temporal_filter"))) return rc;
+  if (final_pass) {
+    if (!c->final_swapped) {
+      // D1: the blend went to a distinct buffer, which now becomes `image`
+      std::swap(c->color_of_role[ROLE_IMAGE], c->color_of_role[ROLE_FILTERED]);
+      c->final_swapped = true;
+      c->final_y0 = static_cast<int>(y0);
+      c->final_y1 = static_cast<int>(y1);
+    } else {
+      c->final_y0 = std::min(c->final_y0, static_cast<int>(y0));
+      c->final_y1 = std::max(c->final_y1, static_cast<int>(y1));
+    }
+  } else if (k == max_it) {
+    c->final_y0 = static_cast<int>(y0);
+    c->final_y1 = static_cast<int>(y1);
+  }
+  return RTPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ K4
+int rtpt_end_frame(rtpt_ctx* c) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  // main.cpp:1364 image -> previousImage: rotate roles instead of blitting.  After the reference's
+  // copy both images hold the same pixels; here IMAGE now names the old history buffer (about to be
+  // overwritten by the next rtpt_raytrace), so until then rtpt_readback(IMAGE) is served from
+  // PREVIOUS (image_alias).
+  std::swap(c->color_of_role[ROLE_IMAGE], c->color_of_role[ROLE_PREVIOUS]);
+  c->image_alias = true;
+  c->hist_y0 = c->final_y0;
+  c->hist_y1 = c->final_y1;
+  // main.cpp:1367 visibilityBuffer -> previousVisibilityBuffer; main.cpp:1372 LUT -> LUTprev
+  c->vis_cur ^= 1;
+  c->lut_cur ^= 1;
+  c->lut_prev_valid = c->n_tris != 0;
+  c->final_swapped = false;
+  return RTPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ sync / copies
+int rtpt_sync(rtpt_ctx* c) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTPT_OK;
+}
+
+int rtpt_readback(rtpt_ctx* c, rtpt_plane which, void* dst, size_t bytes) {
+  if (!c || !dst) return fail(RTPT_E_INVALID, "NULL argument");
+  Buf* b = plane_buf(c, (which == RTPT_PLANE_IMAGE && c->image_alias) ? RTPT_PLANE_PREVIOUS : which);
+  if (!b) return fail(RTPT_E_INVALID, "unknown plane");
+  if (!b->ptr) return fail(RTPT_E_INVALID, "plane not allocated (scene not uploaded / debug plane not enabled)");
+  const size_t need = plane_size(c, which);
+  if (bytes < need) return fail(RTPT_E_INVALID, "destination too small");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(dst, b->ptr, need, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTPT_OK;
+}
+
+int rtpt_set_plane(rtpt_ctx* c, rtpt_plane which, const void* src, size_t bytes) {
+  if (!c || !src) return fail(RTPT_E_INVALID, "NULL argument");
+  Buf* b = plane_buf(c, which);
+  if (!b) return fail(RTPT_E_INVALID, "unknown plane");
+  if (!b->ptr) return fail(RTPT_E_INVALID, "plane not allocated (scene not uploaded / debug plane not enabled)");
+  const size_t need = plane_size(c, which);
+  if (bytes < need) return fail(RTPT_E_INVALID, "source too small");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(b->ptr, src, need, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (which == RTPT_PLANE_PREVIOUS) {
+    c->hist_y0 = static_cast<int>(c->cfg.row_begin);
+    c->hist_y1 = static_cast<int>(c->cfg.row_end);
+  }
+  if (which == RTPT_PLANE_LUT_PREV) c->lut_prev_valid = true;
+  return RTPT_OK;
+}
+
+int rtpt_reset_counters(rtpt_ctx* c) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemsetAsync(c->raycount.ptr, 0, 8, c->stream));
+  return RTPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ timing
+int rtpt_timing_enable(rtpt_ctx* c, int enable) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  c->timing = enable != 0;
+  return RTPT_OK;
+}
+
+int rtpt_timing_collect(rtpt_ctx* c, double ms_sum[RTPT_K_COUNT], uint32_t launches[RTPT_K_COUNT]) {
+  if (!c || !ms_sum || !launches) return fail(RTPT_E_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < RTPT_K_COUNT; i++) {
+    ms_sum[i] = 0.0;
+    launches[i] = 0;
+  }
+  for (auto& t : c->timed) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+      ms_sum[t.kernel] += ms;
+      launches[t.kernel]++;
+    }
+    c->event_pool.push_back(t.start);
+    c->event_pool.push_back(t.stop);
+  }
+  c->timed.clear();
+  return RTPT_OK;
+}
+
+const char* rtpt_kernel_name(rtpt_kernel_id k) {
+  switch (k) {
+    case RTPT_K_GBUFFER: return "k_gbuffer";
+    case RTPT_K_LUT: return "k_lut";
+    case RTPT_K_GRADIENT: return "k_gradient";
+    case RTPT_K_PATHTRACE: return "k_pathtrace";
+    case RTPT_K_ATROUS: return "k_atrous";
+    case RTPT_K_ATROUS_FINAL: return "k_atrous_final";
+    default: return "?";
+  }
+}
+
+// ------------------------------------------------------------------------------------------ self tests
+int rtpt_selftest_math(rtpt_ctx* c, int op, const float* in, float* out, size_t n) {
+  if (!c || !in || !out) return fail(RTPT_E_INVALID, "NULL argument");
+  if (n == 0) return RTPT_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  float *din = nullptr, *dout = nullptr;
+  HIP_TRY(hipMalloc(&din, n * 4));
+  if (hipMalloc(&dout, n * 4) != hipSuccess) {
+    (void)hipFree(din);
+    return fail(RTPT_E_NOMEM, "hipMalloc");
+  }
+  hipError_t e = hipMemcpyAsync(din, in, n * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    rt::launch_selftest_math(op, din, dout, n, c->stream);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(din);
+  (void)hipFree(dout);
+  if (e != hipSuccess) return fail(RTPT_E_DEVICE, std::string("selftest_math: ") + hipGetErrorString(e));
+  return RTPT_OK;
+}
+
+int rtpt_selftest_trace(rtpt_ctx* c, const float* rays, size_t n, uint32_t* out_id, float* out_t) {
+  if (!c || !rays || !out_id) return fail(RTPT_E_INVALID, "NULL argument");
+  if (!c->n_tris) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");
+  if (n == 0) return RTPT_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  float *drays = nullptr, *dt = nullptr;
+  uint32_t* did = nullptr;
+  hipError_t e = hipMalloc(&drays, n * 24);
+  if (e == hipSuccess) e = hipMalloc(&did, n * 4);
+  if (e == hipSuccess) e = hipMalloc(&dt, n * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(drays, rays, n * 24, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    rt::launch_selftest_trace(scene_view(c), drays, n, c->cfg.ray_tmax, did, dt, c->stream);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out_id, did, n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess && out_t) e = hipMemcpyAsync(out_t, dt, n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(drays);
+  (void)hipFree(did);
+  (void)hipFree(dt);
+  if (e != hipSuccess) return fail(RTPT_E_DEVICE, std::string("selftest_trace: ") + hipGetErrorString(e));
+  return RTPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ host helpers
+void rtpt_util_look_at(const float eye[3], const float center[3], const float up[3], float m[16]) {
+  // glm::lookAtRH (main.cpp:482, :1470)
+  using namespace rt;
+  f3 e{eye[0], eye[1], eye[2]};
+  f3 f = exact::normalize(f3{center[0], center[1], center[2]} - e);
+  f3 s = exact::normalize(exact::cross(f, f3{up[0], up[1], up[2]}));
+  f3 u = exact::cross(s, f);
+  std::memset(m, 0, 16 * sizeof(float));
+  m[0] = s.x; m[4] = s.y; m[8] = s.z;
+  m[1] = u.x; m[5] = u.y; m[9] = u.z;
+  m[2] = -f.x; m[6] = -f.y; m[10] = -f.z;
+  m[12] = -exact::dot(s, e);
+  m[13] = -exact::dot(u, e);
+  m[14] = exact::dot(f, e);
+  m[15] = 1.0f;
+}
+
+void rtpt_util_perspective(float fovy, float aspect, float zn, float zf, float m[16]) {
+  // glm::perspectiveRH_ZO (D6; main.cpp:483, :1471)
+  const float t = static_cast<float>(std::tan(static_cast<double>(fovy) * 0.5));
+  std::memset(m, 0, 16 * sizeof(float));
+  m[0] = 1.0f / (aspect * t);
+  m[5] = 1.0f / t;
+  m[10] = zf / (zn - zf);
+  m[11] = -1.0f;
+  m[14] = -(zf * zn) / (zf - zn);
+}
+
+int rtpt_util_load_obj(const char* path, float* xyz, uint32_t* n_verts, uint32_t* idx, uint32_t* n_tris) {
+  if (!path || !n_verts || !n_tris) return fail(RTPT_E_INVALID, "NULL argument");
+  FILE* fp = std::fopen(path, "r");
+  if (!fp) return fail(RTPT_E_INVALID, std::string("cannot open ") + path);
+  std::vector<long> poly;
+  uint32_t nv = 0, nt = 0;
+  char line[2048];
+  int rc = RTPT_OK;
+  while (std::fgets(line, sizeof line, fp)) {
+    const char* p = line;
+    while (*p == ' ' || *p == '\t') p++;
+    if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+      char* end = nullptr;
+      float v[3];
+      const char* q = p + 2;
+      bool ok = true;
+      for (int k = 0; k < 3; k++) {
+        v[k] = std::strtof(q, &end);
+        if (end == q) ok = false;
+        q = end;
+      }
+      if (!ok) continue;
+      if (xyz) std::memcpy(xyz + 3 * static_cast<size_t>(nv), v, sizeof v);
+      nv++;
+    } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+      poly.clear();
+      const char* q = p + 2;
+      while (*q) {
+        while (*q == ' ' || *q == '\t') q++;
+        if (*q == '\0' || *q == '\n' || *q == '\r') break;
+        char* end = nullptr;
+        long v = std::strtol(q, &end, 10);
+        if (end == q) break;
+        long resolved = v > 0 ? v - 1 : static_cast<long>(nv) + v;  // OBJ indices are 1-based; negative = relative
+        if (resolved < 0 || resolved >= static_cast<long>(nv)) rc = fail(RTPT_E_INVALID, "OBJ face index out of range");
+        poly.push_back(resolved);
+        q = end;
+        while (*q && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') q++;  // skip "/vt/vn"
+      }
+      for (size_t k = 1; k + 1 < poly.size(); k++) {  // D5: fan triangulation in file order
+        if (idx) {
+          idx[3 * static_cast<size_t>(nt)] = static_cast<uint32_t>(poly[0]);
+          idx[3 * static_cast<size_t>(nt) + 1] = static_cast<uint32_t>(poly[k]);
+          idx[3 * static_cast<size_t>(nt) + 2] = static_cast<uint32_t>(poly[k + 1]);
+        }
+        nt++;
+      }
+    }
+  }
+  std::fclose(fp);
+  *n_verts = nv;
+  *n_tris = nt;
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+// bvh.cpp — binned-SAH BVH2 builder (host).  See bvh.hpp.
+#include "bvh.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace rt {
+namespace {
+
+struct Box {
+  float mn[3], mx[3];
+  void reset() {
+    for (int a = 0; a < 3; a++) {
+      mn[a] = FLT_MAX;
+      mx[a] = -FLT_MAX;
+    }
+  }
+  void grow(const float* p) {
+    for (int a = 0; a < 3; a++) {
+      mn[a] = std::min(mn[a], p[a]);
+      mx[a] = std::max(mx[a], p[a]);
+    }
+  }
+  void grow(const Box& b) {
+    for (int a = 0; a < 3; a++) {
+      mn[a] = std::min(mn[a], b.mn[a]);
+      mx[a] = std::max(mx[a], b.mx[a]);
+    }
+  }
+  float half_area() const {
+    float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    if (dx < 0.f) return 0.f;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct Prim {
+  Box box;
+  float c[3];
+  uint32_t id;
+};
+
+struct Child {
+  Box box;
+  uint32_t idx;
+  uint32_t cnt;
+};
+
+constexpr int kBins = 16;
+
+struct Builder {
+  std::vector<Prim> prims;
+  Bvh* out;
+  float pad;
+
+  Child make_leaf(uint32_t lo, uint32_t hi) {
+    Child c;
+    c.box.reset();
+    c.idx = static_cast<uint32_t>(out->leaf_order.size());
+    c.cnt = hi - lo;
+    for (uint32_t i = lo; i < hi; i++) {
+      c.box.grow(prims[i].box);
+      out->leaf_order.push_back(prims[i].id);
+    }
+    return c;
+  }
+
+  // returns the descriptor of the subtree over prims[lo,hi)
+  Child build(uint32_t lo, uint32_t hi, int depth) {
+    out->max_depth = std::max(out->max_depth, depth);
+    uint32_t n = hi - lo;
+    if (n <= static_cast<uint32_t>(kBvhMaxLeaf)) return make_leaf(lo, hi);
+
+    Box cb, bb;
+    cb.reset();
+    bb.reset();
+    for (uint32_t i = lo; i < hi; i++) {
+      cb.grow(prims[i].c);
+      bb.grow(prims[i].box);
+    }
+    uint32_t mid = lo;
+    // SAH over kBins bins on every axis; past a depth budget fall back to the object median so the
+    // remaining depth is bounded by log2(n)
+    bool median = depth >= kBvhMaxDepth - 26;
+    if (!median) {
+      float best_cost = FLT_MAX;
+      int best_axis = -1, best_split = -1;
+      for (int a = 0; a < 3; a++) {
+        float ext = cb.mx[a] - cb.mn[a];
+        if (!(ext > 0.f)) continue;
+        Box bins[kBins];
+        uint32_t cnt[kBins];
+        for (int b = 0; b < kBins; b++) {
+          bins[b].reset();
+          cnt[b] = 0;
+        }
+        float scale = kBins / ext;
+        for (uint32_t i = lo; i < hi; i++) {
+          int b = std::min(kBins - 1, static_cast<int>((prims[i].c[a] - cb.mn[a]) * scale));
+          bins[b].grow(prims[i].box);
+          cnt[b]++;
+        }
+        float right_area[kBins];
+        uint32_t right_cnt[kBins];
+        Box acc;
+        acc.reset();
+        uint32_t c = 0;
+        for (int b = kBins - 1; b > 0; b--) {
+          acc.grow(bins[b]);
+          c += cnt[b];
+          right_area[b] = acc.half_area();
+          right_cnt[b] = c;
+        }
+        acc.reset();
+        c = 0;
+        for (int b = 0; b < kBins - 1; b++) {
+          acc.grow(bins[b]);
+          c += cnt[b];
+          if (c == 0 || right_cnt[b + 1] == 0) continue;
+          float cost = acc.half_area() * c + right_area[b + 1] * right_cnt[b + 1];
+          if (cost < best_cost) {
+            best_cost = cost;
+            best_axis = a;
+            best_split = b;
+          }
+        }
+      }
+      if (best_axis >= 0) {
+        float ext = cb.mx[best_axis] - cb.mn[best_axis];
+        float scale = kBins / ext;
+        float mn = cb.mn[best_axis];
+        int axis = best_axis, split = best_split;
+        auto it = std::partition(prims.begin() + lo, prims.begin() + hi, [&](const Prim& p) {
+          int b = std::min(kBins - 1, static_cast<int>((p.c[axis] - mn) * scale));
+          return b <= split;
+        });
+        mid = static_cast<uint32_t>(it - prims.begin());
+      }
+    }
+    if (mid == lo || mid == hi) {
+      // object-median split on the widest centroid axis (also the degenerate-centroid fallback)
+      int axis = 0;
+      float best = -1.f;
+      for (int a = 0; a < 3; a++) {
+        float e = cb.mx[a] - cb.mn[a];
+        if (e > best) {
+          best = e;
+          axis = a;
+        }
+      }
+      mid = lo + n / 2;
+      std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi,
+                       [axis](const Prim& x, const Prim& y) {
+                         return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.id < y.id);
+                       });
+    }
+
+    uint32_t node_index = static_cast<uint32_t>(out->nodes.size());
+    out->nodes.emplace_back();
+    Child l = build(lo, mid, depth + 1);
+    Child r = build(mid, hi, depth + 1);
+    write_pair(node_index, l, r);
+    Child me;
+    me.box = l.box;
+    me.box.grow(r.box);
+    me.idx = node_index;
+    me.cnt = 0;
+    return me;
+  }
+
+  void write_pair(uint32_t node_index, const Child& l, const Child& r) {
+    BvhNode& nd = out->nodes[node_index];
+    for (int a = 0; a < 3; a++) {
+      nd.lmin[a] = l.box.mn[a] - pad;
+      nd.lmax[a] = l.box.mx[a] + pad;
+      nd.rmin[a] = r.box.mn[a] - pad;
+      nd.rmax[a] = r.box.mx[a] + pad;
+    }
+    nd.lidx = l.idx;
+    nd.lcnt = l.cnt;
+    nd.ridx = r.idx;
+    nd.rcnt = r.cnt;
+  }
+};
+
+}  // namespace
+
+void build_bvh(const float* tris, uint32_t n, Bvh& out, float pad_rel) {
+  out.nodes.clear();
+  out.leaf_order.clear();
+  out.max_depth = 0;
+  Builder b;
+  b.out = &out;
+  b.prims.resize(n);
+  Box scene;
+  scene.reset();
+  for (uint32_t i = 0; i < n; i++) {
+    Prim& p = b.prims[i];
+    p.box.reset();
+    for (int k = 0; k < 3; k++) p.box.grow(tris + 9 * static_cast<size_t>(i) + 3 * k);
+    for (int a = 0; a < 3; a++) p.c[a] = 0.5f * (p.box.mn[a] + p.box.mx[a]);
+    p.id = i;
+    scene.grow(p.box);
+  }
+  for (int a = 0; a < 3; a++) {
+    out.scene_min[a] = n ? scene.mn[a] : 0.f;
+    out.scene_max[a] = n ? scene.mx[a] : 0.f;
+  }
+  float diag = 0.f;
+  if (n) {
+    float dx = scene.mx[0] - scene.mn[0], dy = scene.mx[1] - scene.mn[1], dz = scene.mx[2] - scene.mn[2];
+    diag = std::sqrt(dx * dx + dy * dy + dz * dz);
+    float mag = 0.f;
+    for (int a = 0; a < 3; a++) mag = std::max(mag, std::max(std::fabs(scene.mn[a]), std::fabs(scene.mx[a])));
+    diag = std::max(diag, mag);
+  }
+  b.pad = pad_rel * diag;
+  out.nodes.reserve(n / 2 + 2);
+  out.leaf_order.reserve(n);
+
+  if (n <= static_cast<uint32_t>(kBvhMaxLeaf)) {
+    // single-leaf scene: root pair = {leaf, absent}
+    out.nodes.emplace_back();
+    Child l = b.make_leaf(0, n);
+    Child r;
+    r.box.reset();
+    r.idx = kBvhEmpty;
+    r.cnt = 0;
+    if (n == 0) {
+      l.idx = kBvhEmpty;
+      l.cnt = 0;
+    }
+    b.write_pair(0, l, r);
+    return;
+  }
+  Child root = b.build(0, n, 0);
+  (void)root;  // n > kBvhMaxLeaf: the root is interior and is node 0 by construction
+}
+
+}  // namespace rt

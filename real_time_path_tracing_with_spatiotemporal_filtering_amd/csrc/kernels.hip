@@ -1,0 +1,579 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the hot path.
+//
+//   k_scene_prepare / k_lut   per-triangle records, LUT (visibility.geom.glsl:44-59), normal table
+//   k_gbuffer                 K0  visibility.{vert,geom,frag}.glsl as pixel-centre primary rays
+//   k_gradient                K1  temporalGradient.comp.glsl:104-172
+//   k_pathtrace               K2  raytrace.comp.glsl:273-344 (software closest-hit, no ray query)
+//   k_atrous                  K3  temporalFiltering.comp.glsl:191-265, one iteration; FINAL fuses
+//                                 reprojection + blend (:213-263)
+//
+// No MFMA anywhere: nothing on this path is a dense contraction.  Compile with -ffp-contract=off.
+#include "kernels.hpp"
+
+#include "rtpt_math.hpp"
+
+namespace rt {
+namespace {
+
+constexpr int kBlockX = 64;  // one wave = 64 consecutive pixels of a row: 1 KiB float4 stores
+constexpr int kBlockY = 4;
+constexpr int kThreads = kBlockX * kBlockY;
+
+__device__ __forceinline__ f3 ld3(const float* p) { return f3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ f3 xyz(float4 v) { return f3{v.x, v.y, v.z}; }
+
+// ------------------------------------------------------------------------------------------
+// closest hit.  D4: the winner is min over (t, id) of ONE ray-triangle routine, so the result
+// does not depend on which structure enumerates the candidates.
+// ------------------------------------------------------------------------------------------
+struct HitRec {
+  float t;       // best t so far (initialised to tmax)
+  uint32_t id1;  // primitive id + 1, 0 = none
+  float u, v, ad;  // scaled barycentrics of the best hit: b1 = u/ad, b2 = v/ad
+};
+
+// Moller-Trumbore with the division deferred until a candidate passes the inside tests.
+template <bool TIE_BREAK>
+__device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float4 r2, uint32_t id1, HitRec& h) {
+  f3 v0{r0.x, r0.y, r0.z}, e1{r0.w, r1.x, r1.y}, e2{r1.z, r1.w, r2.x};
+  f3 p = exact::cross(d, e2);
+  float det = exact::dot(e1, p);
+  f3 tv = o - v0;
+  float u = exact::dot(tv, p);
+  f3 q = exact::cross(tv, e1);
+  float v = exact::dot(d, q);
+  float tt = exact::dot(e2, q);
+  float ad = __builtin_fabsf(det);
+  if (det < 0.0f) {
+    u = -u;
+    v = -v;
+    tt = -tt;
+  }
+  bool ok = (ad > 0.0f) && (u >= 0.0f) && (v >= 0.0f) && (u + v <= ad) && (tt > 0.0f);
+  if (ok) {
+    float th = tt / ad;
+    bool better = th < h.t;
+    if (TIE_BREAK) better = better || (th == h.t && h.id1 != 0 && id1 < h.id1);
+    if (better) {
+      h.t = th;
+      h.id1 = id1;
+      h.u = u;
+      h.v = v;
+      h.ad = ad;
+    }
+  }
+}
+
+// Small scenes (<= 64 triangles, the Cornell box has 32): every lane of the wave tests the same
+// triangle at the same time, so the record address is wave-uniform and the loads are scalar
+// (s_load_dwordx4 -> SGPR operands of the VALU ops).  No stack, no divergence, no memory latency.
+__device__ __forceinline__ void closest_hit_brute(const SceneView& sc, f3 o, f3 d, HitRec& h) {
+  const float4* rec = sc.isect_id;
+  for (uint32_t i = 0; i < sc.n_tris; i++) {
+    float4 r0 = rec[3 * i], r1 = rec[3 * i + 1], r2 = rec[3 * i + 2];
+    tri_test<false>(o, d, r0, r1, r2, i + 1, h);
+  }
+}
+
+__device__ __forceinline__ bool slab(const float* mn, const float* mx, f3 inv, f3 oi, float tbest, float& tnear) {
+  float t0x = fmaf_(mn[0], inv.x, oi.x), t1x = fmaf_(mx[0], inv.x, oi.x);
+  float t0y = fmaf_(mn[1], inv.y, oi.y), t1y = fmaf_(mx[1], inv.y, oi.y);
+  float t0z = fmaf_(mn[2], inv.z, oi.z), t1z = fmaf_(mx[2], inv.z, oi.z);
+  float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                             __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
+  float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+                             __builtin_fminf(__builtin_fmaxf(t0z, t1z), tbest));
+  tnear = tn;
+  return tn <= tf;
+}
+
+// General scenes: per-lane depth-first traversal of the child-pair BVH with the node stack in LDS
+// (stack[level][thread]: consecutive lanes hit consecutive banks).
+__device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d, HitRec& h, uint32_t* stack,
+                                               int tid) {
+  f3 inv{fast::rcp_(d.x), fast::rcp_(d.y), fast::rcp_(d.z)};
+  f3 oi{-o.x * inv.x, -o.y * inv.y, -o.z * inv.z};
+  int sp = 0;
+  uint32_t node = 0;
+  while (true) {
+    const BvhNode nd = sc.nodes[node];
+    float tl, tr;
+    bool hl = (nd.lidx != kBvhEmpty) && slab(nd.lmin, nd.lmax, inv, oi, h.t, tl);
+    bool hr = (nd.ridx != kBvhEmpty) && slab(nd.rmin, nd.rmax, inv, oi, h.t, tr);
+    if (hl && nd.lcnt) {
+      for (uint32_t j = 0; j < nd.lcnt; j++) {
+        const float4* r = sc.isect_leaf + 3 * (nd.lidx + j);
+        float4 r2 = r[2];
+        tri_test<true>(o, d, r[0], r[1], r2, f2u(r2.y) + 1, h);
+      }
+      hl = false;
+    }
+    if (hr && nd.rcnt) {
+      for (uint32_t j = 0; j < nd.rcnt; j++) {
+        const float4* r = sc.isect_leaf + 3 * (nd.ridx + j);
+        float4 r2 = r[2];
+        tri_test<true>(o, d, r[0], r[1], r2, f2u(r2.y) + 1, h);
+      }
+      hr = false;
+    }
+    if (hl && hr) {
+      bool left_first = tl <= tr;
+      uint32_t near = left_first ? nd.lidx : nd.ridx;
+      uint32_t far = left_first ? nd.ridx : nd.lidx;
+      stack[sp * kThreads + tid] = far;
+      sp++;
+      node = near;
+    } else if (hl) {
+      node = nd.lidx;
+    } else if (hr) {
+      node = nd.ridx;
+    } else {
+      if (sp == 0) break;
+      sp--;
+      node = stack[sp * kThreads + tid];
+    }
+  }
+}
+
+template <bool BVH>
+__device__ __forceinline__ void closest_hit(const SceneView& sc, f3 o, f3 d, HitRec& h, uint32_t* stack, int tid) {
+  if (BVH)
+    closest_hit_bvh(sc, o, d, h, stack, tid);
+  else
+    closest_hit_brute(sc, o, d, h);
+}
+
+// v0*b0 + v1*b1 + v2*b2 (raytrace.comp.glsl:137) := fma(v2,b2, fma(v1,b1, v0*b0))
+__device__ __forceinline__ f3 bary_point(f3 v0, f3 v1, f3 v2, float b0, float b1, float b2) {
+  return f3{fmaf_(v2.x, b2, fmaf_(v1.x, b1, v0.x * b0)), fmaf_(v2.y, b2, fmaf_(v1.y, b1, v0.y * b0)),
+            fmaf_(v2.z, b2, fmaf_(v1.z, b1, v0.z * b0))};
+}
+
+// ------------------------------------------------------------------------------------------
+// scene records
+// ------------------------------------------------------------------------------------------
+__global__ void k_scene_prepare(ScenePrepArgs a) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_tris) return;
+  {
+    const float* t = a.tris + 9 * static_cast<size_t>(i);
+    f3 v0 = ld3(t), v1 = ld3(t + 3), v2 = ld3(t + 6);
+    f3 e1 = v1 - v0, e2 = v2 - v0;
+    a.isect_id[3 * i] = make_float4(v0.x, v0.y, v0.z, e1.x);
+    a.isect_id[3 * i + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+    a.isect_id[3 * i + 2] = make_float4(e2.z, u2f(i), 0.f, 0.f);
+    f3 n = exact::normalize(exact::cross(e1, e2));  // raytrace.comp.glsl:150
+    a.shade[3 * i] = make_float4(v0.x, v0.y, v0.z, n.x);
+    a.shade[3 * i + 1] = make_float4(v1.x, v1.y, v1.z, n.y);
+    a.shade[3 * i + 2] = make_float4(v2.x, v2.y, v2.z, n.z);
+  }
+  {
+    uint32_t id = a.leaf_order[i];
+    const float* t = a.tris + 9 * static_cast<size_t>(id);
+    f3 v0 = ld3(t), v1 = ld3(t + 3), v2 = ld3(t + 6);
+    f3 e1 = v1 - v0, e2 = v2 - v0;
+    a.isect_leaf[3 * i] = make_float4(v0.x, v0.y, v0.z, e1.x);
+    a.isect_leaf[3 * i + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+    a.isect_leaf[3 * i + 2] = make_float4(e2.z, u2f(id), 0.f, 0.f);
+  }
+}
+
+// visibility.vert.glsl:24 + visibility.geom.glsl:57-59: LUT[t+1] = model * (v0,v1,v2), written for
+// every triangle (the geometry stage precedes clipping).  Also the per-id normal table the filter
+// gathers instead of re-deriving normalize(cross) from the LUT at each of its 10 reads per pixel
+// (temporalFiltering.comp.glsl:80-91) — same values, computed once per triangle.
+__global__ void k_lut(LutArgs a) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    a.lut[0] = a.lut[1] = a.lut[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    f3 n{0.f, 0.f, 1.f};  // temporalFiltering.comp.glsl:83
+    a.normal_tab[0] = make_float4(n.x, n.y, n.z, exact::powi(glsl_max(0.0f, exact::dot(n, n)), a.sigma_n));
+  }
+  if (t >= a.n_tris) return;
+  f3 v[3];
+  for (int k = 0; k < 3; k++) {
+    f3 p = xyz(a.shade[3 * t + k]);
+    v[k] = f3{exact::mat_row_point(a.model, 0, p), exact::mat_row_point(a.model, 1, p), exact::mat_row_point(a.model, 2, p)};
+    a.lut[3 * (t + 1) + k] = make_float4(v[k].x, v[k].y, v[k].z, 0.f);
+  }
+  f3 n = exact::normalize(exact::cross(v[1] - v[0], v[2] - v[0]));  // :90
+  a.normal_tab[t + 1] = make_float4(n.x, n.y, n.z, exact::powi(glsl_max(0.0f, exact::dot(n, n)), a.sigma_n));
+}
+
+// ------------------------------------------------------------------------------------------
+// K0 G-buffer
+// ------------------------------------------------------------------------------------------
+template <bool BVH>
+__global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
+  __shared__ uint32_t stack[BVH ? kBvhMaxDepth * kThreads : 1];
+  const int tid = threadIdx.y * kBlockX + threadIdx.x;
+  const int x = blockIdx.x * kBlockX + threadIdx.x;
+  const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
+  if (x >= a.g.W || y >= a.g.y1) return;
+  const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
+  float nx = fmaf_(2.0f, static_cast<float>(x) + 0.5f, -fw) / fw;
+  float ny = fmaf_(2.0f, static_cast<float>(y) + 0.5f, -fh) / fh;
+  f3 dv{nx / a.p00, ny / a.p11, -1.0f};
+  f3 c0 = ld3(a.c0), c1 = ld3(a.c1), c2 = ld3(a.c2);
+  f3 d = exact::normalize(f3{exact::dot(c0, dv), exact::dot(c1, dv), exact::dot(c2, dv)});
+  f3 o = ld3(a.org);
+  HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
+  closest_hit<BVH>(a.scene, o, d, h, stack, tid);
+  const size_t i = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
+  a.vis[i] = h.id1;  // visibility.frag.glsl:23
+  if (h.id1) {
+    float b1 = h.u / h.ad, b2 = h.v / h.ad;
+    float b0 = 1.0f - b1 - b2;
+    const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
+    f3 wp = bary_point(xyz(s[0]), xyz(s[1]), xyz(s[2]), b0, b1, b2);
+    a.worldpos[i] = make_float4(wp.x, wp.y, wp.z, 1.0f);
+    float cz = exact::mat_row_point(a.PV, 2, wp), cw = exact::mat_row_point(a.PV, 3, wp);
+    a.depth[i] = cz / cw;
+  } else {
+    a.worldpos[i] = make_float4(0.f, 0.f, 0.f, 1.0f);  // clear colour main.cpp:1420
+    a.depth[i] = 1.0f;                                  // clear depth  main.cpp:1421
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 temporal gradient
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tri_area(f3 a, f3 b, f3 c) { return exact::length(exact::cross(b - a, c - a)) * 0.5f; }
+__device__ __forceinline__ f3 bary_coords(f3 p, f3 a, f3 b, f3 c) {
+  float at = tri_area(a, b, c);
+  return f3{tri_area(p, b, c) / at, tri_area(a, p, c) / at, tri_area(a, b, p) / at};
+}
+__device__ __forceinline__ f3 bary_mix(f3 bc, f3 a, f3 b, f3 c) {
+  return f3{fmaf_(bc.z, c.x, fmaf_(bc.y, b.x, bc.x * a.x)), fmaf_(bc.z, c.y, fmaf_(bc.y, b.y, bc.x * a.y)),
+            fmaf_(bc.z, c.z, fmaf_(bc.y, b.z, bc.x * a.z))};
+}
+
+// temporalGradient.comp.glsl:71-101
+__device__ __forceinline__ f3 phong(f3 p, f3 n, f3 cam, f3 lpos, f3 lcol) {
+  f3 ldir = exact::normalize(lpos - p);
+  f3 ambient = lcol * 0.1f;
+  float diff = glsl_max(exact::dot(n, ldir), 0.0f);
+  f3 diffuse = lcol * diff;
+  f3 vdir = exact::normalize(cam - p);
+  f3 I = -ldir;
+  float two_ndi = 2.0f * exact::dot(n, I);
+  f3 rdir{fmaf_(-two_ndi, n.x, I.x), fmaf_(-two_ndi, n.y, I.y), fmaf_(-two_ndi, n.z, I.z)};
+  float spec = exact::powi(glsl_max(exact::dot(vdir, rdir), 0.0f), 128);
+  f3 specular = lcol * (0.5f * spec);
+  return ((ambient + diffuse) + specular) * 0.7f;
+}
+
+__global__ __launch_bounds__(kThreads) void k_gradient(GradientArgs a) {
+  const int x = blockIdx.x * kBlockX + threadIdx.x;
+  const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
+  if (x >= a.g.W || y >= a.g.y1) return;  // D10: bounds check first
+  const size_t i = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
+  const uint32_t id = a.vis[i];
+  float lam = 0.0f;
+  if (id != 0) {
+    f3 wp = xyz(a.worldpos[i]);
+    f3 va = xyz(a.lut[3 * id]), vb = xyz(a.lut[3 * id + 1]), vc = xyz(a.lut[3 * id + 2]);
+    f3 nrm = exact::normalize(exact::cross(vb - va, vc - va));
+    f3 bc = bary_coords(wp, va, vb, vc);
+    f3 pa = xyz(a.lut_prev[3 * id]), pb = xyz(a.lut_prev[3 * id + 1]), pc = xyz(a.lut_prev[3 * id + 2]);
+    f3 wpp = bary_mix(bc, pa, pb, pc);
+    f3 cur = phong(wp, nrm, ld3(a.cam), ld3(a.light), ld3(a.color));
+    f3 prv = phong(wpp, nrm, ld3(a.cam), ld3(a.light_prev), ld3(a.color_prev));
+    f3 tg = cur - prv;
+    float delta = glsl_max(exact::length(cur), exact::length(prv));
+    lam = glsl_min(1.0f, exact::length(tg) / delta);
+  }
+  a.grad[i] = make_float4(lam, lam, lam, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2 path trace
+// ------------------------------------------------------------------------------------------
+// raytrace.comp.glsl:168-198 — only the boolean is consumed (:226), and the sphere is tested
+// regardless of the triangle hit distance (the light is never occluded)
+__device__ __forceinline__ bool ray_hits_light(f3 o, f3 d, f3 c, float r2) {
+  f3 oc = o - c;
+  float a = exact::dot(d, d);
+  float b = 2.0f * exact::dot(oc, d);
+  float cc = exact::dot(oc, oc) - r2;
+  float disc = fmaf_(b, b, -((4.0f * a) * cc));
+  if (disc < 0.0f) return false;
+  float sq = exact::sqrt_(disc);
+  float t1 = (-b - sq) / (2.0f * a);
+  float t2 = (-b + sq) / (2.0f * a);
+  return (t1 > 0.0f) || (t2 > 0.0f);
+}
+
+__device__ __forceinline__ f3 sky_color(f3 d) {  // raytrace.comp.glsl:95-107
+  if (d.y > 0.0f) {
+    float t = d.y, it = 1.0f - t;
+    return f3{fmaf_(0.25f, t, it), fmaf_(0.5f, t, it), fmaf_(1.0f, t, it)};
+  }
+  return f3{0.03f, 0.03f, 0.03f};
+}
+
+template <bool BVH>
+__global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
+  __shared__ uint32_t stack[BVH ? kBvhMaxDepth * kThreads : 1];
+  __shared__ unsigned int block_rays;
+  const int tid = threadIdx.y * kBlockX + threadIdx.x;
+  if (tid == 0) block_rays = 0;
+  __syncthreads();
+  const int x = blockIdx.x * kBlockX + threadIdx.x;
+  const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
+  const bool active = (x < a.g.W) && (y < a.g.y1);
+  unsigned int rays = 0;
+  if (active) {
+    uint32_t rng = exact::rng_seed(static_cast<uint32_t>(x), static_cast<uint32_t>(y), a.frame, a.batch);
+    const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
+    const f3 light_c = ld3(a.light_c);
+    f3 sum{0.f, 0.f, 0.f};
+    uint32_t first_id = 0;
+    for (uint32_t smp = 0; smp < a.spp; smp++) {
+      // raytrace.comp.glsl:84-92 Box-Muller jitter
+      float u1 = glsl_max(1e-38f, exact::rng_next(rng));
+      float u2 = exact::rng_next(rng);
+      float rad = exact::sqrt_(-2.0f * exact::log_(u1));
+      float sn, cs;
+      exact::sincos2pi(u2, sn, cs);
+      float cx = fmaf_(a.jitter, rad * cs, static_cast<float>(x) + 0.5f);  // :314
+      float cy = fmaf_(a.jitter, rad * sn, static_cast<float>(y) + 0.5f);
+      float ux = fmaf_(2.0f, cx, -fw) / fh;     // :315
+      float uy = -(fmaf_(2.0f, cy, -fh) / fh);  // :316
+      f3 d = exact::normalize(f3{a.slope * ux, a.slope * uy, -1.0f});  // :319-320
+      f3 o = ld3(a.cam);
+      f3 acc{1.f, 1.f, 1.f};
+      for (uint32_t seg = 0; seg < a.max_segments; seg++) {  // :204
+        HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
+        closest_hit<BVH>(a.scene, o, d, h, stack, tid);  // :208-222
+        rays++;
+        if (seg == 0 && smp == 0) first_id = h.id1;
+        if (ray_hits_light(o, d, light_c, a.light_r2)) {  // :226
+          acc = acc * (seg == 0 ? ld3(a.light_col_first) : ld3(a.light_col));  // :229,:233
+          break;
+        }
+        if (h.id1 == 0) {
+          acc = acc * sky_color(d);  // :266
+          break;
+        }
+        const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
+        float4 s0 = s[0], s1 = s[1], s2 = s[2];
+        float b1 = h.u / h.ad, b2 = h.v / h.ad;
+        float b0 = 1.0f - b1 - b2;                                       // :134
+        f3 pos = bary_point(xyz(s0), xyz(s1), xyz(s2), b0, b1, b2);      // :137
+        f3 n{s0.w, s1.w, s2.w};                                          // :150 (precomputed per triangle)
+        f3 alb = (n.x > 0.99f) ? f3{1.f, 0.f, 0.f} : ((-n.x > 0.99f) ? f3{0.f, 1.f, 0.f} : f3{0.7f, 0.7f, 0.7f});  // :155-163
+        acc = acc * alb;                                                 // :244
+        if (!(exact::dot(n, d) < 0.0f)) n = -n;                          // :247 faceforward
+        o = f3{fmaf_(a.ray_offset, n.x, pos.x), fmaf_(a.ray_offset, n.y, pos.y), fmaf_(a.ray_offset, n.z, pos.z)};  // :250
+        float st, ct;
+        exact::sincos2pi(exact::rng_next(rng), st, ct);                  // :256
+        float u = fmaf_(2.0f, exact::rng_next(rng), -1.0f);              // :257
+        float r = exact::sqrt_(fmaf_(-u, u, 1.0f));                      // :258
+        d = exact::normalize(f3{fmaf_(r, ct, n.x), fmaf_(r, st, n.y), n.z + u});  // :259-261
+      }
+      sum = sum + acc;  // :325
+    }
+    const float ns = static_cast<float>(a.spp);
+    const size_t i = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
+    a.image[i] = make_float4(sum.x / ns, sum.y / ns, sum.z / ns, 0.0f);  // :328,:343
+    if (a.hit_id) a.hit_id[i] = first_id;
+  }
+  // "ray" = one closest-hit query; one 64-bit atomic per block
+  for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+  if ((tid & 63) == 0 && rays) atomicAdd(&block_rays, rays);
+  __syncthreads();
+  if (tid == 0 && block_rays) atomicAdd(a.raycount, static_cast<unsigned long long>(block_rays));
+}
+
+// ------------------------------------------------------------------------------------------
+// K3 a-trous iteration (3x3 taps at stride k, h = 1/9, edge-stopping on normal/depth/colour)
+// ------------------------------------------------------------------------------------------
+template <bool EXACT>
+__device__ __forceinline__ float w_exp(float x) {
+  if (EXACT) return exact::exp_(x);
+  return fast::exp_(x);
+}
+
+template <bool FINAL, bool EXACT>
+__global__ __launch_bounds__(kThreads) void k_atrous(AtrousArgs a) {
+  const int x = blockIdx.x * kBlockX + threadIdx.x;
+  const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
+  if (x >= a.g.W || y >= a.g.y1) return;
+  const int W = a.g.W, H = a.g.H, k = a.k;
+  const size_t ip = static_cast<size_t>(y - a.g.row_base) * W + x;
+  const float4 cp4 = a.in[ip];
+  const f3 cp = xyz(cp4);
+  const float dp = a.depth[ip];
+  const uint32_t idp = a.vis[ip];
+  const float4 np4 = a.normal_tab[idp];
+  const f3 np = xyz(np4);
+  f3 num{0.f, 0.f, 0.f};
+  float den = 0.f;
+  const float h = 1.0f / 9.0f;  // temporalFiltering.comp.glsl:145
+#pragma unroll
+  for (int i = -1; i < 2; i++) {  // :132
+    int qx = x + i * k;
+    qx = qx < 0 ? 0 : (qx > W - 1 ? W - 1 : qx);  // :136
+#pragma unroll
+    for (int j = -1; j < 2; j++) {  // :133
+      int qy = y + j * k;
+      qy = qy < 0 ? 0 : (qy > H - 1 ? H - 1 : qy);
+      const size_t iq = static_cast<size_t>(qy - a.g.row_base) * W + qx;
+      const f3 cq = xyz(a.in[iq]);
+      const float dq = a.depth[iq];
+      const uint32_t idq = a.vis[iq];
+      float wn;
+      if (idq == idp) {
+        wn = np4.w;  // pow(max(0, dot(np,np)), sigma_n), precomputed per id (same bits)
+      } else {
+        const f3 nq = xyz(a.normal_tab[idq]);
+        wn = exact::powi(glsl_max(0.0f, exact::dot(np, nq)), a.sigma_n);  // :62
+      }
+      float wd, wl;
+      const f3 dc = cp - cq;
+      if (EXACT) {
+        wd = exact::exp_(-__builtin_fabsf(dp - dq) / a.sigma_z);          // :67-68
+        wl = exact::exp_(-exact::length(dc) / a.sigma_l);                 // :73
+      } else {
+        wd = fast::exp_(-__builtin_fabsf(dp - dq) * a.inv_sigma_z);
+        wl = fast::exp_(-fast::sqrt_(exact::dot(dc, dc)) * a.inv_sigma_l);
+      }
+      const float w = (wn * wd) * wl;  // :77
+      const float hw = h * w;
+      num = f3{fmaf_(hw, cq.x, num.x), fmaf_(hw, cq.y, num.y), fmaf_(hw, cq.z, num.z)};  // :146
+      den = den + hw;                                                                    // :147
+    }
+  }
+  f3 filtered;
+  if (EXACT) {
+    filtered = f3{num.x / den, num.y / den, num.z / den};  // :150
+  } else {
+    const float rd = fast::rcp_(den);
+    filtered = num * rd;
+  }
+  if (!FINAL) {
+    a.out[ip] = make_float4(filtered.x, filtered.y, filtered.z, 0.0f);  // :152
+    return;
+  }
+  // :213-239 reprojection — exact arithmetic: the truncated pixel coordinate is an integer observable
+  int ppx = x, ppy = y;
+  if (!(idp < 1)) {
+    const f3 wp = xyz(a.worldpos[ip]);
+    const f3 va = xyz(a.lut_prev[3 * idp]), vb = xyz(a.lut_prev[3 * idp + 1]), vc = xyz(a.lut_prev[3 * idp + 2]);  // :223-233
+    const f3 bc = bary_coords(wp, va, vb, vc);
+    const f3 wpp = bary_mix(bc, va, vb, vc);  // :236
+    const float clx = exact::mat_row_point(a.PVprev, 0, wpp), cly = exact::mat_row_point(a.PVprev, 1, wpp),
+                clw = exact::mat_row_point(a.PVprev, 3, wpp);
+    const float ndx = clx / clw, ndy = cly / clw;                 // :183
+    ppx = exact::f2i(fmaf_(ndx, 0.5f, 0.5f) * static_cast<float>(W));  // :186,:238
+    ppy = exact::f2i(fmaf_(ndy, 0.5f, 0.5f) * static_cast<float>(H));
+  }
+  if (a.prev_pixel) a.prev_pixel[ip] = make_int2(ppx, ppy);
+  f3 blend = filtered;  // :258
+  if (a.frame > 0) {    // :251
+    f3 hc{0.f, 0.f, 0.f};  // D2: out-of-image history fetch returns 0
+    if (ppx >= 0 && ppx < W && ppy >= a.hist_y0 && ppy < a.hist_y1)
+      hc = xyz(a.history[static_cast<size_t>(ppy - a.hist_row_base) * W + ppx]);
+    const float oma = 1.0f - a.alpha;
+    blend = f3{fmaf_(filtered.x, a.alpha, hc.x * oma), fmaf_(filtered.y, a.alpha, hc.y * oma),
+               fmaf_(filtered.z, a.alpha, hc.z * oma)};  // :254
+  }
+  a.out[ip] = make_float4(blend.x, blend.y, blend.z, 0.0f);  // :263 (D1: distinct buffer)
+}
+
+// ------------------------------------------------------------------------------------------
+// self tests
+// ------------------------------------------------------------------------------------------
+__global__ void k_selftest_math(int op, const float* in, float* out, size_t n) {
+  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = in[i], r = 0.f, s, c;
+  switch (op) {
+    case 0: r = exact::log_(x); break;
+    case 1: exact::sincos2pi(x, s, c); r = s; break;
+    case 2: exact::sincos2pi(x, s, c); r = c; break;
+    case 3: r = exact::sqrt_(x); break;
+    case 4: r = exact::rcp_(x); break;
+    case 5: r = fast::exp_(x); break;
+    case 6: { uint32_t st = f2u(x); r = exact::rng_next(st); break; }
+    case 7: r = exact::exp_(x); break;
+    default: break;
+  }
+  out[i] = r;
+}
+
+template <bool BVH>
+__global__ __launch_bounds__(kThreads) void k_selftest_trace(SceneView sc, const float* rays, size_t n, float tmax,
+                                                             uint32_t* out_id, float* out_t) {
+  __shared__ uint32_t stack[BVH ? kBvhMaxDepth * kThreads : 1];
+  size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= n) return;
+  f3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
+  HitRec h{tmax, 0u, 0.f, 0.f, 1.f};
+  closest_hit<BVH>(sc, o, d, h, stack, threadIdx.x);
+  out_id[i] = h.id1;
+  if (out_t) out_t[i] = h.id1 ? h.t : 0.0f;
+}
+
+inline dim3 grid_for(const FrameGeom& g) {
+  return dim3((g.W + kBlockX - 1) / kBlockX, (g.y1 - g.y0 + kBlockY - 1) / kBlockY, 1);
+}
+
+}  // namespace
+
+void launch_scene_prepare(const ScenePrepArgs& a, hipStream_t s) {
+  if (!a.n_tris) return;
+  hipLaunchKernelGGL(k_scene_prepare, dim3((a.n_tris + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_lut(const LutArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_lut, dim3((a.n_tris + 256) / 256), dim3(256), 0, s, a);
+}
+void launch_gbuffer(const GbufferArgs& a, hipStream_t s) {
+  if (a.g.y1 <= a.g.y0) return;
+  if (a.scene.use_bvh)
+    hipLaunchKernelGGL(k_gbuffer<true>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_gbuffer<false>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
+}
+void launch_gradient(const GradientArgs& a, hipStream_t s) {
+  if (a.g.y1 <= a.g.y0) return;
+  hipLaunchKernelGGL(k_gradient, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
+}
+void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
+  if (a.g.y1 <= a.g.y0) return;
+  if (a.scene.use_bvh)
+    hipLaunchKernelGGL(k_pathtrace<true>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_pathtrace<false>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
+}
+void launch_atrous(const AtrousArgs& a, bool final_pass, hipStream_t s) {
+  if (a.g.y1 <= a.g.y0) return;
+  dim3 grid = grid_for(a.g), block(kBlockX, kBlockY);
+  if (a.exact) {
+    if (final_pass)
+      hipLaunchKernelGGL((k_atrous<true, true>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((k_atrous<false, true>), grid, block, 0, s, a);
+  } else {
+    if (final_pass)
+      hipLaunchKernelGGL((k_atrous<true, false>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((k_atrous<false, false>), grid, block, 0, s, a);
+  }
+}
+void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_selftest_math, dim3((n + 255) / 256), dim3(256), 0, s, op, in, out, n);
+}
+void launch_selftest_trace(const SceneView& scene, const float* rays, size_t n, float tmax, uint32_t* out_id,
+                           float* out_t, hipStream_t s) {
+  if (!n) return;
+  dim3 grid((n + kThreads - 1) / kThreads), block(kThreads);
+  if (scene.use_bvh)
+    hipLaunchKernelGGL(k_selftest_trace<true>, grid, block, 0, s, scene, rays, n, tmax, out_id, out_t);
+  else
+    hipLaunchKernelGGL(k_selftest_trace<false>, grid, block, 0, s, scene, rays, n, tmax, out_id, out_t);
+}
+
+}  // namespace rt

@@ -1,0 +1,121 @@
+// kernels.hpp — launch interface between the C-ABI layer (api.hip) and the gfx950 kernels
+// (kernels.hip).  Plain structs passed by value as kernel arguments.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bvh.hpp"
+
+namespace rt {
+
+// Device view of the scene.  Records are float4 triples:
+//   isect record  r0 = (v0.x, v0.y, v0.z, e1.x)  r1 = (e1.y, e1.z, e2.x, e2.y)  r2 = (e2.z, id_bits, 0, 0)
+//   shade record  s0 = (v0.xyz, n.x)  s1 = (v1.xyz, n.y)  s2 = (v2.xyz, n.z)     n = unit geometric normal
+struct SceneView {
+  const float4* isect_id;    // id order  (small-scene wave-uniform brute force)
+  const float4* isect_leaf;  // BVH leaf order
+  const float4* shade;       // id order
+  const BvhNode* nodes;
+  uint32_t n_tris;
+  uint32_t use_bvh;  // 0: brute force over isect_id, 1: BVH traversal
+};
+
+struct FrameGeom {
+  int32_t W, H;      // full frame
+  int32_t row_base;  // first frame row stored in the planes of this context
+  int32_t y0, y1;    // rows to compute (frame coordinates)
+};
+
+struct GbufferArgs {
+  FrameGeom g;
+  SceneView scene;
+  float org[3];          // camera origin = -R^T t
+  float c0[3], c1[3], c2[3];  // columns of the view rotation
+  float p00, p11;        // proj[0][0], proj[1][1]
+  float PV[16];          // proj * view (host product, fixed order)
+  float tmax;
+  uint32_t* vis;
+  float4* worldpos;
+  float* depth;
+};
+
+struct LutArgs {
+  uint32_t n_tris;
+  const float4* shade;  // world-space vertices
+  float model[16];
+  float4* lut;          // (n+1) x 3 float4 (stride 48 B)
+  float4* normal_tab;   // (n+1) float4: xyz = unit normal of LUT[id] (id 0: (0,0,1)), w = self weight
+  int32_t sigma_n;
+};
+
+struct GradientArgs {
+  FrameGeom g;
+  float cam[3], light[3], light_prev[3], color[3], color_prev[3];
+  const uint32_t* vis;
+  const float4* worldpos;
+  const float4* lut;
+  const float4* lut_prev;
+  float4* grad;
+};
+
+struct PathtraceArgs {
+  FrameGeom g;
+  SceneView scene;
+  uint32_t frame, batch;
+  uint32_t max_segments, spp;
+  float cam[3];
+  float light_c[3];
+  float light_col[3];        // currentCameraColor * intensity
+  float light_col_first[3];  // light_col / first_hit_light_divisor
+  float light_r2;            // radius * radius
+  float slope, jitter, ray_offset, tmax;
+  float4* image;
+  uint32_t* hit_id;  // nullable
+  unsigned long long* raycount;
+};
+
+struct AtrousArgs {
+  FrameGeom g;
+  int32_t k;             // tap stride = waveletIteration
+  int32_t exact;         // 1: contract arithmetic for the weights (RTPT_FLAG_EXACT_FILTER)
+  int32_t sigma_n;
+  float inv_sigma_z, inv_sigma_l;  // fast path multiplies by reciprocals
+  float sigma_z, sigma_l;
+  const float4* in;
+  float4* out;
+  const float* depth;
+  const uint32_t* vis;
+  const float4* normal_tab;
+  // final pass only
+  uint32_t frame;
+  float alpha;
+  const float4* worldpos;
+  const float4* history;
+  const float4* lut_prev;
+  float PVprev[16];
+  int2* prev_pixel;      // nullable
+  int32_t hist_row_base;          // first frame row stored by the history plane
+  int32_t hist_y0, hist_y1;       // frame rows of the history plane that hold a valid previous frame
+};
+
+struct ScenePrepArgs {
+  uint32_t n_tris;
+  const float* tris;  // n x 9 world-space floats
+  const uint32_t* leaf_order;
+  float4* isect_id;
+  float4* isect_leaf;
+  float4* shade;
+};
+
+void launch_scene_prepare(const ScenePrepArgs& a, hipStream_t s);
+void launch_lut(const LutArgs& a, hipStream_t s);
+void launch_gbuffer(const GbufferArgs& a, hipStream_t s);
+void launch_gradient(const GradientArgs& a, hipStream_t s);
+void launch_pathtrace(const PathtraceArgs& a, hipStream_t s);
+void launch_atrous(const AtrousArgs& a, bool final_pass, hipStream_t s);
+void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s);
+void launch_selftest_trace(const SceneView& scene, const float* rays, size_t n, float tmax, uint32_t* out_id,
+                           float* out_t, hipStream_t s);
+
+}  // namespace rt

@@ -1,0 +1,42 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SCENE = os.path.join(ROOT, "real_time_path_tracing_with_spatiotemporal_filtering_amd", "scenes",
+                     "CornellBox-Original-Merged.obj")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    O.set_threads(min(8, os.cpu_count() or 1))
+    return O
+
+
+@pytest.fixture(scope="session")
+def cornell(oracle):
+    xyz, idx = oracle.load_obj(SCENE)
+    return xyz, idx, oracle.flatten(xyz, idx)
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """the product library; GPU tests fail (not skip) when it is missing"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
+    abi.load()
+    return abi
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)

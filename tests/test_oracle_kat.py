@@ -1,0 +1,160 @@
+"""Known-answer tests pinning the oracle to the reference *sources* (SURVEY.md 4).  The reference
+ships no tests, fixtures or golden images, so these vectors — derived from the GLSL/C++ text and
+the constants folded into the .spv files — are the only reference-side anchors that exist."""
+import ctypes as C
+
+import numpy as np
+
+
+def test_pcg_words_seed0(oracle):
+    # raytrace.comp.glsl:71-78
+    words, floats, _ = oracle.rng_steps(0, 4)
+    assert words == [0x108EF29B, 0x00033628, 0xDCCC2102, 0xD3BB3506]
+    np.testing.assert_array_equal(np.array(floats, np.float32),
+                                  np.array([0.06468121, 4.9004331e-05, 0.86248976, 0.8270753], np.float32))
+
+
+def test_rng_float_is_word_times_2_pow_minus_32(oracle):
+    # :77 — 4294967295.0f rounds to 2^32 in fp32; range [0,1] inclusive
+    for state in (0, 1, 12345, 0xFFFFFFFF, 0x9E3779B9):
+        w, f, _ = oracle.rng_steps(state, 3)
+        for wi, fi in zip(w, f):
+            assert fi == np.float32(np.float32(wi) * np.float32(2.0 ** -32))
+            assert 0.0 <= fi <= 1.0
+
+
+def test_seed_hash(oracle):
+    # raytrace.comp.glsl:297, uint32 wrap-around
+    kat = {(1, 0, 0): 0xC2B2AE3D, (0, 1, 0): 0x27D4EB2F, (128, 128, 0): 0x43CCB600, (128, 128, 1): 0x559AD1B1,
+           (999, 799, 0): 0x18CFF7BC, (3839, 2159, 7): 0x3E7283F3}
+    for (x, y, f), want in kat.items():
+        assert oracle.rng_seed(x, y, f, 0) == want
+
+
+def test_camera_slope_constant(oracle):
+    # common.h:16 FOV 0.20 -> tan folded to 0.20271003 in raytrace.comp.glsl.spv
+    cfg = oracle.config_default(256, 256)
+    assert np.float32(cfg.fov_slope) == np.float32(np.tan(0.20))
+    assert np.float32(cfg.fov_slope) == np.float32(0.20271003)
+
+
+def test_struct_layouts(oracle):
+    # main.cpp:35-49 / :82-90 offsets verified against the .spv
+    P = oracle.PushConstants
+    assert [getattr(P, n).offset for n in ("sample_batch", "frameNumber", "cameraPos", "lightPos", "lightPosPrev",
+                                            "currentCameraColor", "previousCameraColor", "waveletIteration",
+                                            "maxWaveletIteration")] == [0, 4, 16, 32, 48, 64, 80, 92, 96]
+    assert C.sizeof(P) == 112
+    assert C.sizeof(oracle.Ubo) == 384
+    assert [getattr(oracle.Ubo, n).offset for n in ("model", "view", "proj", "modelPrev", "viewPrev", "projPrev")] == \
+        [0, 64, 128, 192, 256, 320]
+
+
+def test_scene_facts(cornell):
+    # scenes/CornellBox-Original-Merged.obj: 64 v, 16 quads -> 32 triangles, AABB
+    xyz, idx, tris = cornell
+    assert xyz.shape == (64, 3) and idx.shape == (32, 3)
+    assert len(np.unique(xyz, axis=0)) == 28
+    np.testing.assert_allclose(xyz.min(0), [-1.02, 0.0, -1.04], atol=1e-6)
+    np.testing.assert_allclose(xyz.max(0), [1.0, 1.99, 0.99], atol=1e-6)
+    # D5 fan triangulation in file order: triangle t = 2*quad + {0,1}
+    assert idx[0].tolist() == [0, 1, 2] and idx[1].tolist() == [0, 2, 3]
+    assert idx[6].tolist() == [12, 13, 14] and idx[7].tolist() == [12, 14, 15]
+
+
+def _normal(tri):
+    n = np.cross(tri[3:6] - tri[0:3], tri[6:9] - tri[0:3])
+    return n / np.linalg.norm(n)
+
+
+def test_albedo_keyed_by_normal(cornell):
+    # raytrace.comp.glsl:155-163: quad 3 (verts 13-16, x = +1 wall, normal -x) green,
+    # quad 4 (verts 17-20, x ~ -1 wall, normal +x) red, rest grey
+    _, _, tris = cornell
+    nx = np.array([_normal(t)[0] for t in tris])
+    red = np.where(nx > 0.99)[0].tolist()
+    green = np.where(-nx > 0.99)[0].tolist()
+    assert red == [8, 9] and green == [6, 7]
+
+
+def test_direct_light_pixel(oracle, cornell):
+    # :226-231 with main.cpp:70-72: a primary ray meeting the sphere returns 0.5*30/5 = 3 exactly
+    _, _, tris = cornell
+    app = oracle.OracleApp(256, 256, tris, max_segments=2, iterations=1)
+    fo = app.draw_scene()
+    lit = (fo.traced[..., :3] == 3.0).all(-1)
+    assert lit.sum() > 100
+    # the light centre (1,1,-0.4) projects to the right of the image centre at mid height
+    ys, xs = np.nonzero(lit)
+    assert 120 < ys.mean() < 136 and xs.mean() > 128
+    assert (fo.traced[..., 3] == 0).all()  # :343 alpha 0
+
+
+def test_static_scene_gradient_is_zero(oracle, cornell):
+    # temporalGradient.comp.glsl:163-167: unchanged light => lambda == 0 on id != 0, id == 0 => 0.
+    # Frame 0 has lightPosPrev = (0,0,0) (main.cpp:71 zero-initialised global), frame 1 is static.
+    _, _, tris = cornell
+    app = oracle.OracleApp(96, 64, tris, max_segments=1, iterations=1)
+    f0 = app.draw_scene()
+    assert f0.gradient.max() > 0.0
+    f1 = app.draw_scene()
+    assert f1.gradient.max() < 1e-3
+    assert (f1.gradient[f1.vis == 0] == 0).all()
+
+
+def test_filter_fixed_point(oracle, cornell):
+    # temporalFiltering.comp.glsl:150: a constant colour image is a fixed point of num/den
+    _, _, tris = cornell
+    app = oracle.OracleApp(64, 48, tris, max_segments=1, iterations=1)
+    fo = app.draw_scene()
+    const = np.zeros((48, 64, 4), np.float32)
+    const[..., :3] = (0.25, 0.5, 0.75)
+    pc = oracle.PushConstants()
+    pc.waveletIteration, pc.maxWaveletIteration = 2, 5
+    out = oracle.atrous(app.cfg, pc, app.ubo, const, fo.depth, fo.vis, fo.lut, fo.lut, fo.worldpos, None)
+    np.testing.assert_allclose(out[..., :3], const[..., :3], rtol=5e-7)  # a few ulp of the 9-term sums
+    assert (out[..., 3] == 0).all()
+
+
+def test_frame0_final_is_filtered_and_reprojection_identity(oracle, cornell):
+    # :251-259 frame 0 => final == filtered; :178-189/:238 static camera => prev pixel == pixel
+    _, _, tris = cornell
+    W, H = 96, 64
+    app = oracle.OracleApp(W, H, tris, max_segments=2, iterations=3)
+    f0 = app.draw_scene()
+    pc = oracle.PushConstants()
+    pc.frameNumber = 0
+    pc.maxWaveletIteration = 3
+    cur = f0.traced
+    for k in (1, 2):
+        pc.waveletIteration = k
+        cur = oracle.atrous(app.cfg, pc, app.ubo, cur, f0.depth, f0.vis, f0.lut, f0.lut, f0.worldpos, None)
+    pc.waveletIteration = 3
+    pc.maxWaveletIteration = 99  # same taps, not final
+    plain = oracle.atrous(app.cfg, pc, app.ubo, cur, f0.depth, f0.vis, f0.lut, f0.lut, f0.worldpos, None)
+    np.testing.assert_array_equal(plain, f0.image)
+    f1 = app.draw_scene()  # static camera (frame-0 viewPrev differs: it looks at (0,1,0), main.cpp:482)
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+    np.testing.assert_array_equal(f1.prev_pixel[..., 0], xs)
+    np.testing.assert_array_equal(f1.prev_pixel[..., 1], ys)
+
+
+def test_grid_counts():
+    # main.cpp:1216-1217 with common.h:18-19 (reference launch shape; informational)
+    for (w, h), want in {(256, 256): (16, 32), (1000, 800): (63, 100), (1920, 1080): (120, 135),
+                         (3840, 2160): (240, 270)}.items():
+        assert ((w + 15) // 16, (h + 7) // 8) == want
+
+
+def test_even_final_iteration_does_not_blend(oracle, cornell):
+    # main.cpp:55 "must be an odd number": with an even N the blend lands in a buffer nothing reads
+    _, _, tris = cornell
+    app = oracle.OracleApp(48, 32, tris, max_segments=1, iterations=2)
+    app.draw_scene()
+    f1 = app.draw_scene()
+    pc = oracle.PushConstants()
+    pc.frameNumber, pc.waveletIteration, pc.maxWaveletIteration = 1, 1, 9
+    a = oracle.atrous(app.cfg, pc, app.ubo, f1.traced, f1.depth, f1.vis, f1.lut, f1.lut, f1.worldpos, None)
+    pc.waveletIteration = 2
+    b = oracle.atrous(app.cfg, pc, app.ubo, a, f1.depth, f1.vis, f1.lut, f1.lut, f1.worldpos, None)
+    np.testing.assert_array_equal(b, f1.image)

@@ -1,0 +1,305 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Bars: bit-exact for integer observables (primitive ids, RNG stream,
+reprojected pixel) and for every float that is a pure function of them (G-buffer planes, traced
+colour); a stated tolerance for the filter, whose weights use the hardware exp2/sqrt/rcp.
+
+FILTER_TOL: per-pixel L2 error of the filtered RGB <= 1e-5 * (1 + ||oracle RGB||).  (GLSL itself
+only promises ~3 ulp on exp and leaves pow unspecified; v_exp_f32/v_sqrt_f32/v_rcp_f32 are 1 ulp.)
+With RTPT_FLAG_EXACT_FILTER the filter is bit-exact too.
+"""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+FILTER_TOL = 1e-5
+W, H = 160, 120
+
+
+def l2_ok(got, want, tol=FILTER_TOL):
+    err = np.linalg.norm((got[..., :3] - want[..., :3]).astype(np.float64), axis=-1)
+    lim = tol * (1.0 + np.linalg.norm(want[..., :3].astype(np.float64), axis=-1))
+    return bool((err <= lim).all()), float((err / (1.0 + np.linalg.norm(want[..., :3], axis=-1))).max())
+
+
+def make_pair(hip_lib, oracle, cornell, w=W, h=H, seg=4, n=5, flags=0):
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    app = make_app(w, h, max_segments=seg, iterations=n, flags=flags,
+                   debug_mask=hip_lib.DEBUG_HIT_ID | hip_lib.DEBUG_PREV_PIXEL)
+    ref = oracle.OracleApp(w, h, cornell[2], max_segments=seg, iterations=n)
+    return app, ref
+
+
+# ------------------------------------------------------------------------------ numerics contract
+@pytest.mark.parametrize("op,lo,hi", [(0, 1e-38, 1.0), (1, 0.0, 1.0), (2, 0.0, 1.0), (3, 0.0, 1e6), (4, 1e-6, 1e6),
+                                      (7, -87.0, 0.0)])
+def test_contract_math_bit_exact(hip_lib, oracle, op, lo, hi):
+    rng = np.random.default_rng(op)
+    x = rng.uniform(lo, hi, 1 << 20).astype(np.float32)
+    if op == 0:  # log: cover the whole (0,1] range logarithmically, incl. subnormals and the 1e-38 clamp
+        x[: 1 << 19] = np.exp(rng.uniform(np.log(1e-38), 0.0, 1 << 19)).astype(np.float32)
+        x[:4] = [1e-38, 1.0, np.float32(2.0 ** -32), 1.17549435e-38]
+    if op in (1, 2):
+        x[:6] = [0.0, 1.0, 0.125, 0.375, 0.625, 0.875]
+        x[6 : 6 + 65536] = (np.arange(65536, dtype=np.uint64) * 65537 % (1 << 32)).astype(np.float32) * np.float32(2.0 ** -32)
+    with hip_lib.Context(hip_lib.config_default(64, 64)) as ctx:
+        got = ctx.selftest_math(op, x)
+    want = oracle.math_array(5 if op == 7 else op, x)
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_pcg_stream_bit_exact(hip_lib, oracle):
+    states = np.random.default_rng(1).integers(0, 1 << 32, 1 << 18, dtype=np.uint64).astype(np.uint32)
+    with hip_lib.Context(hip_lib.config_default(64, 64)) as ctx:
+        got = ctx.selftest_math(6, states.view(np.float32))
+    want = oracle.math_array(6, states.view(np.float32))
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_fast_exp_within_tolerance(hip_lib, oracle):
+    x = np.random.default_rng(2).uniform(-20, 0, 1 << 18).astype(np.float32)
+    with hip_lib.Context(hip_lib.config_default(64, 64)) as ctx:
+        got = ctx.selftest_math(5, x)
+    want = oracle.math_array(5, x)
+    assert np.abs(got / want - 1).max() < 4e-6
+
+
+# ------------------------------------------------------------------------------ closest hit
+def _random_rays(n, seed):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform([-1.0, 0.0, -1.0], [1.0, 2.0, 6.0], (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    # adversarial: rays aimed exactly at mesh vertices and edge midpoints (shared-edge ties, D4)
+    return rays
+
+
+@pytest.mark.parametrize("flags", [0, 2])  # brute force / forced BVH
+def test_closest_hit_ids_bit_exact(hip_lib, oracle, cornell, flags):
+    xyz, idx, tris = cornell
+    rays = _random_rays(200_000, 3)
+    verts = tris.reshape(-1, 3)
+    mids = 0.5 * (tris[:, 0:3] + tris[:, 3:6])
+    targets = np.concatenate([verts, mids])
+    eye = np.array([-0.001, 1.0, 6.0], np.float32)
+    aimed = np.concatenate([np.broadcast_to(eye, targets.shape), targets - eye], 1).astype(np.float32)
+    rays = np.concatenate([rays, aimed])
+    cfg = hip_lib.config_default(64, 64)
+    cfg.flags = flags
+    with hip_lib.Context(cfg) as ctx:
+        ctx.scene_upload(xyz, idx)
+        ids, ts = ctx.selftest_trace(rays)
+    want_ids, want_ts = oracle.trace_rays(tris, rays)
+    assert np.array_equal(ids, want_ids)
+    assert np.array_equal(bits(ts), bits(want_ts))
+    assert (ids > 0).mean() > 0.2  # the sample does exercise hits
+
+
+# ------------------------------------------------------------------------------ per pass, frames 0..2
+@pytest.mark.parametrize("flags", [0, 2])
+def test_frame_sequence_parity(hip_lib, oracle, cornell, flags):
+    """frames 0-1 static, light.x -0.1 on frame 2 (SURVEY 8d config 1 script), camera z +0.1 on 3"""
+    app, ref = make_pair(hip_lib, oracle, cornell, flags=flags)
+    ctx = app.backend.ctx
+    script = [((), None, None), ((), None, None), (("J",), None, (-0.1, 0, 0)), (("S",), (0, 0, 0.1), None)]
+    worst = 0.0
+    for keys, cam_move, light_move in script:
+        app.updateScene(keys)
+        app.drawVisbilityBuffer()
+        app.computeTemporalGradient()
+        app.drawSceneToImage()
+        got = {p: ctx.readback(getattr(hip_lib, "PLANE_" + p)) for p in
+               ("VIS_ID", "WORLDPOS", "DEPTH", "GRADIENT", "IMAGE", "HIT_ID", "LUT", "LUT_PREV")}
+        rays = ctx.raycount()
+        app.applyTemporalFiltering()
+        final = ctx.readback(hip_lib.PLANE_IMAGE)
+        pp = ctx.readback(hip_lib.PLANE_PREV_PIXEL)
+        app.copyImageToSwapChainsCurrentImage()
+        assert np.array_equal(bits(ctx.readback(hip_lib.PLANE_IMAGE)), bits(final))  # image == previousImage after the copy
+        app.frameCount += 1
+        fo = ref.draw_scene(move_camera=cam_move, move_light=light_move)
+        assert bytes(app.pushConstants) == bytes(ref.pc)
+        assert bytes(app.ubo) == bytes(ref.ubo)
+        assert np.array_equal(got["VIS_ID"], fo.vis)
+        assert np.array_equal(bits(got["WORLDPOS"]), bits(fo.worldpos))
+        assert np.array_equal(bits(got["DEPTH"]), bits(fo.depth))
+        assert np.array_equal(bits(got["LUT"]), bits(fo.lut))
+        assert np.array_equal(bits(got["GRADIENT"]), bits(fo.gradient))
+        assert np.array_equal(got["HIT_ID"], fo.hit_id)
+        assert np.array_equal(bits(got["IMAGE"]), bits(fo.traced)), "traced colour must be bit-exact (D7: NaN == NaN)"
+        assert np.array_equal(pp, fo.prev_pixel)
+        ok, rel = l2_ok(final, fo.image)
+        worst = max(worst, rel)
+        assert ok, f"filtered image outside FILTER_TOL: {rel}"
+    assert ctx.raycount() == rays  # filter passes trace nothing
+    total = sum(1 for _ in script)
+    assert ref.frame == total
+    print("worst filter rel L2", worst)
+
+
+def test_ray_count_matches_oracle(hip_lib, oracle, cornell):
+    app, ref = make_pair(hip_lib, oracle, cornell, w=96, h=64)
+    app.drawScene()
+    fo = ref.draw_scene()
+    assert app.backend.ctx.raycount() == fo.rays
+
+
+def test_exact_filter_flag_is_bit_exact(hip_lib, oracle, cornell):
+    app, ref = make_pair(hip_lib, oracle, cornell, w=96, h=64, flags=hip_lib.FLAG_EXACT_FILTER)
+    ctx = app.backend.ctx
+    for f in range(3):
+        app.updateScene(("J",) if f == 2 else ())
+        app.drawVisbilityBuffer()
+        app.computeTemporalGradient()
+        app.drawSceneToImage()
+        app.applyTemporalFiltering()
+        final = ctx.readback(hip_lib.PLANE_IMAGE)
+        app.copyImageToSwapChainsCurrentImage()
+        app.frameCount += 1
+        fo = ref.draw_scene(move_light=(-0.1, 0, 0) if f == 2 else None)
+        assert np.array_equal(bits(final), bits(fo.image))
+
+
+@pytest.mark.parametrize("n_iter", [1, 2, 4, 9])
+def test_iteration_counts_incl_even(hip_lib, oracle, cornell, n_iter):
+    # default N = 9 (main.cpp:55); an even N leaves `image` unblended
+    app, ref = make_pair(hip_lib, oracle, cornell, w=96, h=64, seg=2, n=n_iter)
+    for _ in range(2):
+        app.updateScene()
+        app.drawVisbilityBuffer()
+        app.computeTemporalGradient()
+        app.drawSceneToImage()
+        app.applyTemporalFiltering()
+        final = app.backend.ctx.readback(hip_lib.PLANE_IMAGE)
+        app.copyImageToSwapChainsCurrentImage()
+        app.frameCount += 1
+        fo = ref.draw_scene()
+        ok, rel = l2_ok(final, fo.image)
+        assert ok, rel
+
+
+def test_ragged_sizes_and_border_clamp(hip_lib, oracle, cornell):
+    # widths/heights that are not multiples of the 64x4 block; stride-9 taps clamp at every border
+    for (w, h) in [(1, 1), (63, 5), (65, 7), (130, 33)]:
+        app, ref = make_pair(hip_lib, oracle, cornell, w=w, h=h, seg=3, n=9)
+        app.drawScene()
+        fo = ref.draw_scene()
+        got = app.backend.ctx.readback(hip_lib.PLANE_PREVIOUS)
+        ok, rel = l2_ok(got.reshape(h, w, 4), fo.image)
+        assert ok, (w, h, rel)
+        assert np.array_equal(app.backend.ctx.readback(hip_lib.PLANE_PREV_VIS_ID).reshape(h, w), fo.vis)
+
+
+def test_reference_default_config_32_segments(hip_lib, oracle, cornell):
+    # the reference's own constants: 32 segments, N = 9 (main.cpp:55, raytrace.comp.glsl:204)
+    app, ref = make_pair(hip_lib, oracle, cornell, w=100, h=80, seg=32, n=9)
+    app.drawScene()
+    fo = ref.draw_scene()
+    assert app.backend.ctx.raycount() == fo.rays
+    got = app.backend.ctx.readback(hip_lib.PLANE_PREVIOUS)
+    ok, rel = l2_ok(got, fo.image)
+    assert ok, rel
+
+
+def test_spp_4(hip_lib, oracle, cornell):
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
+    xyz, idx, tris = cornell
+    cfg = abi.config_default(80, 60)
+    cfg.samples_per_pixel = 4
+    cfg.max_segments = 3
+    ocfg = oracle.config_default(80, 60)
+    ocfg.samples_per_pixel = 4
+    ocfg.max_segments = 3
+    pc, opc = abi.PushConstants(), oracle.PushConstants()
+    for p in (pc, opc):
+        p.frameNumber = 5
+        p.cameraPos[:] = (-0.001, 1.0, 6.0)
+        p.lightPos[:] = (1.0, 1.0, -0.4)
+        p.currentCameraColor[:] = (0.5, 0.5, 0.5)
+    with abi.Context(cfg) as ctx:
+        ctx.scene_upload(xyz, idx)
+        ctx.raytrace(pc)
+        got = ctx.readback(abi.PLANE_IMAGE)
+        rays = ctx.raycount()
+    want, want_rays, _ = oracle.raytrace(ocfg, opc, tris)
+    assert np.array_equal(bits(got), bits(want)) and rays == want_rays
+
+
+# ------------------------------------------------------------------------------ strips on one GPU
+@pytest.mark.parametrize("mode", ["redundant", "exchange"])
+def test_strips_equal_single_frame(hip_lib, oracle, cornell, mode):
+    """two/three virtual ranks as separate contexts on one GPU == the single-context frame, bit for bit
+    (exchange mode: the halo rows are copied between contexts by the test instead of RCCL)."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    w, h, n = 96, 72, 5
+    single = make_app(w, h, max_segments=3, iterations=n)
+    for R in (2, 3):
+        ranks = [make_app(w, h, max_segments=3, iterations=n, rank=r, world=R, mode=mode, torch_planes=False)
+                 for r in range(R)]
+        single.frameCount = 0
+        for frame in range(2):
+            for a in [single] + ranks:
+                a.frameCount = frame
+            single.updateScene()
+            single.drawVisbilityBuffer()
+            single.computeTemporalGradient()
+            single.drawSceneToImage()
+            single.applyTemporalFiltering()
+            want = single.backend.ctx.readback(abi.PLANE_IMAGE)
+            single.copyImageToSwapChainsCurrentImage()
+            for a in ranks:
+                a.updateScene()
+                a.drawVisbilityBuffer()
+                a.computeTemporalGradient()
+                a.drawSceneToImage()
+            pcs = [a.pushConstants for a in ranks]
+            for k in range(1, n + 1):
+                for a in ranks:
+                    a.pushConstants.maxWaveletIteration = n
+                    a.pushConstants.waveletIteration = k
+                if mode == "exchange":
+                    plane = abi.PLANE_IMAGE if k & 1 else abi.PLANE_FILTERED
+                    full = [a.backend.ctx.readback(plane) for a in ranks]
+                    for a, buf in zip(ranks, full):
+                        for peer, send_rows, recv_rows in a.plan.exchange_rows(k):
+                            pb, pbase = full[peer], ranks[peer].backend.ctx.cfg.row_begin
+                            base = a.backend.ctx.cfg.row_begin
+                            buf[recv_rows[0] - base:recv_rows[1] - base] = pb[recv_rows[0] - pbase:recv_rows[1] - pbase]
+                        a.backend.ctx.set_plane(plane, buf)
+                for a in ranks:
+                    a.backend.temporal_filter(a.pushConstants, a.ubo, *a.plan.filter_rows(k))
+            got = np.zeros_like(want)
+            for a in ranks:
+                o0, o1 = a.plan.own
+                got[o0:o1] = a.backend.readback_rows(abi.PLANE_IMAGE, o0, o1)
+                a.copyImageToSwapChainsCurrentImage()
+            assert np.array_equal(bits(got), bits(want)), (mode, R, frame)
+        for a in ranks:
+            a.backend.close()
+
+
+def test_errors(hip_lib, cornell):
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
+    xyz, idx, _ = cornell
+    with abi.Context(abi.config_default(32, 32)) as ctx:
+        pc, ubo = abi.PushConstants(), abi.Ubo()
+        with pytest.raises(abi.RtptError) as e:
+            ctx.raytrace(pc)
+        assert e.value.code == abi.RTPT_E_NO_SCENE
+        ctx.scene_upload(xyz, idx)
+        with pytest.raises(abi.RtptError) as e:
+            ctx.gbuffer(ubo)  # all-zero model matrix is not identity
+        assert e.value.code == abi.RTPT_E_INVALID
+        pc.waveletIteration, pc.maxWaveletIteration = 3, 2
+        with pytest.raises(abi.RtptError):
+            ctx.temporal_filter(pc, ubo)
+        with pytest.raises(abi.RtptError):
+            ctx.raytrace(pc, 10, 40)  # beyond the stored rows
+    bad = abi.config_default(32, 32)
+    bad.struct_size = 4
+    with pytest.raises(abi.RtptError):
+        abi.Context(bad)
