@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py — whole-frame throughput of the hot path on N MI355X (one process per GPU).
+
+A *step* is one `drawScene()` (main.cpp:1090-1113) of the headless host mirror: G-buffer, temporal
+gradient, 1-spp path trace, N a-trous iterations (last one fused with reprojection + blend),
+history hand-over — on synthetic input (the Cornell box, scripted static camera), every buffer
+resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p] [--halo exchange|redundant]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...`; the frame is split into N row strips (strong scaling, BASELINE.json configs[3]).
+
+Prints ONE JSON line (rank 0): metric Mray/s over the whole frame time, ms per frame, the HBM
+roofline of the a-trous kernel measured live with HIP events, and the CPU oracle timed beside it.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[2]/[3]: Cornell box 3840x2160, 1 spp, 4 bounces, 5-level a-trous
+    "4k": dict(width=3840, height=2160, max_segments=4, iterations=5),
+    # BASELINE.json configs[1]
+    "1080p": dict(width=1920, height=1080, max_segments=4, iterations=5),
+    # the reference's own constants (main.cpp:52-55, raytrace.comp.glsl:204)
+    "reference": dict(width=1000, height=800, max_segments=32, iterations=9),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# algorithmic bytes per pixel per launch (SURVEY.md 8d / BASELINE.md 3)
+BYTES_PER_PX = {"k_atrous": 40, "k_atrous_final": 72, "k_gradient": 36, "k_gbuffer": 24, "k_pathtrace": 16}
+
+
+def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=True):
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    app = make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"],
+                   rank=rank, world=world, mode=args.halo, torch_planes=(world > 1))
+    ctx = app.backend.ctx
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(warmup):
+        app.drawScene()
+    fence()
+    ctx.reset_counters()
+    ctx.timing_enable(collect_kernels)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        app.drawScene()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.timing_enable(False)
+    kern = ctx.timing_collect() if collect_kernels else {}
+    rays = ctx.raycount()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays], dtype=torch.int64, device="cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays = int(r.item())
+    plan = app.plan
+    app.backend.close()
+    return elapsed, rays, kern, plan
+
+
+def kernel_report(kern, wl, plan, steps):
+    """per-kernel average launch duration (HIP events on the launch stream) and algorithmic GB/s"""
+    W = wl["width"]
+    rows = {
+        "k_gbuffer": plan.gbuffer_rows(), "k_gradient": plan.gradient_rows(), "k_pathtrace": plan.raytrace_rows(),
+        "k_atrous_final": plan.filter_rows(wl["iterations"]),
+    }
+    out = {}
+    for name, (ms, n) in kern.items():
+        if not n:
+            continue
+        avg_us = ms / n * 1e3
+        e = {"launches_per_frame": n / steps, "avg_us": round(avg_us, 3)}
+        if name == "k_atrous":
+            N = wl["iterations"]
+            ks = [k for k in range(1, N + 1) if not (k == N and N & 1)]  # an odd final pass is k_atrous_final
+            px = sum(b - a for a, b in map(plan.filter_rows, ks)) * W / len(ks)
+        elif name in rows:
+            a, b = rows[name]
+            px = (b - a) * W
+        else:
+            px = None
+        if px and name in BYTES_PER_PX:
+            e["algorithmic_bytes"] = int(BYTES_PER_PX[name] * px)
+            e["algorithmic_GBps"] = round(BYTES_PER_PX[name] * px / (avg_us * 1e-6) / 1e9, 1)
+        out[name] = e
+    return out
+
+
+def cpu_baseline(wl, budget_s=12.0):
+    """the CPU oracle (oracle/rtpt_oracle.c, "port") on a bounded row band of the same workload"""
+    from oracle import oracle as O
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE
+    O.build()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, 16)  # the one-GPU box's CPU share
+    O.set_threads(cores)
+    xyz, idx = O.load_obj(DEFAULT_SCENE)
+    tris = O.flatten(xyz, idx)
+    W, H, N = wl["width"], wl["height"], wl["iterations"]
+    app = O.OracleApp(W, H, tris, max_segments=wl["max_segments"], iterations=N)
+    app.update_scene()
+    import numpy as np
+    lut = O.lut(tris, np.array(app.ubo.model[:], np.float32))
+
+    def band_frame(rows):
+        y0 = H // 2 - rows // 2
+        y1 = y0 + rows
+        g0, g1 = max(0, y0 - N * (N + 1) // 2), min(H, y1 + N * (N + 1) // 2)
+        t0 = time.perf_counter()
+        vis, wp, depth = O.gbuffer(app.cfg, tris, app.ubo, g0, g1)
+        O.temporal_gradient(app.cfg, app.pc, vis, wp, lut, lut, y0, y1)
+        img, rays, _ = O.raytrace(app.cfg, app.pc, tris, g0, g1, want_hit_id=False)
+        own_rays = None
+        app.pc.maxWaveletIteration = N
+        cur = img
+        for k in range(1, N + 1):
+            app.pc.waveletIteration = k
+            rem = sum(range(k + 1, N + 1))
+            cur = O.atrous(app.cfg, app.pc, app.ubo, cur, depth, vis, lut, lut, wp, None,
+                           max(0, y0 - rem), min(H, y1 + rem))
+        dt = time.perf_counter() - t0
+        # rays of the band rows only (the halo rows are overhead of banding, as on a strip rank)
+        _, own_rays, _ = O.raytrace(app.cfg, app.pc, tris, y0, y1, want_hit_id=False)
+        return dt, own_rays
+
+    rows = 16
+    dt, rays = band_frame(rows)
+    while dt < budget_s / 2 and rows < H:
+        rows = min(H, int(rows * min(8.0, max(2.0, budget_s / max(dt, 1e-3) * 0.8))))
+        dt, rays = band_frame(rows)
+    return {
+        "value": round(rays / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
+        "sample": f"{rows} centre rows of the {W}x{H} frame (+{N * (N + 1) // 2} halo rows per side), all passes, "
+                  f"{dt:.1f} s of oracle/rtpt_oracle.c with {cores} OpenMP threads",
+        "ms_per_frame_extrapolated": round(dt / rows * H * 1e3, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k")
+    ap.add_argument("--halo", choices=["exchange", "redundant"], default="exchange")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run "
+                     f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+        world, rank, local_rank = 1, 0, 0
+
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    elapsed, rays, kern, plan = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist)
+    ms_per_step = elapsed / args.steps * 1e3
+    result = None
+    if rank == 0:
+        kr = kernel_report(kern, wl, plan, args.steps)
+        at = kr.get("k_atrous", {})
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and world == 1:
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("k_atrous")
+            except Exception:
+                traffic = None
+        achieved = at.get("algorithmic_GBps")
+        result = {
+            "metric": "Mray/s (closest-hit queries / whole-frame time: G-buffer + gradient + trace + a-trous)",
+            "value": round(rays / elapsed / 1e6, 2),
+            "unit": "Mray/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "fps": round(1e3 / ms_per_step, 1),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (Cornell box OBJ, scripted static camera/light, RNG seeded by pixel+frame)",
+            "config": {"workload": f"cornell-{args.workload}-1spp-{wl['max_segments']}seg-{wl['iterations']}atrous",
+                       "width": wl["width"], "height": wl["height"], "max_segments": wl["max_segments"],
+                       "atrous_iterations": wl["iterations"], "triangles": 32,
+                       "parallelism": f"row-strips x{world}" + (f" ({args.halo} halo)" if world > 1 else "")},
+            "rays_per_frame": round(rays / args.steps, 1),
+            "roofline": {"kernel": "k_atrous (one a-trous iteration, k < N)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                         "avg_launch_us": at.get("avg_us"), "algorithmic_bytes": at.get("algorithmic_bytes"),
+                         "traffic": traffic},
+            "kernels": kr,
+        }
+        pt = kr.get("k_pathtrace")
+        if pt:
+            result["pathtrace_kernel_mray_s"] = round(rays / args.steps / (pt["avg_us"] * 1e-6) / 1e6, 1)
+
+    if world == 1 and rank == 0 and not args.no_secondary and args.workload == "4k":
+        e2, r2, k2, p2 = run_gpu(WORKLOADS["1080p"], args, 0, 1, args.steps, args.warmup, torch, None)
+        kr2 = kernel_report(k2, WORKLOADS["1080p"], p2, args.steps)
+        result["also"] = {"cornell-1080p-1spp-4seg-5atrous": {
+            "value": round(r2 / e2 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
+            "atrous_GBps": kr2.get("k_atrous", {}).get("algorithmic_GBps"),
+            "atrous_frac": round(kr2.get("k_atrous", {}).get("algorithmic_GBps", 0) / HBM_PEAK_GBS, 4)}}
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(wl)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -201,6 +201,10 @@ int rtpt_readback(rtpt_ctx* ctx, rtpt_plane which, void* dst, size_t bytes);
  * "checkpoint/resume": the only cross-frame state is PREVIOUS, PREV_VIS_ID, LUT_PREV) */
 int rtpt_set_plane(rtpt_ctx* ctx, rtpt_plane which, const void* src, size_t bytes);
 int rtpt_reset_counters(rtpt_ctx* ctx);
+/* only closest-hit queries of pixels in frame rows [y0,y1) are added to RAYCOUNT (default: all
+ * stored rows).  Strip ranks that trace halo rows redundantly set this to their owned rows so the
+ * sum over ranks equals the single-GPU count. */
+int rtpt_set_count_rows(rtpt_ctx* ctx, uint32_t y0, uint32_t y1);
 /* enable build-only observables (off by default: they cost extra stores per pixel) */
 #define RTPT_DEBUG_HIT_ID 0x1u     /* RTPT_PLANE_HIT_ID written by rtpt_raytrace */
 #define RTPT_DEBUG_PREV_PIXEL 0x2u /* RTPT_PLANE_PREV_PIXEL written by the final filter pass */

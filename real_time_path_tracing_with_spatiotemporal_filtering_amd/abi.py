@@ -77,7 +77,7 @@ SYMBOLS = [
     "rtpt_config_default", "rtpt_create", "rtpt_destroy", "rtpt_last_error", "rtpt_set_stream", "rtpt_bind_plane",
     "rtpt_plane_ptr", "rtpt_plane_bytes", "rtpt_scene_upload", "rtpt_gbuffer", "rtpt_temporal_gradient",
     "rtpt_raytrace", "rtpt_temporal_filter", "rtpt_end_frame", "rtpt_sync", "rtpt_readback", "rtpt_set_plane",
-    "rtpt_reset_counters", "rtpt_enable_debug", "rtpt_timing_enable", "rtpt_timing_collect", "rtpt_kernel_name",
+    "rtpt_reset_counters", "rtpt_set_count_rows", "rtpt_enable_debug", "rtpt_timing_enable", "rtpt_timing_collect", "rtpt_kernel_name",
     "rtpt_selftest_math", "rtpt_selftest_trace", "rtpt_util_look_at", "rtpt_util_perspective", "rtpt_util_load_obj",
 ]
 
@@ -118,6 +118,7 @@ def load() -> C.CDLL:
         "rtpt_set_plane": [vp, C.c_int, vp, sz],
         "rtpt_reset_counters": [vp],
         "rtpt_enable_debug": [vp, u32],
+        "rtpt_set_count_rows": [vp, u32, u32],
         "rtpt_timing_enable": [vp, C.c_int],
         "rtpt_timing_collect": [vp, C.POINTER(C.c_double * K_COUNT), C.POINTER(u32 * K_COUNT)],
         "rtpt_selftest_math": [vp, C.c_int, vp, vp, sz],
@@ -286,6 +287,9 @@ class Context:
 
     def reset_counters(self):
         _check(self._lib.rtpt_reset_counters(self._h))
+
+    def set_count_rows(self, y0: int, y1: int):
+        _check(self._lib.rtpt_set_count_rows(self._h, y0, y1))
 
     def raycount(self) -> int:
         return int(self.readback(PLANE_RAYCOUNT)[0])

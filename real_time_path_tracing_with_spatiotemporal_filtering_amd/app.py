@@ -22,8 +22,9 @@ SPEED = np.float32(0.1)    # main.cpp:68
 DEFAULT_SCENE = os.path.join(abi.PKG_DIR, "scenes", "CornellBox-Original-Merged.obj")
 
 
-def _np_dtype_to_torch(torch):
-    return {np.float32: torch.float32, np.uint32: torch.int32, np.int32: torch.int32}
+def _null_scope():
+    import contextlib
+    return contextlib.nullcontext()
 
 
 class HipBackend:
@@ -40,6 +41,8 @@ class HipBackend:
         self.ctx = abi.Context(cfg)
         self.width, self.height = width, height
         self._tensors = None
+        self.torch_stream = None
+        self.ctx.set_count_rows(*self.plan.own)
         if debug_mask:
             self.ctx.enable_debug(debug_mask)
         if torch_planes:
@@ -49,7 +52,19 @@ class HipBackend:
             self._tensors = [torch.zeros((rows, width, 4), dtype=torch.float32, device=dev) for _ in range(3)]
             for role, t in zip((abi.PLANE_IMAGE, abi.PLANE_FILTERED, abi.PLANE_PREVIOUS), self._tensors):
                 self.ctx.bind_plane(role, t.data_ptr(), t.numel() * 4)
-            self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            # a dedicated non-default stream: the kernels and the RCCL point-to-point ops issued while
+            # it is current are ordered with each other (the default stream's handle is 0, which the
+            # ABI reads as "use the context's own stream")
+            self.torch_stream = torch.cuda.Stream(device=dev)
+            self.ctx.set_stream(self.torch_stream.cuda_stream)
+
+    def stream_scope(self):
+        """context manager making the stream the kernels run on torch's current stream"""
+        if self.torch_stream is None:
+            import contextlib
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(self.torch_stream)
 
     # passes ------------------------------------------------------------------------------
     def scene_upload(self, xyz, idx, xforms=None):
@@ -224,12 +239,14 @@ class PathTracingApplication:
 
     def drawScene(self, keys=()):
         """main.cpp:1090-1113."""
-        self.updateScene(keys)
-        self.drawVisbilityBuffer()
-        self.computeTemporalGradient()
-        self.drawSceneToImage()
-        self.applyTemporalFiltering()
-        self.copyImageToSwapChainsCurrentImage()
+        scope = getattr(self.backend, "stream_scope", None)
+        with (scope() if scope else _null_scope()):
+            self.updateScene(keys)
+            self.drawVisbilityBuffer()
+            self.computeTemporalGradient()
+            self.drawSceneToImage()
+            self.applyTemporalFiltering()
+            self.copyImageToSwapChainsCurrentImage()
         self.frameCount += 1
 
     def run(self, frames: int, script=None):

@@ -72,6 +72,7 @@ struct rtpt_ctx {
   int hist_y0 = 0, hist_y1 = 0;  // rows of PREVIOUS holding a valid previous frame
   int final_y0 = 0, final_y1 = 0;
   uint32_t debug_mask = 0;
+  int count_y0 = 0, count_y1 = 0;  // rows counted into RAYCOUNT
 
   // timing
   bool timing = false;
@@ -273,6 +274,8 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
     return fail(RTPT_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   }
   c->stream = c->own_stream;
+  c->count_y0 = static_cast<int>(cfg->row_begin);
+  c->count_y1 = static_cast<int>(cfg->row_end);
   const size_t px = c->pixels();
   int rc = RTPT_OK;
   for (int i = 0; i < 3 && rc == RTPT_OK; i++) rc = alloc_buf(c->color[i], px * 16);
@@ -555,6 +558,8 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   a.image = static_cast<float4*>(c->color[c->color_of_role[ROLE_IMAGE]].ptr);
   a.hit_id = (c->debug_mask & RTPT_DEBUG_HIT_ID) ? static_cast<uint32_t*>(c->hit_id.ptr) : nullptr;
   a.raycount = static_cast<unsigned long long*>(c->raycount.ptr);
+  a.count_y0 = c->count_y0;
+  a.count_y1 = c->count_y1;
   c->final_swapped = false;
   c->image_alias = false;
   {
@@ -700,6 +705,14 @@ int rtpt_reset_counters(rtpt_ctx* c) {
   if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemsetAsync(c->raycount.ptr, 0, 8, c->stream));
+  return RTPT_OK;
+}
+
+int rtpt_set_count_rows(rtpt_ctx* c, uint32_t y0, uint32_t y1) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  if (y0 > y1) return fail(RTPT_E_INVALID, "y0 > y1");
+  c->count_y0 = static_cast<int>(y0);
+  c->count_y1 = static_cast<int>(y1);
   return RTPT_OK;
 }
 

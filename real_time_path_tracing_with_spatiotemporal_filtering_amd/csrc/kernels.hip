@@ -380,6 +380,7 @@ __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
     if (a.hit_id) a.hit_id[i] = first_id;
   }
   // "ray" = one closest-hit query; one 64-bit atomic per block
+  if (y < a.count_y0 || y >= a.count_y1) rays = 0;
   for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
   if ((tid & 63) == 0 && rays) atomicAdd(&block_rays, rays);
   __syncthreads();

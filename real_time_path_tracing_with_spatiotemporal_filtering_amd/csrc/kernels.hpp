@@ -73,6 +73,7 @@ struct PathtraceArgs {
   float4* image;
   uint32_t* hit_id;  // nullable
   unsigned long long* raycount;
+  int32_t count_y0, count_y1;  // rows whose queries are counted
 };
 
 struct AtrousArgs {
