@@ -90,6 +90,9 @@ typedef struct rtpt_visibility_data {
 #define RTPT_FLAG_FORCE_BVH 0x2u    /* traverse the BVH even for scenes small enough for the
                                        wave-uniform brute-force path (<= 64 triangles) */
 
+#define RTPT_FLAG_DIRECT_FILTER 0x4u /* a-trous taps by direct global loads instead of the LDS-staged
+                                       tile kernel (the fallback for strides whose halo exceeds LDS) */
+
 typedef struct rtpt_config {
   uint32_t struct_size;          /* = sizeof(rtpt_config), ABI guard */
   uint32_t width, height;        /* full frame; main.cpp:52-53 (1000x800) */

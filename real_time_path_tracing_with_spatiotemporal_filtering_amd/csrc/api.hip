@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -57,7 +58,7 @@ struct rtpt_ctx {
   int vis_cur = 0;  // vis[vis_cur] = VIS_ID, the other PREV_VIS_ID
   Buf lut[2];
   int lut_cur = 0;
-  Buf worldpos, gradient, depth, prev_pixel, hit_id, raycount, normal_tab;
+  Buf worldpos, gradient, depth, prev_pixel, hit_id, raycount, normal_tab, pair_tab;
 
   // scene
   uint32_t n_tris = 0;
@@ -316,7 +317,7 @@ int rtpt_destroy(rtpt_ctx* c) {
   for (auto& b : c->color) free_buf(b);
   for (auto& b : c->vis) free_buf(b);
   for (auto& b : c->lut) free_buf(b);
-  for (Buf* b : {&c->worldpos, &c->gradient, &c->depth, &c->prev_pixel, &c->hit_id, &c->raycount, &c->normal_tab, &c->tris,
+  for (Buf* b : {&c->worldpos, &c->gradient, &c->depth, &c->prev_pixel, &c->hit_id, &c->raycount, &c->normal_tab, &c->pair_tab, &c->tris,
                  &c->leaf_order, &c->isect_id, &c->isect_leaf, &c->shade, &c->nodes})
     free_buf(*b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -426,6 +427,7 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   if ((rc = alloc_buf(c->shade, static_cast<size_t>(total) * 48))) return rc;
   if ((rc = alloc_buf(c->nodes, bvh.nodes.size() * sizeof(rt::BvhNode)))) return rc;
   if ((rc = alloc_buf(c->normal_tab, (static_cast<size_t>(total) + 1) * 16))) return rc;
+  if ((rc = alloc_buf(c->pair_tab, total + 1 <= 64 ? (static_cast<size_t>(total) + 1) * (total + 1) * 4 : 0))) return rc;
   for (int i = 0; i < 2; i++)
     if ((rc = alloc_buf(c->lut[i], (static_cast<size_t>(total) + 1) * sizeof(rtpt_visibility_data)))) return rc;
   HIP_TRY(hipMemcpyAsync(c->tris.ptr, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -466,6 +468,7 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
     std::memcpy(la.model, ubo->model, sizeof la.model);
     la.lut = static_cast<float4*>(c->lut[c->lut_cur].ptr);
     la.normal_tab = static_cast<float4*>(c->normal_tab.ptr);
+    la.pair_tab = static_cast<float*>(c->pair_tab.ptr);
     la.sigma_n = c->cfg.sigma_n;
     rt::launch_lut(la, c->stream);
   }
@@ -598,11 +601,13 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
   a.g = geom(c, y0, y1);
   a.k = k;
   a.exact = (c->cfg.flags & RTPT_FLAG_EXACT_FILTER) ? 1 : 0;
+  a.direct = (c->cfg.flags & RTPT_FLAG_DIRECT_FILTER) ? 1 : 0;
+  a.n_tris = c->n_tris;
+  a.pair_tab = static_cast<const float*>(c->pair_tab.ptr);
+  a.rows_stored = static_cast<int32_t>(c->rows());
   a.sigma_n = c->cfg.sigma_n;
   a.sigma_z = c->cfg.sigma_z;
   a.sigma_l = c->cfg.sigma_l;
-  a.inv_sigma_z = 1.0f / c->cfg.sigma_z;
-  a.inv_sigma_l = 1.0f / c->cfg.sigma_l;
   a.in = static_cast<const float4*>(c->color[c->color_of_role[in_role]].ptr);
   a.out = static_cast<float4*>(c->color[c->color_of_role[out_role]].ptr);
   a.depth = static_cast<const float*>(c->depth.ptr);

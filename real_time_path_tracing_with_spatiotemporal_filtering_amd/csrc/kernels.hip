@@ -8,19 +8,10 @@
 //                                 reprojection + blend (:213-263)
 //
 // No MFMA anywhere: nothing on this path is a dense contraction.  Compile with -ffp-contract=off.
-#include "kernels.hpp"
-
-#include "rtpt_math.hpp"
+#include "device_common.hpp"
 
 namespace rt {
 namespace {
-
-constexpr int kBlockX = 64;  // one wave = 64 consecutive pixels of a row: 1 KiB float4 stores
-constexpr int kBlockY = 4;
-constexpr int kThreads = kBlockX * kBlockY;
-
-__device__ __forceinline__ f3 ld3(const float* p) { return f3{p[0], p[1], p[2]}; }
-__device__ __forceinline__ f3 xyz(float4 v) { return f3{v.x, v.y, v.z}; }
 
 // ------------------------------------------------------------------------------------------
 // closest hit.  D4: the winner is min over (t, id) of ONE ray-triangle routine, so the result
@@ -69,7 +60,9 @@ __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float
 // (s_load_dwordx4 -> SGPR operands of the VALU ops).  No stack, no divergence, no memory latency.
 __device__ __forceinline__ void closest_hit_brute(const SceneView& sc, f3 o, f3 d, HitRec& h) {
   const float4* rec = sc.isect_id;
-  for (uint32_t i = 0; i < sc.n_tris; i++) {
+  const uint32_t n = sc.n_tris;
+#pragma unroll 4
+  for (uint32_t i = 0; i < n; i++) {
     float4 r0 = rec[3 * i], r1 = rec[3 * i + 1], r2 = rec[3 * i + 2];
     tri_test<false>(o, d, r0, r1, r2, i + 1, h);
   }
@@ -200,6 +193,16 @@ __global__ void k_lut(LutArgs a) {
   a.normal_tab[t + 1] = make_float4(n.x, n.y, n.z, exact::powi(glsl_max(0.0f, exact::dot(n, n)), a.sigma_n));
 }
 
+// pow(max(0, dot(n_p, n_q)), sigma_n) for every id pair (temporalFiltering.comp.glsl:62), small scenes
+__global__ void k_pair_weights(LutArgs a) {
+  const uint32_t np = a.n_tris + 1;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np * np) return;
+  const uint32_t p = i / np, q = i - p * np;
+  const f3 n_p = xyz(a.normal_tab[p]), n_q = xyz(a.normal_tab[q]);
+  a.pair_tab[i] = exact::powi(glsl_max(0.0f, exact::dot(n_p, n_q)), a.sigma_n);
+}
+
 // ------------------------------------------------------------------------------------------
 // K0 G-buffer
 // ------------------------------------------------------------------------------------------
@@ -238,16 +241,6 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
 // ------------------------------------------------------------------------------------------
 // K1 temporal gradient
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float tri_area(f3 a, f3 b, f3 c) { return exact::length(exact::cross(b - a, c - a)) * 0.5f; }
-__device__ __forceinline__ f3 bary_coords(f3 p, f3 a, f3 b, f3 c) {
-  float at = tri_area(a, b, c);
-  return f3{tri_area(p, b, c) / at, tri_area(a, p, c) / at, tri_area(a, b, p) / at};
-}
-__device__ __forceinline__ f3 bary_mix(f3 bc, f3 a, f3 b, f3 c) {
-  return f3{fmaf_(bc.z, c.x, fmaf_(bc.y, b.x, bc.x * a.x)), fmaf_(bc.z, c.y, fmaf_(bc.y, b.y, bc.x * a.y)),
-            fmaf_(bc.z, c.z, fmaf_(bc.y, b.z, bc.x * a.z))};
-}
-
 // temporalGradient.comp.glsl:71-101
 __device__ __forceinline__ f3 phong(f3 p, f3 n, f3 cam, f3 lpos, f3 lcol) {
   f3 ldir = exact::normalize(lpos - p);
@@ -388,102 +381,6 @@ __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K3 a-trous iteration (3x3 taps at stride k, h = 1/9, edge-stopping on normal/depth/colour)
-// ------------------------------------------------------------------------------------------
-template <bool EXACT>
-__device__ __forceinline__ float w_exp(float x) {
-  if (EXACT) return exact::exp_(x);
-  return fast::exp_(x);
-}
-
-template <bool FINAL, bool EXACT>
-__global__ __launch_bounds__(kThreads) void k_atrous(AtrousArgs a) {
-  const int x = blockIdx.x * kBlockX + threadIdx.x;
-  const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
-  if (x >= a.g.W || y >= a.g.y1) return;
-  const int W = a.g.W, H = a.g.H, k = a.k;
-  const size_t ip = static_cast<size_t>(y - a.g.row_base) * W + x;
-  const float4 cp4 = a.in[ip];
-  const f3 cp = xyz(cp4);
-  const float dp = a.depth[ip];
-  const uint32_t idp = a.vis[ip];
-  const float4 np4 = a.normal_tab[idp];
-  const f3 np = xyz(np4);
-  f3 num{0.f, 0.f, 0.f};
-  float den = 0.f;
-  const float h = 1.0f / 9.0f;  // temporalFiltering.comp.glsl:145
-#pragma unroll
-  for (int i = -1; i < 2; i++) {  // :132
-    int qx = x + i * k;
-    qx = qx < 0 ? 0 : (qx > W - 1 ? W - 1 : qx);  // :136
-#pragma unroll
-    for (int j = -1; j < 2; j++) {  // :133
-      int qy = y + j * k;
-      qy = qy < 0 ? 0 : (qy > H - 1 ? H - 1 : qy);
-      const size_t iq = static_cast<size_t>(qy - a.g.row_base) * W + qx;
-      const f3 cq = xyz(a.in[iq]);
-      const float dq = a.depth[iq];
-      const uint32_t idq = a.vis[iq];
-      float wn;
-      if (idq == idp) {
-        wn = np4.w;  // pow(max(0, dot(np,np)), sigma_n), precomputed per id (same bits)
-      } else {
-        const f3 nq = xyz(a.normal_tab[idq]);
-        wn = exact::powi(glsl_max(0.0f, exact::dot(np, nq)), a.sigma_n);  // :62
-      }
-      float wd, wl;
-      const f3 dc = cp - cq;
-      if (EXACT) {
-        wd = exact::exp_(-__builtin_fabsf(dp - dq) / a.sigma_z);          // :67-68
-        wl = exact::exp_(-exact::length(dc) / a.sigma_l);                 // :73
-      } else {
-        wd = fast::exp_(-__builtin_fabsf(dp - dq) * a.inv_sigma_z);
-        wl = fast::exp_(-fast::sqrt_(exact::dot(dc, dc)) * a.inv_sigma_l);
-      }
-      const float w = (wn * wd) * wl;  // :77
-      const float hw = h * w;
-      num = f3{fmaf_(hw, cq.x, num.x), fmaf_(hw, cq.y, num.y), fmaf_(hw, cq.z, num.z)};  // :146
-      den = den + hw;                                                                    // :147
-    }
-  }
-  f3 filtered;
-  if (EXACT) {
-    filtered = f3{num.x / den, num.y / den, num.z / den};  // :150
-  } else {
-    const float rd = fast::rcp_(den);
-    filtered = num * rd;
-  }
-  if (!FINAL) {
-    a.out[ip] = make_float4(filtered.x, filtered.y, filtered.z, 0.0f);  // :152
-    return;
-  }
-  // :213-239 reprojection — exact arithmetic: the truncated pixel coordinate is an integer observable
-  int ppx = x, ppy = y;
-  if (!(idp < 1)) {
-    const f3 wp = xyz(a.worldpos[ip]);
-    const f3 va = xyz(a.lut_prev[3 * idp]), vb = xyz(a.lut_prev[3 * idp + 1]), vc = xyz(a.lut_prev[3 * idp + 2]);  // :223-233
-    const f3 bc = bary_coords(wp, va, vb, vc);
-    const f3 wpp = bary_mix(bc, va, vb, vc);  // :236
-    const float clx = exact::mat_row_point(a.PVprev, 0, wpp), cly = exact::mat_row_point(a.PVprev, 1, wpp),
-                clw = exact::mat_row_point(a.PVprev, 3, wpp);
-    const float ndx = clx / clw, ndy = cly / clw;                 // :183
-    ppx = exact::f2i(fmaf_(ndx, 0.5f, 0.5f) * static_cast<float>(W));  // :186,:238
-    ppy = exact::f2i(fmaf_(ndy, 0.5f, 0.5f) * static_cast<float>(H));
-  }
-  if (a.prev_pixel) a.prev_pixel[ip] = make_int2(ppx, ppy);
-  f3 blend = filtered;  // :258
-  if (a.frame > 0) {    // :251
-    f3 hc{0.f, 0.f, 0.f};  // D2: out-of-image history fetch returns 0
-    if (ppx >= 0 && ppx < W && ppy >= a.hist_y0 && ppy < a.hist_y1)
-      hc = xyz(a.history[static_cast<size_t>(ppy - a.hist_row_base) * W + ppx]);
-    const float oma = 1.0f - a.alpha;
-    blend = f3{fmaf_(filtered.x, a.alpha, hc.x * oma), fmaf_(filtered.y, a.alpha, hc.y * oma),
-               fmaf_(filtered.z, a.alpha, hc.z * oma)};  // :254
-  }
-  a.out[ip] = make_float4(blend.x, blend.y, blend.z, 0.0f);  // :263 (D1: distinct buffer)
-}
-
-// ------------------------------------------------------------------------------------------
 // self tests
 // ------------------------------------------------------------------------------------------
 __global__ void k_selftest_math(int op, const float* in, float* out, size_t n) {
@@ -517,10 +414,6 @@ __global__ __launch_bounds__(kThreads) void k_selftest_trace(SceneView sc, const
   if (out_t) out_t[i] = h.id1 ? h.t : 0.0f;
 }
 
-inline dim3 grid_for(const FrameGeom& g) {
-  return dim3((g.W + kBlockX - 1) / kBlockX, (g.y1 - g.y0 + kBlockY - 1) / kBlockY, 1);
-}
-
 }  // namespace
 
 void launch_scene_prepare(const ScenePrepArgs& a, hipStream_t s) {
@@ -529,6 +422,10 @@ void launch_scene_prepare(const ScenePrepArgs& a, hipStream_t s) {
 }
 void launch_lut(const LutArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_lut, dim3((a.n_tris + 256) / 256), dim3(256), 0, s, a);
+  if (a.pair_tab) {
+    const uint32_t n = (a.n_tris + 1) * (a.n_tris + 1);
+    hipLaunchKernelGGL(k_pair_weights, dim3((n + 255) / 256), dim3(256), 0, s, a);
+  }
 }
 void launch_gbuffer(const GbufferArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;
@@ -547,21 +444,6 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_pathtrace<true>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
   else
     hipLaunchKernelGGL(k_pathtrace<false>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
-}
-void launch_atrous(const AtrousArgs& a, bool final_pass, hipStream_t s) {
-  if (a.g.y1 <= a.g.y0) return;
-  dim3 grid = grid_for(a.g), block(kBlockX, kBlockY);
-  if (a.exact) {
-    if (final_pass)
-      hipLaunchKernelGGL((k_atrous<true, true>), grid, block, 0, s, a);
-    else
-      hipLaunchKernelGGL((k_atrous<false, true>), grid, block, 0, s, a);
-  } else {
-    if (final_pass)
-      hipLaunchKernelGGL((k_atrous<true, false>), grid, block, 0, s, a);
-    else
-      hipLaunchKernelGGL((k_atrous<false, false>), grid, block, 0, s, a);
-  }
 }
 void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s) {
   if (!n) return;

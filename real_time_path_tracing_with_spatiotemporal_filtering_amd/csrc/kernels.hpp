@@ -46,6 +46,7 @@ struct LutArgs {
   float model[16];
   float4* lut;          // (n+1) x 3 float4 (stride 48 B)
   float4* normal_tab;   // (n+1) float4: xyz = unit normal of LUT[id] (id 0: (0,0,1)), w = self weight
+  float* pair_tab;      // (n+1)^2 pow(max(0,dot(n_p,n_q)),sigma_n), NULL when n+1 > 64
   int32_t sigma_n;
 };
 
@@ -80,8 +81,14 @@ struct AtrousArgs {
   FrameGeom g;
   int32_t k;             // tap stride = waveletIteration
   int32_t exact;         // 1: contract arithmetic for the weights (RTPT_FLAG_EXACT_FILTER)
+  int32_t direct;        // 1: force the direct-load kernel (no LDS staging)
+  int32_t rows_stored;   // rows held by the planes (row_base .. row_base+rows_stored-1)
+  int32_t cwp;           // comb kernel: staged row length in cells (set by launch_atrous)
+  const float* pair_tab; // (n_tris+1)^2 id-pair normal weights, NULL when the scene is too large
+  uint32_t n_tris;       // normal_tab has n_tris + 1 entries
   int32_t sigma_n;
-  float inv_sigma_z, inv_sigma_l;  // fast path multiplies by reciprocals
+  float cz, cl;          // fast path: -log2(e)/sigma_z, -log2(e)/sigma_l (set by launch_atrous)
+  int32_t tiles_x, tiles_y;  // 64x4 tiles covering [y0,y1) (set by launch_atrous)
   float sigma_z, sigma_l;
   const float4* in;
   float4* out;

@@ -1,8 +1,9 @@
-import sys, time
+import sys, time, os
 sys.path.insert(0, '.')
 from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
 from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
-for (w,h) in [(1920,1080),(3840,2160)]:
+sizes = [(3840,2160)] if len(sys.argv)<2 else [tuple(map(int,a.split('x'))) for a in sys.argv[1:]]
+for (w,h) in sizes:
     app = make_app(w,h,max_segments=4,iterations=5)
     ctx = app.backend.ctx
     for _ in range(3): app.drawScene()
@@ -11,9 +12,5 @@ for (w,h) in [(1920,1080),(3840,2160)]:
     for _ in range(20): app.drawScene()
     ctx.sync(); dt=time.time()-t
     tm = ctx.timing_collect(); rays = ctx.raycount()
-    print(w,h,'ms/frame',dt/20*1e3,'Mray/s',rays/dt/1e6)
-    for k,(ms,n) in tm.items():
-        if n: print('   ',k,ms/n*1e3,'us x',n//20)
-    px=w*h
-    print('   atrous GB/s', 40*px/(tm['k_atrous'][0]/tm['k_atrous'][1]*1e-3)/1e9, 'final GB/s', 72*px/(tm['k_atrous_final'][0]/tm['k_atrous_final'][1]*1e-3)/1e9)
+    print('EXP',os.environ.get('RTPT_EXPERIMENT'),w,h,'ms/frame %.3f'%(dt/20*1e3),'Mray/s %.0f'%(rays/dt/1e6), ' '.join('%s=%.1f'%(k[2:],ms/n*1e3) for k,(ms,n) in tm.items() if n))
     app.backend.close()
