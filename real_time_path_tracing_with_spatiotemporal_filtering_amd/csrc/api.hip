@@ -54,6 +54,7 @@ struct rtpt_ctx {
 
   Buf color[3];          // physical RGBA32F buffers
   int color_of_role[3];  // role -> physical index
+  bool alpha_depth[3] = {false, false, false};  // physical buffer carries depth in alpha ("rgbd")
   Buf vis[2];
   int vis_cur = 0;  // vis[vis_cur] = VIS_ID, the other PREV_VIS_ID
   Buf lut[2];
@@ -363,6 +364,8 @@ int rtpt_bind_plane(rtpt_ctx* c, rtpt_plane which, void* device_ptr, size_t byte
   b->ptr = device_ptr;
   b->bytes = bytes;
   b->owned = false;
+  for (int i = 0; i < 3; i++)
+    if (b == &c->color[i]) c->alpha_depth[i] = false;
   return RTPT_OK;
 }
 
@@ -559,6 +562,8 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   a.ray_offset = c->cfg.ray_offset;
   a.tmax = c->cfg.ray_tmax;
   a.image = static_cast<float4*>(c->color[c->color_of_role[ROLE_IMAGE]].ptr);
+  a.depth = static_cast<const float*>(c->depth.ptr);
+  c->alpha_depth[c->color_of_role[ROLE_IMAGE]] = true;
   a.hit_id = (c->debug_mask & RTPT_DEBUG_HIT_ID) ? static_cast<uint32_t*>(c->hit_id.ptr) : nullptr;
   a.raycount = static_cast<unsigned long long*>(c->raycount.ptr);
   a.count_y0 = c->count_y0;
@@ -610,9 +615,15 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
   a.sigma_l = c->cfg.sigma_l;
   a.in = static_cast<const float4*>(c->color[c->color_of_role[in_role]].ptr);
   a.out = static_cast<float4*>(c->color[c->color_of_role[out_role]].ptr);
-  a.depth = static_cast<const float*>(c->depth.ptr);
   a.vis = static_cast<const uint32_t*>(c->vis[c->vis_cur].ptr);
   a.normal_tab = static_cast<const float4*>(c->normal_tab.ptr);
+  if (!c->alpha_depth[c->color_of_role[in_role]]) {
+    // the input plane was injected (rtpt_set_plane / rtpt_bind_plane): give it its depth channel
+    rt::launch_stamp_depth(geom(c, c->cfg.row_begin, c->cfg.row_end), static_cast<float4*>(c->color[c->color_of_role[in_role]].ptr),
+                           static_cast<const float*>(c->depth.ptr), c->stream);
+    c->alpha_depth[c->color_of_role[in_role]] = true;
+  }
+  c->alpha_depth[c->color_of_role[out_role]] = !final_pass;
   if (final_pass) {
     a.frame = pc->frameNumber;
     a.alpha = c->cfg.alpha;
@@ -685,6 +696,12 @@ int rtpt_readback(rtpt_ctx* c, rtpt_plane which, void* dst, size_t bytes) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpyAsync(dst, b->ptr, need, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 3; i++)
+    if (b == &c->color[i] && c->alpha_depth[i]) {
+      // the reference's colour images have alpha 0; internally alpha carries depth between passes
+      float* f = static_cast<float*>(dst);
+      for (size_t px = 0, n = need / 16; px < n; px++) f[4 * px + 3] = 0.0f;
+    }
   return RTPT_OK;
 }
 
@@ -698,6 +715,8 @@ int rtpt_set_plane(rtpt_ctx* c, rtpt_plane which, const void* src, size_t bytes)
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpyAsync(b->ptr, src, need, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 3; i++)
+    if (b == &c->color[i]) c->alpha_depth[i] = false;
   if (which == RTPT_PLANE_PREVIOUS) {
     c->hist_y0 = static_cast<int>(c->cfg.row_begin);
     c->hist_y1 = static_cast<int>(c->cfg.row_end);

@@ -9,6 +9,13 @@
 // Measured on MI355X at 3840x2160 (profiles/): the direct kernel is bound by the vector-memory pipe
 // (27 load instructions per pixel: 107 us even with every tap an L1 hit); tile kernels with a
 // workgroup barrier run the chip in load/compute lockstep.  The comb kernel has neither problem.
+//
+// Colour planes are "rgbd" while a frame is being filtered: the alpha channel, which the reference
+// always writes as 0 (raytrace.comp.glsl:343, temporalFiltering.comp.glsl:152), carries the pixel's
+// G-buffer depth from rtpt_raytrace through every non-final pass, so a tap is ONE 16-byte cell
+// (colour + depth) plus the 4-byte id instead of three separate planes — 36 instead of 40 bytes of
+// HBM traffic per pixel and a third fewer load instructions.  The final pass writes alpha 0 again;
+// the C-ABI layer hides the convention (rtpt_readback masks alpha, rtpt_set_plane re-stamps depth).
 #include "device_common.hpp"
 
 namespace rt {
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(kThreads) void k_atrous(AtrousArgs a) {
   const size_t rowp = static_cast<size_t>(y - a.g.row_base) * W;
   const float4 cp4 = a.in[rowp + x];
   const f3 cp = xyz(cp4);
-  const float dp = a.depth[rowp + x];
+  const float dp = cp4.w;  // rgbd
   const uint32_t idp = a.vis[rowp + x];
   const float4 np4 = a.normal_tab[idp];
   const f3 np = xyz(np4);
@@ -86,8 +93,9 @@ __global__ __launch_bounds__(kThreads) void k_atrous(AtrousArgs a) {
       } else {
         const size_t rowq = static_cast<size_t>(qys[j] - a.g.row_base) * W;
         const int qx = qxs[i];
-        cq = xyz(a.in[rowq + qx]);
-        const float dq = a.depth[rowq + qx];
+        const float4 cq4 = a.in[rowq + qx];
+        cq = xyz(cq4);
+        const float dq = cq4.w;  // rgbd
         const uint32_t idq = a.vis[rowq + qx];
         float wn;
         if (idq == idp) {
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void k_atrous(AtrousArgs a) {
     filtered = num * rd;
   }
   if (!FINAL) {
-    a.out[rowp + x] = make_float4(filtered.x, filtered.y, filtered.z, 0.0f);  // :152
+    a.out[rowp + x] = make_float4(filtered.x, filtered.y, filtered.z, dp);  // :152 (+ depth in alpha)
     return;
   }
   // :213-239 reprojection — exact arithmetic: the truncated pixel coordinate is an integer observable
@@ -162,11 +170,12 @@ __global__ __launch_bounds__(kThreads) void k_atrous(AtrousArgs a) {
 // that pass and is ordered by hand: counted vmcnt + s_barrier before the reads (below).  M0 carries
 // the wave-uniform LDS byte address; lane i lands at M0 + i*size.  One wait state is required between
 // the SALU write of M0 and the LDS-DMA that reads it.
-__device__ __forceinline__ void dma_b128(const void* g, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
+// `base` is a wave-uniform pointer (SGPR pair), `voff` the per-lane byte offset: no 64-bit VALU math.
+__device__ __forceinline__ void dma_b128(const void* base, uint32_t voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
-__device__ __forceinline__ void dma_b32(const void* g, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_addr) : "memory");
+__device__ __forceinline__ void dma_b32(const void* base, uint32_t voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
 
 
@@ -187,69 +196,105 @@ __device__ __forceinline__ void dma_b32(const void* g, uint32_t lds_addr) {
 constexpr int kCombM = 2;       // output rows per wave
 constexpr int kPairMax = 64;    // ids (T+1) for which the pair table is kept in LDS
 
-template <bool FINAL, bool EXACT>
-__global__ __launch_bounds__(kThreads) void k_atrous_comb(AtrousArgs a) {
+template <int CWp, bool FINAL, bool EXACT>  // CWp: staged row stride in cells, >= 64 + 2k (compile time:
+__global__ __launch_bounds__(kThreads) void k_atrous_comb(AtrousArgs a) {  // tap rows become ds_read immediates)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int W = a.g.W, H = a.g.H, k = a.k;
-  const int CWp = a.cwp;                       // staged row length in cells (64 + 2k rounded up to 8)
-  const int rows = kCombM + 2, cells = rows * CWp;
+  constexpr int rows = kCombM + 2, cells = rows * CWp;
   const int NP = static_cast<int>(a.n_tris) + 1;
   const int lane = static_cast<int>(threadIdx.x);
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   float* pairw = reinterpret_cast<float*>(lds_raw);  // [NP][NP]
   const int pair_bytes = (NP * NP * 4 + 15) & ~15;
-  unsigned char* mine = lds_raw + pair_bytes + wave * (cells * 24);
-  const float4* col = reinterpret_cast<const float4*>(mine);
-  const float* dep = reinterpret_cast<const float*>(mine + 16 * cells);
-  const uint32_t* ids = reinterpret_cast<const uint32_t*>(mine + 20 * cells);
+  unsigned char* mine = lds_raw + pair_bytes + wave * (cells * 20);
+  const float4* col = reinterpret_cast<const float4*>(mine);                // (r, g, b, depth)
+  const uint32_t* ids = reinterpret_cast<const uint32_t*>(mine + 16 * cells);
   const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)mine));
-  const uint32_t lds_col = lds0, lds_dep = lds0 + 16u * static_cast<uint32_t>(cells),
-                 lds_ids = lds0 + 20u * static_cast<uint32_t>(cells);
+  const uint32_t lds_col = lds0, lds_ids = lds0 + 16u * static_cast<uint32_t>(cells);
 
   // id-pair weight table -> LDS (plain loads; no DMA is in flight yet)
   for (int i = wave * 64 + lane; i < NP * NP; i += kThreads) pairw[i] = a.pair_tab[i];
   __syncthreads();
 
-  // comb of this wave
-  const int bx = static_cast<int>(blockIdx.x % static_cast<uint32_t>(a.tiles_x));
-  const int q = static_cast<int>(blockIdx.x / static_cast<uint32_t>(a.tiles_x)) * kBlockY + wave;
-  const int chunk = q / k, r = q - chunk * k;
-  const int yc = a.g.y0 + chunk * (kCombM * k) + r;  // first output row of the comb
-  if (yc >= a.g.y1) return;                          // (after the only barrier)
-  const int x0 = bx * kBlockX;
+  // Work list.  A logical block = four CONSECUTIVE chunks (one per wave) of one residue and one
+  // column: chunk c and c+1 share two of their four staged rows, so the second fetch is an L1/L2 hit.
+  // Logical blocks are ordered (residue, column, chunk group); each XCD (physical blocks b, b+8, ...)
+  // owns a contiguous eighth of that order and each of its resident blocks a contiguous run of it, so
+  // consecutive iterations of a block walk down one column and re-use the rows they share.  The grid
+  // is persistent (<= 5 blocks per CU): the pair table is loaded once per block, not per comb.
+  // Speed only, never correctness: any mapping filters every pixel exactly once.
+  const uint32_t per_res = static_cast<uint32_t>(a.tiles_x) * static_cast<uint32_t>(a.tiles_y);  // tiles_y = chunk groups
+  const uint32_t nlb = per_res * static_cast<uint32_t>(k);
+  const uint32_t xcd = blockIdx.x & 7u, jx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const uint32_t x_lo = static_cast<uint32_t>((static_cast<uint64_t>(nlb) * xcd) >> 3);
+  const uint32_t x_hi = static_cast<uint32_t>((static_cast<uint64_t>(nlb) * (xcd + 1)) >> 3);
+  const uint32_t lb_lo = x_lo + static_cast<uint32_t>((static_cast<uint64_t>(x_hi - x_lo) * jx) / per_xcd);
+  const uint32_t lb_hi = x_lo + static_cast<uint32_t>((static_cast<uint64_t>(x_hi - x_lo) * (jx + 1)) / per_xcd);
   const int row_lo = a.g.row_base, row_hi = a.g.row_base + a.rows_stored - 1;
+  const bool tail_lane = lane < 2 * k;  // columns 64 .. 64+2k-1
+  const float h = 1.0f / 9.0f;  // :145
+  // (residue, column, chunk group) of lb_lo, then advanced incrementally (scalar adds, no divisions)
+  int r = static_cast<int>(lb_lo / per_res);
+  int bx, cg;
+  {
+    const uint32_t rem = lb_lo - static_cast<uint32_t>(r) * per_res;
+    bx = static_cast<int>(rem / static_cast<uint32_t>(a.tiles_y));
+    cg = static_cast<int>(rem - static_cast<uint32_t>(bx) * static_cast<uint32_t>(a.tiles_y));
+  }
+  r = __builtin_amdgcn_readfirstlane(r);
+  bx = __builtin_amdgcn_readfirstlane(bx);
+  cg = __builtin_amdgcn_readfirstlane(cg);
+
+#pragma unroll 1
+  for (uint32_t lb = lb_lo; lb < lb_hi; lb++) {
+  const int r_now = r, bx_now = bx, cg_now = cg;
+  if (++cg == a.tiles_y) {
+    cg = 0;
+    if (++bx == a.tiles_x) {
+      bx = 0;
+      ++r;
+    }
+  }
+  const int chunk = cg_now * kBlockY + wave;
+  const int yc = a.g.y0 + chunk * (kCombM * k) + r_now;  // first output row of the comb
+  if (yc >= a.g.y1) continue;
+  const int x0 = bx_now * kBlockX;
   int gx0 = x0 - k + lane, gx1 = x0 - k + 64 + lane;
   gx0 = gx0 < 0 ? 0 : (gx0 > W - 1 ? W - 1 : gx0);  // :136
   gx1 = gx1 < 0 ? 0 : (gx1 > W - 1 ? W - 1 : gx1);
-  const bool tail_lane = lane < CWp - 64;
+  const uint32_t o16a = static_cast<uint32_t>(gx0) * 16u, o4a = static_cast<uint32_t>(gx0) * 4u;
+  const uint32_t o16b = static_cast<uint32_t>(gx1) * 16u, o4b = static_cast<uint32_t>(gx1) * 4u;
+  // the previous comb's ds_reads have returned (their values were consumed); make that explicit
+  // before the DMA overwrites the cells
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int j = 0; j < rows; j++) {
     int gy = yc + (j - 1) * k;
     gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);              // :136
     gy = gy < row_lo ? row_lo : (gy > row_hi ? row_hi : gy);  // rows only masked outputs could reach
-    const size_t grow = static_cast<size_t>(gy - a.g.row_base) * W;
-    const uint32_t c0 = static_cast<uint32_t>(j * CWp);
-    dma_b128(a.in + grow + gx0, lds_col + c0 * 16u);
-    dma_b32(a.depth + grow + gx0, lds_dep + c0 * 4u);
-    dma_b32(a.vis + grow + gx0, lds_ids + c0 * 4u);
+    const size_t grow = static_cast<size_t>(gy - a.g.row_base) * W;  // wave-uniform
+    const float4* rin = a.in + grow;
+    const uint32_t* rvis = a.vis + grow;
+    const uint32_t cj = static_cast<uint32_t>(j * CWp);
+    dma_b128(rin, o16a, lds_col + cj * 16u);
+    dma_b32(rvis, o4a, lds_ids + cj * 4u);
     if (tail_lane) {
-      dma_b128(a.in + grow + gx1, lds_col + (c0 + 64u) * 16u);
-      dma_b32(a.depth + grow + gx1, lds_dep + (c0 + 64u) * 4u);
-      dma_b32(a.vis + grow + gx1, lds_ids + (c0 + 64u) * 4u);
+      dma_b128(rin, o16b, lds_col + (cj + 64u) * 16u);
+      dma_b32(rvis, o4b, lds_ids + (cj + 64u) * 4u);
     }
   }
   // only this wave reads these cells: its own vmcnt orders the DMA before the ds_reads below
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   const int x = x0 + lane;
-  const float h = 1.0f / 9.0f;  // :145
 #pragma unroll
   for (int m = 0; m < kCombM; m++) {
     const int y = yc + m * k;
     if (x >= W || y >= a.g.y1) continue;
     const int cc = (m + 1) * CWp + lane + k;
-    const f3 cp = xyz(col[cc]);
-    const float dp = dep[cc];
+    const float4 cp4 = col[cc];
+    const f3 cp = xyz(cp4);
+    const float dp = cp4.w;
     const uint32_t idp = ids[cc];
     const float* prow = pairw + idp * NP;
     const float wself = prow[idp];
@@ -266,8 +311,9 @@ __global__ __launch_bounds__(kThreads) void k_atrous_comb(AtrousArgs a) {
           w = wself;  // centre tap: q == p, both exponentials are exactly 1
         } else {
           const int qi = cc + jj * CWp + i * k;
-          cq = xyz(col[qi]);
-          const float dq = dep[qi];
+          const float4 cq4 = col[qi];
+          cq = xyz(cq4);
+          const float dq = cq4.w;
           const float wn = prow[ids[qi]];  // :62 via the id-pair table
           const f3 dc = cp - cq;
           if (EXACT) {
@@ -299,7 +345,7 @@ __global__ __launch_bounds__(kThreads) void k_atrous_comb(AtrousArgs a) {
     }
     const size_t ip = static_cast<size_t>(y - a.g.row_base) * W + x;
     if (!FINAL) {
-      a.out[ip] = make_float4(filtered.x, filtered.y, filtered.z, 0.0f);  // :152
+      a.out[ip] = make_float4(filtered.x, filtered.y, filtered.z, dp);  // :152 (+ depth in alpha)
       continue;
     }
     // :213-239 reprojection — exact arithmetic: the truncated pixel coordinate is an integer observable
@@ -327,9 +373,25 @@ __global__ __launch_bounds__(kThreads) void k_atrous_comb(AtrousArgs a) {
     }
     a.out[ip] = make_float4(blend.x, blend.y, blend.z, 0.0f);  // :263 (D1: distinct buffer)
   }
+  }  // work list
+}
+
+// copy the G-buffer depth into the alpha channel of a colour plane (used when a plane was injected
+// through rtpt_set_plane / rtpt_bind_plane and does not carry it yet)
+__global__ __launch_bounds__(kThreads) void k_stamp_depth(FrameGeom g, float4* color, const float* depth) {
+  const int x = blockIdx.x * kBlockX + threadIdx.x;
+  const int y = g.y0 + blockIdx.y * kBlockY + threadIdx.y;
+  if (x >= g.W || y >= g.y1) return;
+  const size_t i = static_cast<size_t>(y - g.row_base) * g.W + x;
+  reinterpret_cast<float*>(color + i)[3] = depth[i];
 }
 
 }  // namespace
+
+void launch_stamp_depth(const FrameGeom& g, float4* color, const float* depth, hipStream_t s) {
+  if (g.y1 <= g.y0) return;
+  hipLaunchKernelGGL(k_stamp_depth, grid_for(g), dim3(kBlockX, kBlockY), 0, s, g, color, depth);
+}
 
 void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
   if (a0.g.y1 <= a0.g.y0) return;
@@ -339,26 +401,45 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
   dim3 block(kBlockX, kBlockY);
   const int np = static_cast<int>(a.n_tris) + 1;
   if (!a.direct && a.pair_tab && np <= kPairMax && a.k >= 1 && a.k <= 16) {
-    a.cwp = (kBlockX + 2 * a.k + 7) & ~7;
     a.tiles_x = (a.g.W + kBlockX - 1) / kBlockX;
     const int nrows = a.g.y1 - a.g.y0;
     const int chunks = (nrows + kCombM * a.k - 1) / (kCombM * a.k);
-    const int combs = chunks * a.k;                       // one wave each
-    a.tiles_y = (combs + kBlockY - 1) / kBlockY;          // blocks along y
-    const size_t lds = static_cast<size_t>((np * np * 4 + 15) & ~15) +
-                       static_cast<size_t>(kBlockY) * (kCombM + 2) * a.cwp * 24;
-    dim3 grid(static_cast<uint32_t>(a.tiles_x) * static_cast<uint32_t>(a.tiles_y));
-    if (a.exact) {
-      if (final_pass)
-        hipLaunchKernelGGL((k_atrous_comb<true, true>), grid, block, lds, s, a);
-      else
-        hipLaunchKernelGGL((k_atrous_comb<false, true>), grid, block, lds, s, a);
-    } else {
-      if (final_pass)
-        hipLaunchKernelGGL((k_atrous_comb<true, false>), grid, block, lds, s, a);
-      else
-        hipLaunchKernelGGL((k_atrous_comb<false, false>), grid, block, lds, s, a);
+    a.tiles_y = (chunks + kBlockY - 1) / kBlockY;         // chunk groups (4 consecutive chunks per block)
+    static int n_cu = 0;
+    if (!n_cu) {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
+    const uint32_t nlb = static_cast<uint32_t>(a.tiles_x) * static_cast<uint32_t>(a.tiles_y) * static_cast<uint32_t>(a.k);
+    uint32_t per_xcd = static_cast<uint32_t>((n_cu + 7) / 8) * 5u;  // 5 resident blocks per CU (LDS-bound)
+    if (per_xcd > (nlb + 7) / 8) per_xcd = (nlb + 7) / 8;
+    dim3 grid(per_xcd * 8u);
+    // staged row stride: 72 cells for k <= 4, 80 for k <= 8, 96 for k <= 16
+#define RTPT_LAUNCH_COMB(CW)                                                                         \
+  do {                                                                                               \
+    const size_t lds = static_cast<size_t>((np * np * 4 + 15) & ~15) +                               \
+                       static_cast<size_t>(kBlockY) * (kCombM + 2) * (CW) * 20;                      \
+    if (a.exact) {                                                                                   \
+      if (final_pass)                                                                                \
+        hipLaunchKernelGGL((k_atrous_comb<CW, true, true>), grid, block, lds, s, a);                 \
+      else                                                                                           \
+        hipLaunchKernelGGL((k_atrous_comb<CW, false, true>), grid, block, lds, s, a);                \
+    } else {                                                                                         \
+      if (final_pass)                                                                                \
+        hipLaunchKernelGGL((k_atrous_comb<CW, true, false>), grid, block, lds, s, a);                \
+      else                                                                                           \
+        hipLaunchKernelGGL((k_atrous_comb<CW, false, false>), grid, block, lds, s, a);               \
+    }                                                                                                \
+  } while (0)
+    if (a.k <= 4)
+      RTPT_LAUNCH_COMB(72);
+    else if (a.k <= 8)
+      RTPT_LAUNCH_COMB(80);
+    else
+      RTPT_LAUNCH_COMB(96);
+#undef RTPT_LAUNCH_COMB
     return;
   }
   const dim3 g2 = grid_for(a.g);

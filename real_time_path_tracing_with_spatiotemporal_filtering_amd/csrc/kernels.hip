@@ -369,7 +369,8 @@ __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
     }
     const float ns = static_cast<float>(a.spp);
     const size_t i = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
-    a.image[i] = make_float4(sum.x / ns, sum.y / ns, sum.z / ns, 0.0f);  // :328,:343
+    // :328,:343 — the reference's alpha is 0; here it carries the G-buffer depth for the filter (rgbd)
+    a.image[i] = make_float4(sum.x / ns, sum.y / ns, sum.z / ns, a.depth[i]);
     if (a.hit_id) a.hit_id[i] = first_id;
   }
   // "ray" = one closest-hit query; one 64-bit atomic per block

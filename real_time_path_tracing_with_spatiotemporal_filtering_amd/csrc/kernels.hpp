@@ -71,7 +71,8 @@ struct PathtraceArgs {
   float light_col_first[3];  // light_col / first_hit_light_divisor
   float light_r2;            // radius * radius
   float slope, jitter, ray_offset, tmax;
-  float4* image;
+  float4* image;        // written as (rgb, depth): see atrous.hip "rgbd"
+  const float* depth;   // G-buffer depth of the same pixels
   uint32_t* hit_id;  // nullable
   unsigned long long* raycount;
   int32_t count_y0, count_y1;  // rows whose queries are counted
@@ -92,7 +93,6 @@ struct AtrousArgs {
   float sigma_z, sigma_l;
   const float4* in;
   float4* out;
-  const float* depth;
   const uint32_t* vis;
   const float4* normal_tab;
   // final pass only
@@ -122,6 +122,7 @@ void launch_gbuffer(const GbufferArgs& a, hipStream_t s);
 void launch_gradient(const GradientArgs& a, hipStream_t s);
 void launch_pathtrace(const PathtraceArgs& a, hipStream_t s);
 void launch_atrous(const AtrousArgs& a, bool final_pass, hipStream_t s);
+void launch_stamp_depth(const FrameGeom& g, float4* color, const float* depth, hipStream_t s);
 void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s);
 void launch_selftest_trace(const SceneView& scene, const float* rays, size_t n, float tmax, uint32_t* out_id,
                            float* out_t, hipStream_t s);
