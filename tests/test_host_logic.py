@@ -1,0 +1,115 @@
+"""The headless host mirror (app.PathTracingApplication) against the reference's per-frame rules
+(main.cpp:1090-1185, :1255-1306, :1463-1475), with a recording backend — no GPU involved."""
+import ctypes as C
+
+import numpy as np
+
+from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
+from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import PathTracingApplication
+from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripPlan
+
+
+class Recorder:
+    def __init__(self):
+        self.calls = []
+
+    def scene_upload(self, *a):
+        self.calls.append(("scene_upload",))
+
+    def gbuffer(self, ubo, y0, y1):
+        self.calls.append(("gbuffer", bytes(ubo), y0, y1))
+
+    def temporal_gradient(self, pc, y0, y1):
+        self.calls.append(("gradient", bytes(pc), y0, y1))
+
+    def raytrace(self, pc, y0, y1):
+        self.calls.append(("raytrace", bytes(pc), y0, y1))
+
+    def temporal_filter(self, pc, ubo, y0, y1):
+        self.calls.append(("filter", pc.waveletIteration, pc.maxWaveletIteration, y0, y1))
+
+    def end_frame(self):
+        self.calls.append(("end_frame",))
+
+
+def pc_of(raw):
+    return abi.PushConstants.from_buffer_copy(raw)
+
+
+def test_draw_scene_call_order_and_filter_loop():
+    be = Recorder()
+    app = PathTracingApplication(be, 100, 80, maxWaveletIteration=9)
+    app.drawScene()
+    names = [c[0] for c in be.calls]
+    assert names == ["gbuffer", "gradient", "raytrace"] + ["filter"] * 9 + ["end_frame"]  # main.cpp:1105-1110
+    assert [(c[1], c[2]) for c in be.calls if c[0] == "filter"] == [(k, 9) for k in range(1, 10)]  # :1258-1260
+    assert all(c[-2:] == (0, 80) for c in be.calls if c[0] in ("gbuffer", "gradient", "raytrace", "filter"))
+    assert app.frameCount == 1
+
+
+def test_push_constant_update_rules():
+    be = Recorder()
+    app = PathTracingApplication(be, 64, 48, maxWaveletIteration=1)
+    app.drawScene()                 # frame 0
+    app.drawScene(("L",))           # light.x += 0.1
+    app.drawScene(("W", "O"))       # camera.z -= 0.1, light.y += 0.1
+    app.drawScene()
+    pcs = [pc_of(c[1]) for c in be.calls if c[0] == "raytrace"]
+    assert [p.frameNumber for p in pcs] == [0, 1, 2, 3]                      # :1171
+    assert [p.sample_batch for p in pcs] == [0, 0, 0, 0]                     # :1237
+    # frame 0: lightPosPrev is what initializeSceneConstants left in lightPos (main.cpp:661-666, :1177)
+    assert list(pcs[0].lightPosPrev) == [1.0, 1.0, np.float32(-0.4)]
+    assert list(pcs[0].lightPos) == [1.0, 1.0, np.float32(-0.4)]
+    assert list(pcs[1].lightPos)[0] == np.float32(np.float32(1.0) + np.float32(0.1))
+    assert list(pcs[1].lightPosPrev) == list(pcs[0].lightPos)               # :1177
+    assert list(pcs[2].lightPosPrev) == list(pcs[1].lightPos)
+    assert list(pcs[3].lightPosPrev) == list(pcs[3].lightPos)                # static again
+    assert list(pcs[0].previousCameraColor) == [0.5, 0.5, 0.5]               # :1173 after :662
+    # cameraPos is pushed on frame 0 and when the camera moved (:1181-1184)
+    assert list(pcs[0].cameraPos) == [np.float32(-0.001), 1.0, 6.0]
+    assert list(pcs[1].cameraPos) == list(pcs[0].cameraPos)
+    assert list(pcs[2].cameraPos)[2] == np.float32(np.float32(6.0) - np.float32(0.1))
+
+
+def test_light_wraparound_keys():
+    be = Recorder()
+    app = PathTracingApplication(be, 32, 32, maxWaveletIteration=1, lightPos=(1.95, 1.0, 0.0))
+    app.updateScene(("L",))   # 2.05 > 2 -> -20 (main.cpp:1151-1153)
+    assert app.lightPos[0] == -20
+    app.updateScene(("J",))   # -20.1 < -20 -> 2 (main.cpp:1157-1160)
+    assert app.lightPos[0] == 2
+
+
+def test_ubo_prev_matrices_and_initial_view():
+    be = Recorder()
+    app = PathTracingApplication(be, 100, 80, maxWaveletIteration=1)
+    first = bytes(app.ubo)
+    u0 = abi.Ubo.from_buffer_copy(first)
+    # uploadBuffers (main.cpp:481-489): the initial view looks at (0,1,0), prev = current
+    assert list(u0.view) == list(abi.look_at((-0.001, 1.0, 6.0), (0, 1, 0), (0, 1, 0)))
+    assert list(u0.viewPrev) == list(u0.view) and list(u0.projPrev) == list(u0.proj)
+    assert u0.proj[5] < 0                                           # proj[1][1] *= -1 (main.cpp:484)
+    app.drawScene()
+    u1 = abi.Ubo.from_buffer_copy(be.calls[0][1])
+    assert list(u1.viewPrev) == list(u0.view)                       # main.cpp:1465-1467
+    assert list(u1.view) == list(abi.look_at((-0.001, 1.0, 6.0), (-0.001, 1.0, 0.0), (0, 1, 0)))  # :1470
+    app.drawScene(("D",))
+    u2 = abi.Ubo.from_buffer_copy([c for c in be.calls if c[0] == "gbuffer"][1][1])
+    assert list(u2.viewPrev) == list(u1.view)
+    assert u2.view[12] != u1.view[12]                               # camera x moved
+    assert list(u2.model) == list(np.eye(4, dtype=np.float32).ravel())
+
+
+def test_strip_rank_row_ranges_reach_the_backend():
+    be = Recorder()
+    plan = StripPlan(2160, 8, 3, 5, "redundant")
+    app = PathTracingApplication(be, 3840, 2160, maxWaveletIteration=5, plan=plan)
+    app.drawScene()
+    o0, o1 = plan.own
+    assert (o0, o1) == (810, 1080)
+    calls = {c[0]: c for c in be.calls if c[0] != "filter"}
+    assert calls["gbuffer"][-2:] == (o0 - 15, o1 + 15)
+    assert calls["gradient"][-2:] == (o0, o1)
+    assert calls["raytrace"][-2:] == (o0 - 15, o1 + 15)
+    filt = [c for c in be.calls if c[0] == "filter"]
+    assert [c[-2:] for c in filt] == [(o0 - 14, o1 + 14), (o0 - 12, o1 + 12), (o0 - 9, o1 + 9), (o0 - 5, o1 + 5), (o0, o1)]

@@ -101,10 +101,11 @@ def test_closest_hit_ids_bit_exact(hip_lib, oracle, cornell, flags):
 # ------------------------------------------------------------------------------ per pass, frames 0..2
 @pytest.mark.parametrize("flags", [0, 2])
 def test_frame_sequence_parity(hip_lib, oracle, cornell, flags):
-    """frames 0-1 static, light.x -0.1 on frame 2 (SURVEY 8d config 1 script), camera z +0.1 on 3"""
+    """frames 0-1 static, light.x -0.1 on frame 2 (SURVEY 8d config 1 script), camera x +0.1 on 3, z +0.1 on 4"""
     app, ref = make_pair(hip_lib, oracle, cornell, flags=flags)
     ctx = app.backend.ctx
-    script = [((), None, None), ((), None, None), (("J",), None, (-0.1, 0, 0)), (("S",), (0, 0, 0.1), None)]
+    script = [((), None, None), ((), None, None), (("J",), None, (-0.1, 0, 0)), (("D",), (0.1, 0, 0), None),
+              (("S",), (0, 0, 0.1), None)]
     worst = 0.0
     for keys, cam_move, light_move in script:
         app.updateScene(keys)

@@ -1,0 +1,174 @@
+"""Row-strip sharding (strips.py) on CPU: plan invariants, and the N>1 path end to end with two
+(and three) gloo ranks — each rank runs the SAME PathTracingApplication / exchange_halo code the GPU
+path runs, on a backend made of the oracle passes, and the assembled frame must equal the
+single-rank frame bit for bit (the RNG seed depends only on absolute pixel + frame,
+raytrace.comp.glsl:297)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENE
+from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
+from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import PathTracingApplication
+from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripPlan
+
+
+# ------------------------------------------------------------------------------ plan invariants
+@pytest.mark.parametrize("H,R,N", [(2160, 8, 5), (1080, 4, 5), (2160, 2, 9), (97, 3, 5), (48, 2, 5), (800, 8, 9)])
+@pytest.mark.parametrize("mode", ["exchange", "redundant"])
+def test_plan_covers_frame_and_halos(H, R, N, mode):
+    plans = [StripPlan(H, R, r, N, mode) for r in range(R)]
+    rows = []
+    for p in plans:
+        o0, o1 = p.own
+        s0, s1 = p.stored
+        assert 0 <= s0 <= o0 < o1 <= s1 <= H
+        rows += list(range(o0, o1))
+        assert p.gradient_rows() == (o0, o1) and p.filter_rows(N) == (o0, o1)
+        for k in range(1, N + 1):
+            f0, f1 = p.filter_rows(k)
+            assert s0 <= max(0, f0 - k) and min(H, f1 + k) <= s1, "taps of computed rows must be stored"
+        if mode == "redundant":
+            # what iteration k+1 reads must have been produced by iteration k on this rank
+            prev = p.raytrace_rows()
+            for k in range(1, N + 1):
+                f0, f1 = p.filter_rows(k)
+                assert prev[0] <= max(0, f0 - k) and min(H, f1 + k) <= prev[1]
+                prev = (f0, f1)
+    assert rows == list(range(H))
+
+
+def test_exchange_lists_are_symmetric():
+    H, R, N = 240, 4, 5
+    plans = [StripPlan(H, R, r, N, "exchange") for r in range(R)]
+    for k in range(1, N + 1):
+        sends = {(p.rank, peer): s for p in plans for peer, s, _ in p.exchange_rows(k)}
+        recvs = {(peer, p.rank): r for p in plans for peer, _, r in p.exchange_rows(k)}
+        assert sends.keys() == recvs.keys() and len(sends) == 2 * (R - 1)
+        for key in sends:
+            assert sends[key] == recvs[key], "what A sends to B is exactly the rows B expects from A"
+            assert sends[key][1] - sends[key][0] == k
+    assert StripPlan(H, 1, 0, N).exchange_rows(3) == []
+    with pytest.raises(ValueError):
+        StripPlan(12, 4, 1, 5, "exchange").exchange_rows(5)   # 3-row strips cannot feed a 5-row halo
+    with pytest.raises(ValueError):
+        StripPlan(10, 2, 0, 5, "diagonal")
+
+
+# ------------------------------------------------------------------------------ oracle-backed backend
+class OracleBackend:
+    """the backend protocol of app.py on top of the oracle passes (CPU, numpy/torch shared memory)"""
+
+    def __init__(self, O, width, height, max_segments, plan):
+        import torch
+        self.O, self.plan = O, plan
+        self.cfg = O.config_default(width, height)
+        self.cfg.max_segments = max_segments
+        W, H = width, height
+        self.color = [np.zeros((H, W, 4), np.float32) for _ in range(3)]
+        self.torch_color = [torch.from_numpy(c) for c in self.color]
+        self.role = {abi.PLANE_IMAGE: 0, abi.PLANE_FILTERED: 1, abi.PLANE_PREVIOUS: 2}
+        self.vis = np.zeros((H, W), np.uint32)
+        self.wp = np.zeros((H, W, 4), np.float32)
+        self.depth = np.zeros((H, W), np.float32)
+        self.grad = np.zeros((H, W, 4), np.float32)
+        self.lut = self.lut_prev = None
+        self.rays = 0
+
+    def scene_upload(self, xyz, idx, xforms=None):
+        self.tris = self.O.flatten(xyz, idx, xforms)
+
+    def _opc(self, pc):
+        return self.O.PushConstants.from_buffer_copy(bytes(pc))
+
+    def _oubo(self, ubo):
+        return self.O.Ubo.from_buffer_copy(bytes(ubo))
+
+    def gbuffer(self, ubo, y0, y1):
+        self.lut = self.O.lut(self.tris, np.array(ubo.model[:], np.float32))
+        if self.lut_prev is None:
+            self.lut_prev = self.lut.copy()
+        v, w, d = self.O.gbuffer(self.cfg, self.tris, self._oubo(ubo), y0, y1)
+        self.vis[y0:y1], self.wp[y0:y1], self.depth[y0:y1] = v[y0:y1], w[y0:y1], d[y0:y1]
+
+    def temporal_gradient(self, pc, y0, y1):
+        g = self.O.temporal_gradient(self.cfg, self._opc(pc), self.vis, self.wp, self.lut, self.lut_prev, y0, y1)
+        self.grad[y0:y1] = g[y0:y1]
+
+    def raytrace(self, pc, y0, y1):
+        img, rays, _ = self.O.raytrace(self.cfg, self._opc(pc), self.tris, y0, y1, want_hit_id=False)
+        self.color[self.role[abi.PLANE_IMAGE]][y0:y1] = img[y0:y1]
+        o0, o1 = self.plan.own
+        _, own_rays, _ = self.O.raytrace(self.cfg, self._opc(pc), self.tris, max(y0, o0), min(y1, o1), want_hit_id=False)
+        self.rays += own_rays
+
+    def temporal_filter(self, pc, ubo, y0, y1):
+        k, n = pc.waveletIteration, pc.maxWaveletIteration
+        src, dst = (abi.PLANE_IMAGE, abi.PLANE_FILTERED) if k & 1 else (abi.PLANE_FILTERED, abi.PLANE_IMAGE)
+        out = self.O.atrous(self.cfg, self._opc(pc), self._oubo(ubo), self.color[self.role[src]], self.depth, self.vis,
+                            self.lut, self.lut_prev, self.wp, self.color[self.role[abi.PLANE_PREVIOUS]], y0, y1)
+        self.color[self.role[dst]][y0:y1] = out[y0:y1]
+        if k == n and k & 1:   # D1: the blend becomes `image`
+            self.role[abi.PLANE_IMAGE], self.role[abi.PLANE_FILTERED] = self.role[abi.PLANE_FILTERED], self.role[abi.PLANE_IMAGE]
+
+    def end_frame(self):
+        self.role[abi.PLANE_IMAGE], self.role[abi.PLANE_PREVIOUS] = self.role[abi.PLANE_PREVIOUS], self.role[abi.PLANE_IMAGE]
+        self.lut_prev = self.lut
+
+    def color_rows(self, plane, y0, y1):
+        return self.torch_color[self.role[plane]][y0:y1]
+
+    def final_image(self):
+        return self.color[self.role[abi.PLANE_PREVIOUS]]
+
+
+W, H, SEG, N, FRAMES = 48, 40, 2, 5, 3
+KEYS = [(), ("J",), ("D",)]
+
+
+def _run_rank(rank, world, mode, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import oracle as O
+    O.set_threads(2)
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    plan = StripPlan(H, world, rank, N, mode)
+    be = OracleBackend(O, W, H, SEG, plan)
+    app = PathTracingApplication(be, W, H, N, plan)
+    app.loadMesh(SCENE)
+    app.buildAccelerationStructure()
+    frames = []
+    for f in range(FRAMES):
+        app.drawScene(KEYS[f])
+        o0, o1 = plan.own
+        frames.append(be.final_image()[o0:o1].copy())
+    np.savez(os.path.join(out_dir, f"{mode}_{world}_{rank}.npz"), *frames, rays=np.array([be.rays]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,mode", [(2, "exchange"), (2, "redundant"), (3, "exchange")])
+def test_gloo_ranks_reproduce_the_single_rank_frame(tmp_path, oracle, world, mode):
+    import torch.multiprocessing as mp
+    single = tmp_path / f"{mode}_1_0.npz"
+    _run_rank(0, 1, mode, 0, str(tmp_path))
+    mp.spawn(_run_rank, args=(world, mode, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(single)
+    parts = [np.load(tmp_path / f"{mode}_{world}_{r}.npz") for r in range(world)]
+    for f in range(FRAMES):
+        want = ref[f"arr_{f}"]
+        got = np.concatenate([p[f"arr_{f}"] for p in parts], axis=0)
+        assert got.shape == want.shape == (H, W, 4)
+        assert got.tobytes() == want.tobytes(), f"frame {f}: strips differ from the single-rank frame"
+    assert sum(int(p["rays"][0]) for p in parts) == int(ref["rays"][0])
