@@ -1,0 +1,71 @@
+// app.hpp — headless C++ host: the reference's PathTracingApplication (main.cpp:179-1529) with the
+// same method names and per-frame order, driving the HIP hot path through the C ABI of rtpt.h.
+// What the reference did with Vulkan objects (images, descriptor sets, pipelines, command buffers)
+// is one rtpt_* call per dispatch here; window, swapchain and keyboard are replaced by a scripted
+// key list and an optional PFM dump (out of scope as code, in scope as a scripted path).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rtpt.h"
+
+namespace rtpt_host {
+
+struct Options {
+  uint32_t width = 1000, height = 800;  // main.cpp:52-53
+  int maxWaveletIteration = 9;          // main.cpp:55
+  uint32_t max_segments = 32;           // raytrace.comp.glsl:204
+  uint32_t flags = 0;
+  std::string scene;                    // scenes/CornellBox-Original-Merged.obj (main.cpp:417)
+};
+
+class PathTracingApplication {
+ public:
+  explicit PathTracingApplication(const Options& opt);
+  ~PathTracingApplication();
+  PathTracingApplication(const PathTracingApplication&) = delete;
+  PathTracingApplication& operator=(const PathTracingApplication&) = delete;
+
+  // run(): initWindow (nothing to do headless), initVulkan, mainLoop — main.cpp:185-189
+  void run(int frames, const std::vector<std::string>& script);
+
+  void initVulkan();                           // main.cpp:280-300 (device + resources + scene)
+  void loadMesh();                             // main.cpp:409-462
+  void createBuffers();                        // main.cpp:357-407  -> rtpt_create
+  void buildAccelerationStructure();           // main.cpp:687-742  -> rtpt_scene_upload
+  void initializeSceneConstants();             // main.cpp:661-666
+  void updateScene(const std::string& keys);   // main.cpp:1115-1185, keys = GLFW keys held this frame
+  void updateUBO();                            // main.cpp:1463-1475
+  void drawVisbilityBuffer();                  // main.cpp:1187-1199 -> rtpt_gbuffer
+  void computeTemporalGradient();              // main.cpp:1201-1220 -> rtpt_temporal_gradient
+  void drawSceneToImage();                     // main.cpp:1222-1253 -> rtpt_raytrace
+  void applyTemporalFiltering();               // main.cpp:1255-1306 -> rtpt_temporal_filter x N
+  void copyImageToSwapChainsCurrentImage();    // main.cpp:1308-1406 -> rtpt_end_frame (+ optional dump)
+  void drawScene(const std::string& keys);     // main.cpp:1090-1113
+  void freeRessources();                       // main.cpp:1477-1528
+
+  // read-back helpers (the reference's only output is the swapchain image)
+  std::vector<float> readImage();              // RGBA32F, width*height*4
+  uint64_t rayCount();
+  void writePFM(const std::string& path);      // linear RGB, bottom-up rows as PFM prescribes
+  void sync();
+
+  uint32_t frameCount = 0;                     // main.cpp:259
+  rtpt_push_constants pushConstants{};         // main.cpp:51
+  rtpt_ubo ubo{};                              // main.cpp:248
+
+ private:
+  void check(int rc, const char* what);
+  Options opt_;
+  rtpt_ctx* ctx_ = nullptr;
+  std::vector<float> objVertices;              // main.cpp:255
+  std::vector<uint32_t> objIndices;            // main.cpp:256
+  float cameraOrigin[3] = {-0.001f, 1.0f, 6.0f};  // main.cpp:65
+  float lightPos[3] = {1.0f, 1.0f, -0.4f};        // main.cpp:70
+  float lightColor[3] = {0.5f, 0.5f, 0.5f};       // main.cpp:72
+  bool cameraMoved = false;
+};
+
+}  // namespace rtpt_host

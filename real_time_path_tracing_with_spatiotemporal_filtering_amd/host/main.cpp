@@ -1,0 +1,74 @@
+// main.cpp — CLI of the headless host (the reference's main(), main.cpp:1532-1537, plus the knobs the
+// reference keeps as compile-time constants).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "app.hpp"
+
+static void usage(const char* argv0) {
+  std::printf(
+      "usage: %s [--width W] [--height H] [--frames N] [--segments S] [--iterations K]\n"
+      "          [--scene file.obj] [--script \"keys0,keys1,...\"] [--dump out.pfm] [--exact-filter]\n"
+      "  keys per frame are the reference's GLFW keys: WASDQE move the camera, IJKLUO the light\n"
+      "  defaults are the reference's constants: 1000x800, 32 segments, 9 iterations (main.cpp:52-55)\n",
+      argv0);
+}
+
+int main(int argc, char** argv) {
+  rtpt_host::Options opt;
+  int frames = 3;
+  std::string dump, script_arg;
+  // scene path relative to this binary: <pkg>/scenes/...
+  std::string self(argv[0]);
+  size_t slash = self.find_last_of('/');
+  opt.scene = (slash == std::string::npos ? std::string(".") : self.substr(0, slash)) + "/scenes/CornellBox-Original-Merged.obj";
+  for (int i = 1; i < argc; i++) {
+    auto need = [&](const char* name) -> const char* {
+      if (i + 1 >= argc) {
+        std::fprintf(stderr, "%s needs a value\n", name);
+        std::exit(2);
+      }
+      return argv[++i];
+    };
+    if (!std::strcmp(argv[i], "--width")) opt.width = static_cast<uint32_t>(std::atoi(need("--width")));
+    else if (!std::strcmp(argv[i], "--height")) opt.height = static_cast<uint32_t>(std::atoi(need("--height")));
+    else if (!std::strcmp(argv[i], "--frames")) frames = std::atoi(need("--frames"));
+    else if (!std::strcmp(argv[i], "--segments")) opt.max_segments = static_cast<uint32_t>(std::atoi(need("--segments")));
+    else if (!std::strcmp(argv[i], "--iterations")) opt.maxWaveletIteration = std::atoi(need("--iterations"));
+    else if (!std::strcmp(argv[i], "--scene")) opt.scene = need("--scene");
+    else if (!std::strcmp(argv[i], "--script")) script_arg = need("--script");
+    else if (!std::strcmp(argv[i], "--dump")) dump = need("--dump");
+    else if (!std::strcmp(argv[i], "--exact-filter")) opt.flags |= RTPT_FLAG_EXACT_FILTER;
+    else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) { usage(argv[0]); return 0; }
+    else { std::fprintf(stderr, "unknown option %s\n", argv[i]); usage(argv[0]); return 2; }
+  }
+  std::vector<std::string> script;
+  {
+    std::stringstream ss(script_arg);
+    std::string item;
+    while (std::getline(ss, item, ',')) script.push_back(item);
+  }
+  try {
+    rtpt_host::PathTracingApplication app(opt);
+    app.initVulkan();
+    app.sync();
+    auto t0 = std::chrono::steady_clock::now();
+    for (int f = 0; f < frames; f++) app.drawScene(static_cast<size_t>(f) < script.size() ? script[static_cast<size_t>(f)] : "");
+    app.sync();
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    uint64_t rays = app.rayCount();
+    std::printf("{\"frames\": %d, \"width\": %u, \"height\": %u, \"ms_per_frame\": %.4f, \"rays\": %llu, \"mray_per_s\": %.1f}\n", frames,
+                opt.width, opt.height, ms / frames, static_cast<unsigned long long>(rays), rays / (ms * 1e-3) / 1e6);
+    if (!dump.empty()) app.writePFM(dump);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "rtpt_app: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,62 @@
+"""The headless C++ host (host/app.cpp: the reference's PathTracingApplication over the C ABI)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bits
+
+PKG = os.path.join(ROOT, "real_time_path_tracing_with_spatiotemporal_filtering_amd")
+APP = os.path.join(PKG, "rtpt_app")
+
+
+@pytest.fixture(scope="module")
+def app_binary():
+    subprocess.check_call(["make", "-C", os.path.join(PKG, "csrc"), "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(PKG, "host"), "-s"])
+    return APP
+
+
+def test_cli_help_and_bad_option(app_binary):
+    out = subprocess.run([app_binary, "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "--iterations" in out.stdout
+    assert subprocess.run([app_binary, "--bogus"], capture_output=True).returncode == 2
+
+
+def test_no_gpu_is_an_error(app_binary):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    out = subprocess.run([app_binary, "--frames", "1", "--width", "32", "--height", "32"], capture_output=True, text=True)
+    assert out.returncode == 1 and "no CPU fallback" in out.stderr
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = map(int, f.readline().split())
+        assert float(f.readline()) < 0  # little endian
+        data = np.frombuffer(f.read(), np.float32).reshape(h, w, 3)
+    return data[::-1]
+
+
+@pytest.mark.gpu
+def test_cpp_host_equals_python_host(app_binary, hip_lib, tmp_path):
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    W, H, SEG, N = 96, 64, 3, 5
+    keys = ["", "", "J", "D", "SI"]
+    pfm = tmp_path / "out.pfm"
+    out = subprocess.run([app_binary, "--width", str(W), "--height", str(H), "--segments", str(SEG), "--iterations", str(N),
+                          "--frames", str(len(keys)), "--script", ",".join(keys), "--dump", str(pfm)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    stats = json.loads(out.stdout.strip().splitlines()[-1])
+    app = make_app(W, H, max_segments=SEG, iterations=N)
+    for k in keys:
+        app.drawScene(tuple(k))
+    want = app.backend.ctx.readback(hip_lib.PLANE_IMAGE)
+    got = read_pfm(pfm)
+    assert np.array_equal(bits(got), bits(np.ascontiguousarray(want[..., :3])))
+    assert stats["rays"] == app.backend.ctx.raycount() and stats["frames"] == len(keys)
