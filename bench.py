@@ -152,11 +152,16 @@ def cpu_baseline(wl, budget_s=12.0):
     while dt < budget_s / 2 and rows < H:
         rows = min(H, int(rows * min(8.0, max(2.0, budget_s / max(dt, 1e-3) * 0.8))))
         dt, rays = band_frame(rows)
+    reps = 1
+    while dt < budget_s * 0.8:  # the whole frame is cheaper than the budget: repeat it (successive frame numbers)
+        app.pc.frameNumber += 1
+        d2, r2 = band_frame(rows)
+        dt, rays, reps = dt + d2, rays + r2, reps + 1
     return {
         "value": round(rays / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
-        "sample": f"{rows} centre rows of the {W}x{H} frame (+{N * (N + 1) // 2} halo rows per side), all passes, "
-                  f"{dt:.1f} s of oracle/rtpt_oracle.c with {cores} OpenMP threads",
-        "ms_per_frame_extrapolated": round(dt / rows * H * 1e3, 1),
+        "sample": f"{reps} x {rows} centre rows of the {W}x{H} frame (+{N * (N + 1) // 2} halo rows per side when banded), "
+                  f"all passes, {dt:.1f} s of oracle/rtpt_oracle.c with {cores} OpenMP threads",
+        "ms_per_frame_extrapolated": round(dt / reps / rows * H * 1e3, 1),
     }
 
 
