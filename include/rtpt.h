@@ -93,6 +93,10 @@ typedef struct rtpt_visibility_data {
 #define RTPT_FLAG_DIRECT_FILTER 0x4u /* a-trous taps by direct global loads instead of the LDS-staged
                                        tile kernel (the fallback for strides whose halo exceeds LDS) */
 
+#define RTPT_FLAG_REGEN_PATHS 0x8u   /* path tracer: per-wave path regeneration (lanes whose path ended
+                                       take the next pixel) instead of one pixel per lane;
+                                       chosen automatically when max_segments >= 16 */
+
 typedef struct rtpt_config {
   uint32_t struct_size;          /* = sizeof(rtpt_config), ABI guard */
   uint32_t width, height;        /* full frame; main.cpp:52-53 (1000x800) */

@@ -568,6 +568,9 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   a.raycount = static_cast<unsigned long long*>(c->raycount.ptr);
   a.count_y0 = c->count_y0;
   a.count_y1 = c->count_y1;
+  // measured at 4K on the Cornell box: tile kernel 0.77 / 1.32 / 4.14 ms vs regeneration 1.10 / 1.60 / 2.54 ms
+  // at 4 / 8 / 32 segments
+  a.regen = ((c->cfg.flags & RTPT_FLAG_REGEN_PATHS) || c->cfg.max_segments >= 16) ? 1 : 0;
   c->final_swapped = false;
   c->image_alias = false;
   {

@@ -59,12 +59,19 @@ __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float
 // triangle at the same time, so the record address is wave-uniform and the loads are scalar
 // (s_load_dwordx4 -> SGPR operands of the VALU ops).  No stack, no divergence, no memory latency.
 __device__ __forceinline__ void closest_hit_brute(const SceneView& sc, f3 o, f3 d, HitRec& h) {
-  const float4* rec = sc.isect_id;
+  // The records are read through the CONSTANT address space: they are never written while a kernel
+  // that traces runs, and saying so keeps the loads scalar (s_load_dwordx4) even when the surrounding
+  // loop also stores pixels — otherwise hipcc must assume the stores may clobber them and falls back
+  // to one vector load + vmcnt(0) per triangle (measured: 2x slower).
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  using cv4f = const __attribute__((address_space(4))) v4f;
+  cv4f* rec = (cv4f*)sc.isect_id;
   const uint32_t n = sc.n_tris;
 #pragma unroll 4
   for (uint32_t i = 0; i < n; i++) {
-    float4 r0 = rec[3 * i], r1 = rec[3 * i + 1], r2 = rec[3 * i + 2];
-    tri_test<false>(o, d, r0, r1, r2, i + 1, h);
+    const v4f a0 = rec[3 * i], a1 = rec[3 * i + 1], a2 = rec[3 * i + 2];
+    tri_test<false>(o, d, make_float4(a0.x, a0.y, a0.z, a0.w), make_float4(a1.x, a1.y, a1.z, a1.w),
+                    make_float4(a2.x, a2.y, a2.z, a2.w), i + 1, h);
   }
 }
 
@@ -305,6 +312,9 @@ __device__ __forceinline__ f3 sky_color(f3 d) {  // raytrace.comp.glsl:95-107
   return f3{0.03f, 0.03f, 0.03f};
 }
 
+// One pixel per lane, 64x4 tiles (the shipping kernel for short paths: at 4 segments the Cornell box
+// averages 2.25 queries per pixel and most waves retire early — light hit and sky end whole waves —
+// so regeneration does not pay, see below).
 template <bool BVH>
 __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
   __shared__ uint32_t stack[BVH ? kBvhMaxDepth * kThreads : 1];
@@ -381,6 +391,136 @@ __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
   if (tid == 0 && block_rays) atomicAdd(a.raycount, static_cast<unsigned long long>(block_rays));
 }
 
+// Path regeneration.  Paths end after 1..max_segments closest-hit queries (light, sky, budget), and with
+// one pixel per lane a wave runs until its longest path ends: at 4 segments and ~2.25 queries per pixel
+// 44 % of the lane slots idle.  Here a wave owns kRegenPixels consecutive pixels and keeps its 64 lanes
+// full: every iteration of the wave loop is ONE segment for every live lane, and lanes whose path just
+// ended pick up the next pixel of the wave's range (ballot + prefix count, no atomics, no LDS).  The
+// result is schedule-independent: a path's RNG stream depends only on (x, y, frame, batch)
+// (raytrace.comp.glsl:297) and each lane runs the reference's loop body unchanged.
+// Measured (profiles/): at max_segments = 4 it executes MORE instructions than the tile kernel (527M vs
+// 476M VALU at 4K: every iteration mixes primary and secondary rays, so all 32 triangles take the
+// slow accept path, while the tile kernel's primary segment is coherent) and is 1.5x slower; it is
+// selected only for long paths (PathtraceArgs::regen).
+constexpr uint32_t kRegenPixels = 1024;
+
+template <bool BVH>
+__global__ __launch_bounds__(kThreads) void k_pathtrace_regen(PathtraceArgs a) {
+  __shared__ uint32_t stack[BVH ? kBvhMaxDepth * kThreads : 1];
+  __shared__ unsigned int block_rays;
+  const int tid = threadIdx.y * kBlockX + threadIdx.x;
+  if (tid == 0) block_rays = 0;
+  __syncthreads();
+  const uint32_t W = static_cast<uint32_t>(a.g.W);
+  const uint32_t P = W * static_cast<uint32_t>(a.g.y1 - a.g.y0);
+  const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * kBlockY + threadIdx.y);
+  uint32_t cursor = gw * kRegenPixels;  // wave-uniform
+  const uint32_t end = (cursor + kRegenPixels < P) ? cursor + kRegenPixels : P;
+  const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
+  const f3 light_c = ld3(a.light_c);
+
+  bool alive = false;
+  int x = 0, y = 0;
+  uint32_t rng = 0, seg = 0, smp = 0, first_id = 0;
+  f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, -1.f}, acc{1.f, 1.f, 1.f}, sum{0.f, 0.f, 0.f};
+  unsigned int rays = 0;
+
+  // raytrace.comp.glsl:309-320: jittered primary ray of the next sample
+  auto start_sample = [&]() {
+    float u1 = glsl_max(1e-38f, exact::rng_next(rng));  // :87 Box-Muller
+    float u2 = exact::rng_next(rng);
+    float rad = exact::sqrt_(-2.0f * exact::log_(u1));
+    float sn, cs;
+    exact::sincos2pi(u2, sn, cs);
+    float cx = fmaf_(a.jitter, rad * cs, static_cast<float>(x) + 0.5f);  // :314
+    float cy = fmaf_(a.jitter, rad * sn, static_cast<float>(y) + 0.5f);
+    float ux = fmaf_(2.0f, cx, -fw) / fh;     // :315
+    float uy = -(fmaf_(2.0f, cy, -fh) / fh);  // :316
+    d = exact::normalize(f3{a.slope * ux, a.slope * uy, -1.0f});  // :319-320
+    o = ld3(a.cam);
+    acc = f3{1.f, 1.f, 1.f};  // :201
+    seg = 0;
+  };
+
+  while (true) {
+    // ---- regenerate: dead lanes take the next pixels of this wave's range
+    const unsigned long long dead = __ballot(!alive);
+    if (dead != 0ull && cursor < end) {
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dead >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dead), 0u));
+      if (!alive) {
+        const uint32_t p = cursor + rank;
+        if (p < end) {
+          const uint32_t row = p / W;
+          y = a.g.y0 + static_cast<int>(row);
+          x = static_cast<int>(p - row * W);
+          rng = exact::rng_seed(static_cast<uint32_t>(x), static_cast<uint32_t>(y), a.frame, a.batch);  // :297
+          sum = f3{0.f, 0.f, 0.f};
+          smp = 0;
+          first_id = 0;
+          start_sample();
+          alive = true;
+        }
+      }
+      const uint32_t n_dead = static_cast<uint32_t>(__builtin_popcountll(dead));
+      cursor = (cursor + n_dead < end) ? cursor + n_dead : end;
+    }
+    if (__ballot(alive) == 0ull) break;  // range exhausted and every path finished
+    if (alive) {
+      // ---- one iteration of the segment loop, raytrace.comp.glsl:204-269
+      HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
+      closest_hit<BVH>(a.scene, o, d, h, stack, tid);  // :208-222
+      if (y >= a.count_y0 && y < a.count_y1) rays++;
+      if (seg == 0 && smp == 0) first_id = h.id1;
+      bool path_done;
+      if (ray_hits_light(o, d, light_c, a.light_r2)) {  // :226
+        acc = acc * (seg == 0 ? ld3(a.light_col_first) : ld3(a.light_col));  // :229,:233
+        path_done = true;
+      } else if (h.id1 == 0) {
+        acc = acc * sky_color(d);  // :266
+        path_done = true;
+      } else {
+        const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
+        float4 s0 = s[0], s1 = s[1], s2 = s[2];
+        float b1 = h.u / h.ad, b2 = h.v / h.ad;
+        float b0 = 1.0f - b1 - b2;                                       // :134
+        f3 pos = bary_point(xyz(s0), xyz(s1), xyz(s2), b0, b1, b2);      // :137
+        f3 n{s0.w, s1.w, s2.w};                                          // :150 (precomputed per triangle)
+        f3 alb = (n.x > 0.99f) ? f3{1.f, 0.f, 0.f} : ((-n.x > 0.99f) ? f3{0.f, 1.f, 0.f} : f3{0.7f, 0.7f, 0.7f});  // :155-163
+        acc = acc * alb;                                                 // :244
+        if (!(exact::dot(n, d) < 0.0f)) n = -n;                          // :247 faceforward
+        o = f3{fmaf_(a.ray_offset, n.x, pos.x), fmaf_(a.ray_offset, n.y, pos.y), fmaf_(a.ray_offset, n.z, pos.z)};  // :250
+        float st, ct;
+        exact::sincos2pi(exact::rng_next(rng), st, ct);                  // :256
+        float u = fmaf_(2.0f, exact::rng_next(rng), -1.0f);              // :257
+        float r = exact::sqrt_(fmaf_(-u, u, 1.0f));                      // :258
+        d = exact::normalize(f3{fmaf_(r, ct, n.x), fmaf_(r, st, n.y), n.z + u});  // :259-261
+        seg++;
+        path_done = (seg >= a.max_segments);  // :204 — a path that exhausts its budget returns its throughput (:270)
+      }
+      if (path_done) {
+        sum = sum + acc;  // :325
+        smp++;
+        if (smp < a.spp) {
+          start_sample();
+        } else {
+          const float ns = static_cast<float>(a.spp);
+          const size_t i = static_cast<size_t>(y - a.g.row_base) * W + static_cast<uint32_t>(x);
+          // :328,:343 — the reference's alpha is 0; here it carries the G-buffer depth for the filter (rgbd)
+          a.image[i] = make_float4(sum.x / ns, sum.y / ns, sum.z / ns, a.depth[i]);
+          if (a.hit_id) a.hit_id[i] = first_id;
+          alive = false;
+        }
+      }
+    }
+  }
+  // "ray" = one closest-hit query; one 64-bit atomic per block
+  for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+  if ((tid & 63) == 0 && rays) atomicAdd(&block_rays, rays);
+  __syncthreads();
+  if (tid == 0 && block_rays) atomicAdd(a.raycount, static_cast<unsigned long long>(block_rays));
+}
+
 // ------------------------------------------------------------------------------------------
 // self tests
 // ------------------------------------------------------------------------------------------
@@ -441,10 +581,20 @@ void launch_gradient(const GradientArgs& a, hipStream_t s) {
 }
 void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;
-  if (a.scene.use_bvh)
-    hipLaunchKernelGGL(k_pathtrace<true>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
-  else
-    hipLaunchKernelGGL(k_pathtrace<false>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
+  const uint64_t px = static_cast<uint64_t>(a.g.W) * static_cast<uint64_t>(a.g.y1 - a.g.y0);
+  const uint64_t waves = (px + kRegenPixels - 1) / kRegenPixels;
+  dim3 grid(static_cast<uint32_t>((waves + kBlockY - 1) / kBlockY)), block(kBlockX, kBlockY);
+  if (a.regen) {
+    if (a.scene.use_bvh)
+      hipLaunchKernelGGL(k_pathtrace_regen<true>, grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL(k_pathtrace_regen<false>, grid, block, 0, s, a);
+  } else {
+    if (a.scene.use_bvh)
+      hipLaunchKernelGGL(k_pathtrace<true>, grid_for(a.g), block, 0, s, a);
+    else
+      hipLaunchKernelGGL(k_pathtrace<false>, grid_for(a.g), block, 0, s, a);
+  }
 }
 void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s) {
   if (!n) return;

@@ -76,6 +76,7 @@ struct PathtraceArgs {
   uint32_t* hit_id;  // nullable
   unsigned long long* raycount;
   int32_t count_y0, count_y1;  // rows whose queries are counted
+  int32_t regen;               // 1: path-regeneration kernel (long paths)
 };
 
 struct AtrousArgs {
