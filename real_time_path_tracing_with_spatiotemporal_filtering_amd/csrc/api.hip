@@ -2,6 +2,7 @@
 // reference dispatch.  Host code only (compiled by hipcc together with kernels.hip).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -66,6 +67,7 @@ struct rtpt_ctx {
   Buf tris, leaf_order, isect_id, isect_leaf, shade, nodes;
   bool use_bvh = false;
   int bvh_depth = 0;
+  std::vector<float> host_tris;  // flattened world-space triangles, kept for small scenes (screen bounds)
 
   // frame state
   bool lut_prev_valid = false;   // D3
@@ -82,6 +84,7 @@ struct rtpt_ctx {
   std::vector<hipEvent_t> event_pool;
 
   uint32_t rows() const { return cfg.row_end - cfg.row_begin; }
+  bool width_fits_i16() const { return cfg.width < 30000 && cfg.height < 30000; }
   size_t pixels() const { return static_cast<size_t>(rows()) * cfg.width; }
 };
 
@@ -199,6 +202,46 @@ rt::SceneView scene_view(const rtpt_ctx* c) {
   s.n_tris = c->n_tris;
   s.use_bvh = c->use_bvh ? 1u : 0u;
   return s;
+}
+
+// Conservative screen bounds of the triangles of a small scene for a pinhole camera at `org` whose
+// view-space axes are the columns c0,c1,c2 and whose pixel (x,y) looks along
+// (nx/p00, ny/p11, -1), nx = (2(x+.5)-W)/W, ny = (2(y+.5)-H)/H  (the K0 ray; the K2 camera is the
+// special case c = identity, p00 = H/(W*slope), p11 = -1/slope).  `jitter_px` widens the bounds by
+// the largest possible sub-pixel offset of a primary ray.  A vertex at or behind the camera plane
+// makes the projection unbounded: such a triangle is never culled.
+bool screen_bounds(const rtpt_ctx* c, const double org[3], const double c0[3], const double c1[3], const double c2[3],
+                   double p00, double p11, double jitter_px, rt::TriBounds* out) {
+  if (c->host_tris.empty() || c->n_tris > static_cast<uint32_t>(rt::kCullMaxTris)) return false;
+  const double W = c->cfg.width, H = c->cfg.height;
+  for (uint32_t t = 0; t < c->n_tris; t++) {
+    double xmin = 1e30, xmax = -1e30, ymin = 1e30, ymax = -1e30;
+    bool unbounded = false;
+    for (int k = 0; k < 3; k++) {
+      const float* P = c->host_tris.data() + 9 * static_cast<size_t>(t) + 3 * k;
+      const double r[3] = {P[0] - org[0], P[1] - org[1], P[2] - org[2]};
+      const double xv = c0[0] * r[0] + c0[1] * r[1] + c0[2] * r[2];
+      const double yv = c1[0] * r[0] + c1[1] * r[1] + c1[2] * r[2];
+      const double zv = c2[0] * r[0] + c2[1] * r[1] + c2[2] * r[2];
+      const double len = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+      if (!(-zv > 1e-4 * (len + 1.0))) {
+        unbounded = true;
+        break;
+      }
+      const double cx = (p00 * xv / (-zv) + 1.0) * 0.5 * W, cy = (p11 * yv / (-zv) + 1.0) * 0.5 * H;
+      xmin = std::min(xmin, cx); xmax = std::max(xmax, cx);
+      ymin = std::min(ymin, cy); ymax = std::max(ymax, cy);
+    }
+    auto clamp16 = [](double v) { return static_cast<int16_t>(std::max(-32000.0, std::min(32000.0, v))); };
+    if (unbounded || !(xmax >= xmin)) {
+      out[t] = rt::TriBounds{-32000, -32000, 32000, 32000};
+    } else {
+      const double pad = jitter_px + 1.5;  // pixel index = continuous coordinate - 0.5, +1 px of slack
+      out[t] = rt::TriBounds{clamp16(std::floor(xmin - pad)), clamp16(std::floor(ymin - pad)), clamp16(std::ceil(xmax + pad)),
+                             clamp16(std::ceil(ymax + pad))};
+    }
+  }
+  return true;
 }
 
 bool is_identity(const float* m) {
@@ -448,6 +491,10 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   if ((rc = launch_check("scene_prepare"))) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));  // host staging vectors die at return
   c->n_tris = total;
+  if (total <= static_cast<uint32_t>(rt::kCullMaxTris))
+    c->host_tris = tris;
+  else
+    c->host_tris.clear();
   c->use_bvh = (total > 64) || (c->cfg.flags & RTPT_FLAG_FORCE_BVH);
   c->bvh_depth = bvh.max_depth;
   c->lut_prev_valid = false;
@@ -498,6 +545,14 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
   a.p11 = ubo->proj[5];
   rt::exact::mat_mul(ubo->proj, ubo->view, a.PV);
   a.tmax = c->cfg.ray_tmax;
+  {
+    const double org[3] = {a.org[0], a.org[1], a.org[2]};
+    const double d0[3] = {c0.x, c0.y, c0.z}, d1[3] = {c1.x, c1.y, c1.z}, d2[3] = {c2.x, c2.y, c2.z};
+    // view-space axis i of a world vector r is dot(row i of R, r); the columns c0,c1,c2 of the view
+    // matrix's rotation hold R^T's rows, i.e. x_view = (c0.x, c1.x, c2.x) . r
+    const double rx[3] = {d0[0], d1[0], d2[0]}, ry[3] = {d0[1], d1[1], d2[1]}, rz[3] = {d0[2], d1[2], d2[2]};
+    a.cull = (!c->use_bvh && c->width_fits_i16() && screen_bounds(c, org, rx, ry, rz, a.p00, a.p11, 0.0, a.bounds)) ? 1 : 0;
+  }
   a.vis = static_cast<uint32_t*>(c->vis[c->vis_cur].ptr);
   a.worldpos = static_cast<float4*>(c->worldpos.ptr);
   a.depth = static_cast<float*>(c->depth.ptr);
@@ -571,6 +626,17 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   // measured at 4K on the Cornell box: tile kernel 0.77 / 1.32 / 4.14 ms vs regeneration 1.10 / 1.60 / 2.54 ms
   // at 4 / 8 / 32 segments
   a.regen = ((c->cfg.flags & RTPT_FLAG_REGEN_PATHS) || c->cfg.max_segments >= 16) ? 1 : 0;
+  a.cull = 0;
+  if (!a.regen && !c->use_bvh && c->width_fits_i16()) {
+    // K2 camera (raytrace.comp.glsl:314-320): at cameraPos, looking down -z, d = (slope*ux, slope*uy, -1) with
+    // ux = (2cx - W)/H, uy = -(2cy - H)/H.  The Gaussian jitter is 0.375 * sqrt(-2 ln u1) <= 0.375 * 13.3 px
+    // (u1 >= 1e-38, :87).
+    const double org[3] = {pc->cameraPos[0], pc->cameraPos[1], pc->cameraPos[2]};
+    const double ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0}, ez[3] = {0, 0, 1};
+    const double slope = c->cfg.fov_slope, W = c->cfg.width, H = c->cfg.height;
+    if (slope > 0)
+      a.cull = screen_bounds(c, org, ex, ey, ez, H / (W * slope), -1.0 / slope, std::fabs(c->cfg.pixel_jitter) * 13.3, a.bounds) ? 1 : 0;
+  }
   c->final_swapped = false;
   c->image_alias = false;
   {

@@ -75,6 +75,30 @@ __device__ __forceinline__ void closest_hit_brute(const SceneView& sc, f3 o, f3 
   }
 }
 
+// Primary rays of one wave (64 pixels of row y, columns [x0, x0+63]) can only hit triangles whose padded
+// screen bounds meet that span.  Lane i classifies triangle i (n <= 64) and the ballot is the
+// candidate set; must be called with the whole wave converged (before any early return).
+__device__ __forceinline__ unsigned long long span_candidates(const TriBounds* bounds, uint32_t n, int x0, int y) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const TriBounds b = bounds[lane < n ? lane : 0u];
+  const bool overlap = lane < n && !(b.x0 > x0 + 63 || b.x1 < x0 || b.y0 > y || b.y1 < y);
+  return __ballot(overlap);
+}
+
+// brute force over a wave-uniform candidate set; ascending ids, so equal-t ties keep the lower id
+__device__ __forceinline__ void closest_hit_brute_set(const SceneView& sc, unsigned long long cand, f3 o, f3 d, HitRec& h) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  using cv4f = const __attribute__((address_space(4))) v4f;
+  cv4f* rec = (cv4f*)sc.isect_id;
+  while (cand) {
+    const uint32_t i = static_cast<uint32_t>(__builtin_ctzll(cand));
+    cand &= cand - 1;
+    const v4f a0 = rec[3 * i], a1 = rec[3 * i + 1], a2 = rec[3 * i + 2];
+    tri_test<false>(o, d, make_float4(a0.x, a0.y, a0.z, a0.w), make_float4(a1.x, a1.y, a1.z, a1.w),
+                    make_float4(a2.x, a2.y, a2.z, a2.w), i + 1, h);
+  }
+}
+
 __device__ __forceinline__ bool slab(const float* mn, const float* mx, f3 inv, f3 oi, float tbest, float& tnear) {
   float t0x = fmaf_(mn[0], inv.x, oi.x), t1x = fmaf_(mx[0], inv.x, oi.x);
   float t0y = fmaf_(mn[1], inv.y, oi.y), t1y = fmaf_(mx[1], inv.y, oi.y);
@@ -219,6 +243,9 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
   const int x = blockIdx.x * kBlockX + threadIdx.x;
   const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
+  unsigned long long cand = 0;
+  if (!BVH && a.cull)
+    cand = span_candidates(a.bounds, a.scene.n_tris, static_cast<int>(blockIdx.x) * kBlockX, __builtin_amdgcn_readfirstlane(y));
   if (x >= a.g.W || y >= a.g.y1) return;
   const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
   float nx = fmaf_(2.0f, static_cast<float>(x) + 0.5f, -fw) / fw;
@@ -228,7 +255,10 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
   f3 d = exact::normalize(f3{exact::dot(c0, dv), exact::dot(c1, dv), exact::dot(c2, dv)});
   f3 o = ld3(a.org);
   HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
-  closest_hit<BVH>(a.scene, o, d, h, stack, tid);
+  if (!BVH && a.cull)
+    closest_hit_brute_set(a.scene, cand, o, d, h);
+  else
+    closest_hit<BVH>(a.scene, o, d, h, stack, tid);
   const size_t i = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
   a.vis[i] = h.id1;  // visibility.frag.glsl:23
   if (h.id1) {
@@ -326,6 +356,9 @@ __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
   const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
   const bool active = (x < a.g.W) && (y < a.g.y1);
   unsigned int rays = 0;
+  unsigned long long cand = 0;  // candidates of this wave's (jittered) primary rays
+  if (!BVH && a.cull)
+    cand = span_candidates(a.bounds, a.scene.n_tris, static_cast<int>(blockIdx.x) * kBlockX, __builtin_amdgcn_readfirstlane(y));
   if (active) {
     uint32_t rng = exact::rng_seed(static_cast<uint32_t>(x), static_cast<uint32_t>(y), a.frame, a.batch);
     const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
@@ -348,7 +381,12 @@ __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
       f3 acc{1.f, 1.f, 1.f};
       for (uint32_t seg = 0; seg < a.max_segments; seg++) {  // :204
         HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
-        closest_hit<BVH>(a.scene, o, d, h, stack, tid);  // :208-222
+        if (!BVH && a.cull && seg == 0) {
+          // the jittered primary rays of this wave stay inside the padded bounds (see api.hip)
+          closest_hit_brute_set(a.scene, cand, o, d, h);
+        } else {
+          closest_hit<BVH>(a.scene, o, d, h, stack, tid);  // :208-222
+        }
         rays++;
         if (seg == 0 && smp == 0) first_id = h.id1;
         if (ray_hits_light(o, d, light_c, a.light_r2)) {  // :226

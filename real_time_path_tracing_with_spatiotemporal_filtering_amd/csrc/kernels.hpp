@@ -21,6 +21,15 @@ struct SceneView {
   uint32_t use_bvh;  // 0: brute force over isect_id, 1: BVH traversal
 };
 
+// Screen-space bounds of every triangle of a small scene (<= 64), computed on the host per call and
+// passed in the kernel-argument segment (scalar loads).  A wave covers 64 pixels of one row; a
+// triangle whose padded bounds miss that span cannot be hit by any of the wave's PRIMARY rays, so the
+// wave skips it with a scalar branch.  Conservative by construction => results are unchanged.
+struct TriBounds {
+  int16_t x0, y0, x1, y1;  // inclusive pixel bounds, already padded; x0 > x1 marks "never"
+};
+constexpr int kCullMaxTris = 64;
+
 struct FrameGeom {
   int32_t W, H;      // full frame
   int32_t row_base;  // first frame row stored in the planes of this context
@@ -38,6 +47,8 @@ struct GbufferArgs {
   uint32_t* vis;
   float4* worldpos;
   float* depth;
+  int32_t cull;                      // 1: bounds[] is valid
+  TriBounds bounds[kCullMaxTris];
 };
 
 struct LutArgs {
@@ -77,6 +88,8 @@ struct PathtraceArgs {
   unsigned long long* raycount;
   int32_t count_y0, count_y1;  // rows whose queries are counted
   int32_t regen;               // 1: path-regeneration kernel (long paths)
+  int32_t cull;                // 1: bounds[] is valid for the primary segment (tile kernel only)
+  TriBounds bounds[kCullMaxTris];
 };
 
 struct AtrousArgs {
