@@ -189,20 +189,23 @@ void oracle_flatten(const float* xyz, const uint32_t* idx, uint32_t n_tris, cons
       }
 }
 
-/* One ray-triangle routine shared by every closest-hit query (D4).  Moller-Trumbore with the
- * division deferred: returns 1 and (t, b1, b2) when the ray o + t d, 0 < t < tmax, meets the
- * triangle (both faces; raytrace.comp.glsl:209-216: opaque, no culling, tmin 0, tmax 1e4). */
+/* One ray-triangle routine shared by every closest-hit query (D4).  Scalar-triple-product form of
+ * Moller-Trumbore with the plane normal n = e1 x e2 precomputed per triangle and the division
+ * deferred:  det = -d.n,  tt = (o-v0).n,  c = (o-v0) x d,  u = e2.c,  v = -e1.c
+ * (e1.(d x e2) = -d.n,  tv.(d x e2) = e2.(tv x d),  d.(tv x e1) = -e1.(tv x d),  e2.(tv x e1) = tv.n).
+ * Returns 1 and (t, b1, b2) when the ray o + t d, 0 < t < tmax, meets the triangle (both faces;
+ * raytrace.comp.glsl:209-216: opaque, no culling, tmin 0, tmax 1e4). */
 static inline int tri_hit(vec3 o, vec3 d, const float* tri, float tmax, float* t, float* b1, float* b2) {
   vec3 v0 = v3(tri[0], tri[1], tri[2]);
   vec3 e1 = v3(tri[3] - tri[0], tri[4] - tri[1], tri[5] - tri[2]);
   vec3 e2 = v3(tri[6] - tri[0], tri[7] - tri[1], tri[8] - tri[2]);
-  vec3 p = v3_cross(d, e2);
-  float det = v3_dot(e1, p);
+  vec3 n = v3_cross(e1, e2);
   vec3 tv = v3_sub(o, v0);
-  float u = v3_dot(tv, p);
-  vec3 q = v3_cross(tv, e1);
-  float v = v3_dot(d, q);
-  float tt = v3_dot(e2, q);
+  float det = -v3_dot(d, n);
+  float tt = v3_dot(tv, n);
+  vec3 c = v3_cross(tv, d);
+  float u = v3_dot(e2, c);
+  float v = -v3_dot(e1, c);
   float ad = fabsf(det);
   if (!(ad > 0.0f)) return 0; /* det == 0 or NaN */
   if (det < 0.0f) { u = -u; v = -v; tt = -tt; }

@@ -197,6 +197,7 @@ rt::SceneView scene_view(const rtpt_ctx* c) {
   rt::SceneView s;
   s.isect_id = static_cast<const float4*>(c->isect_id.ptr);
   s.isect_leaf = static_cast<const float4*>(c->isect_leaf.ptr);
+  s.leaf_ids = static_cast<const uint32_t*>(c->leaf_order.ptr);
   s.shade = static_cast<const float4*>(c->shade.ptr);
   s.nodes = static_cast<const rt::BvhNode*>(c->nodes.ptr);
   s.n_tris = c->n_tris;

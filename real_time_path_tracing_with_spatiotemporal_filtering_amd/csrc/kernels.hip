@@ -23,17 +23,19 @@ struct HitRec {
   float u, v, ad;  // scaled barycentrics of the best hit: b1 = u/ad, b2 = v/ad
 };
 
-// Moller-Trumbore with the division deferred until a candidate passes the inside tests.
+// Scalar-triple-product form of Moller-Trumbore, plane normal n = e1 x e2 precomputed per triangle,
+// division deferred until a candidate passes the inside tests:
+//   det = -d.n,  tt = (o-v0).n,  c = (o-v0) x d,  u = e2.c,  v = -e1.c        (21 flops instead of 27)
+// record: r0 = (v0.xyz, e1.x)  r1 = (e1.yz, e2.xy)  r2 = (e2.z, n.xyz)
 template <bool TIE_BREAK>
 __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float4 r2, uint32_t id1, HitRec& h) {
-  f3 v0{r0.x, r0.y, r0.z}, e1{r0.w, r1.x, r1.y}, e2{r1.z, r1.w, r2.x};
-  f3 p = exact::cross(d, e2);
-  float det = exact::dot(e1, p);
+  f3 v0{r0.x, r0.y, r0.z}, e1{r0.w, r1.x, r1.y}, e2{r1.z, r1.w, r2.x}, n{r2.y, r2.z, r2.w};
   f3 tv = o - v0;
-  float u = exact::dot(tv, p);
-  f3 q = exact::cross(tv, e1);
-  float v = exact::dot(d, q);
-  float tt = exact::dot(e2, q);
+  float det = -exact::dot(d, n);
+  float tt = exact::dot(tv, n);
+  f3 c = exact::cross(tv, d);
+  float u = exact::dot(e2, c);
+  float v = -exact::dot(e1, c);
   float ad = __builtin_fabsf(det);
   if (det < 0.0f) {
     u = -u;
@@ -127,16 +129,14 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
     if (hl && nd.lcnt) {
       for (uint32_t j = 0; j < nd.lcnt; j++) {
         const float4* r = sc.isect_leaf + 3 * (nd.lidx + j);
-        float4 r2 = r[2];
-        tri_test<true>(o, d, r[0], r[1], r2, f2u(r2.y) + 1, h);
+        tri_test<true>(o, d, r[0], r[1], r[2], sc.leaf_ids[nd.lidx + j] + 1, h);
       }
       hl = false;
     }
     if (hr && nd.rcnt) {
       for (uint32_t j = 0; j < nd.rcnt; j++) {
         const float4* r = sc.isect_leaf + 3 * (nd.ridx + j);
-        float4 r2 = r[2];
-        tri_test<true>(o, d, r[0], r[1], r2, f2u(r2.y) + 1, h);
+        tri_test<true>(o, d, r[0], r[1], r[2], sc.leaf_ids[nd.ridx + j] + 1, h);
       }
       hr = false;
     }
@@ -183,22 +183,24 @@ __global__ void k_scene_prepare(ScenePrepArgs a) {
     const float* t = a.tris + 9 * static_cast<size_t>(i);
     f3 v0 = ld3(t), v1 = ld3(t + 3), v2 = ld3(t + 6);
     f3 e1 = v1 - v0, e2 = v2 - v0;
+    f3 nn = exact::cross(e1, e2);
     a.isect_id[3 * i] = make_float4(v0.x, v0.y, v0.z, e1.x);
     a.isect_id[3 * i + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-    a.isect_id[3 * i + 2] = make_float4(e2.z, u2f(i), 0.f, 0.f);
-    f3 n = exact::normalize(exact::cross(e1, e2));  // raytrace.comp.glsl:150
+    a.isect_id[3 * i + 2] = make_float4(e2.z, nn.x, nn.y, nn.z);
+    f3 n = exact::normalize(nn);  // raytrace.comp.glsl:150
     a.shade[3 * i] = make_float4(v0.x, v0.y, v0.z, n.x);
     a.shade[3 * i + 1] = make_float4(v1.x, v1.y, v1.z, n.y);
     a.shade[3 * i + 2] = make_float4(v2.x, v2.y, v2.z, n.z);
   }
   {
-    uint32_t id = a.leaf_order[i];
+    uint32_t id = a.leaf_order[i];  // leaf slot i holds triangle id (ids stay in leaf_order)
     const float* t = a.tris + 9 * static_cast<size_t>(id);
     f3 v0 = ld3(t), v1 = ld3(t + 3), v2 = ld3(t + 6);
     f3 e1 = v1 - v0, e2 = v2 - v0;
+    f3 nn = exact::cross(e1, e2);
     a.isect_leaf[3 * i] = make_float4(v0.x, v0.y, v0.z, e1.x);
     a.isect_leaf[3 * i + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-    a.isect_leaf[3 * i + 2] = make_float4(e2.z, u2f(id), 0.f, 0.f);
+    a.isect_leaf[3 * i + 2] = make_float4(e2.z, nn.x, nn.y, nn.z);
   }
 }
 

@@ -10,11 +10,12 @@
 namespace rt {
 
 // Device view of the scene.  Records are float4 triples:
-//   isect record  r0 = (v0.x, v0.y, v0.z, e1.x)  r1 = (e1.y, e1.z, e2.x, e2.y)  r2 = (e2.z, id_bits, 0, 0)
+//   isect record  r0 = (v0.x, v0.y, v0.z, e1.x)  r1 = (e1.y, e1.z, e2.x, e2.y)  r2 = (e2.z, n.x, n.y, n.z)   n = e1 x e2
 //   shade record  s0 = (v0.xyz, n.x)  s1 = (v1.xyz, n.y)  s2 = (v2.xyz, n.z)     n = unit geometric normal
 struct SceneView {
   const float4* isect_id;    // id order  (small-scene wave-uniform brute force)
   const float4* isect_leaf;  // BVH leaf order
+  const uint32_t* leaf_ids;  // triangle id of each leaf slot
   const float4* shade;       // id order
   const BvhNode* nodes;
   uint32_t n_tris;
