@@ -181,7 +181,7 @@ __device__ __forceinline__ void dma_b32(const void* base, uint32_t voff, uint32_
 
 // Wave-private "comb" kernel.
 //
-// A wave owns a 64-px-wide column segment and kCombM output rows spaced k apart: y_m = yc + m*k + r.
+// A wave owns a 64-px-wide column segment and kCombM (= 3; 2/3/4 measured 78/72/72 us at 4K) output rows spaced k apart: y_m = yc + m*k + r.
 // Their tap rows y_m - k, y_m, y_m + k are the kCombM + 2 rows yc + (j-1)*k + r, j = 0..M+1, so each
 // staged row serves up to three outputs (2 rows fetched per output at M = 2 instead of 3).  The wave
 // stages those rows (64 + 2k px: colour, depth, id) into its OWN slice of LDS with LDS-DMA, waits for
@@ -193,7 +193,10 @@ __device__ __forceinline__ void dma_b32(const void* base, uint32_t voff, uint32_
 // Normal weights pow(max(0, dot(n_p, n_q)), sigma_n) (:62) depend only on the id pair, so k_lut
 // tabulates them once per frame ((T+1)^2 floats, same arithmetic) and the block copies the table to
 // LDS: one ds_read_b32 per tap replaces the compare/branch/gather/pow sequence.
-constexpr int kCombM = 2;       // output rows per wave
+#ifndef RTPT_COMB_M
+#define RTPT_COMB_M 3
+#endif
+constexpr int kCombM = RTPT_COMB_M;  // output rows per wave
 constexpr int kPairMax = 64;    // ids (T+1) for which the pair table is kept in LDS
 
 template <int CWp, bool FINAL, bool EXACT>  // CWp: staged row stride in cells, >= 64 + 2k (compile time:
@@ -413,7 +416,13 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
       n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     const uint32_t nlb = static_cast<uint32_t>(a.tiles_x) * static_cast<uint32_t>(a.tiles_y) * static_cast<uint32_t>(a.k);
-    uint32_t per_xcd = static_cast<uint32_t>((n_cu + 7) / 8) * 5u;  // 5 resident blocks per CU (LDS-bound)
+    // persistent grid: as many blocks per CU as 160 KiB of LDS admits (5 at M = 2, k <= 8)
+    const size_t lds_block = static_cast<size_t>((np * np * 4 + 15) & ~15) +
+                             static_cast<size_t>(kBlockY) * (kCombM + 2) * (a.k <= 4 ? 72 : (a.k <= 8 ? 80 : 96)) * 20;
+    uint32_t per_cu = static_cast<uint32_t>((160u * 1024u) / lds_block);
+    if (per_cu > 8u) per_cu = 8u;
+    if (per_cu < 1u) per_cu = 1u;
+    uint32_t per_xcd = static_cast<uint32_t>((n_cu + 7) / 8) * per_cu;
     if (per_xcd > (nlb + 7) / 8) per_xcd = (nlb + 7) / 8;
     dim3 grid(per_xcd * 8u);
     // staged row stride: 72 cells for k <= 4, 80 for k <= 8, 96 for k <= 16
