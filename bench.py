@@ -33,6 +33,9 @@ WORKLOADS = {
     "1080p": dict(width=1920, height=1080, max_segments=4, iterations=5),
     # the reference's own constants (main.cpp:52-55, raytrace.comp.glsl:204)
     "reference": dict(width=1000, height=800, max_segments=32, iterations=9),
+    # BASELINE.json configs[4]: 10x10x10 lattice of 6x6-tessellated Cornell boxes = 1,152,000 triangles,
+    # 8 segments (divergent-traversal stress; BVH path, direct filter kernel)
+    "instanced": dict(width=3840, height=2160, max_segments=8, iterations=5, instanced=True),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # algorithmic bytes per pixel per launch (SURVEY.md 8d / BASELINE.md 3)
@@ -40,9 +43,16 @@ BYTES_PER_PX = {"k_atrous": 40, "k_atrous_final": 72, "k_gradient": 36, "k_gbuff
 
 
 def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=True):
-    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE, make_app
+    extra = {}
+    if wl.get("instanced"):
+        from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi, scenes
+        xyz, idx = abi.load_obj(DEFAULT_SCENE)
+        vx, ti, xf, cam, zfar = scenes.instanced_cornell(xyz, idx)
+        extra = dict(mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar,
+                     lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
     app = make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"],
-                   rank=rank, world=world, mode=args.halo, torch_planes=(world > 1))
+                   rank=rank, world=world, mode=args.halo, torch_planes=(world > 1), **extra)
     ctx = app.backend.ctx
 
     def fence():
@@ -224,7 +234,7 @@ def main():
             "data": "synthetic (Cornell box OBJ, scripted static camera/light, RNG seeded by pixel+frame)",
             "config": {"workload": f"cornell-{args.workload}-1spp-{wl['max_segments']}seg-{wl['iterations']}atrous",
                        "width": wl["width"], "height": wl["height"], "max_segments": wl["max_segments"],
-                       "atrous_iterations": wl["iterations"], "triangles": 32,
+                       "atrous_iterations": wl["iterations"], "triangles": 1152000 if wl.get("instanced") else 32,
                        "parallelism": f"row-strips x{world}" + (f" ({args.halo} halo)" if world > 1 else "")},
             "rays_per_frame": round(rays / args.steps, 1),
             "roofline": {"kernel": "k_atrous (one a-trous iteration, k < N)", "bound": "hbm",
@@ -245,7 +255,7 @@ def main():
             "value": round(r2 / e2 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
             "atrous_GBps": kr2.get("k_atrous", {}).get("algorithmic_GBps"),
             "atrous_frac": round(kr2.get("k_atrous", {}).get("algorithmic_GBps", 0) / HBM_PEAK_GBS, 4)}}
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and not wl.get("instanced"):
         result["cpu_baseline"] = cpu_baseline(wl)
     if world > 1:
         dist.barrier()

@@ -244,7 +244,7 @@ class OracleApp:
     of scope)."""
 
     def __init__(self, width, height, tris, max_segments=32, iterations=9,
-                 camera=(-0.001, 1.0, 6.0), light=(1.0, 1.0, -0.4), light_color=(0.5, 0.5, 0.5)):
+                 camera=(-0.001, 1.0, 6.0), light=(1.0, 1.0, -0.4), light_color=(0.5, 0.5, 0.5), z_near=0.1, z_far=10.0):
         self.cfg = config_default(width, height)
         self.cfg.max_segments = max_segments
         self.iterations = iterations          # main.cpp:55
@@ -253,13 +253,14 @@ class OracleApp:
         self.light = np.array(light, np.float32)     # main.cpp:70
         self.light_color = np.array(light_color, np.float32)  # main.cpp:72
         self.camera_moved = False
+        self.z_near, self.z_far = z_near, z_far
         self.frame = 0
         self.pc = PushConstants()
         self.ubo = Ubo()
         # uploadBuffers main.cpp:481-489 — initial matrices look at (0,1,0)
         self.ubo.model[:] = np.eye(4, dtype=np.float32).ravel()
         self.ubo.view[:] = look_at(self.camera, (0.0, 1.0, 0.0), (0.0, 1.0, 0.0))
-        proj = perspective(np.float32(0.20) * 2, np.float32(width) / np.float32(height), 0.1, 10.0)
+        proj = perspective(np.float32(0.20) * 2, np.float32(width) / np.float32(height), self.z_near, self.z_far)
         proj[5] *= -1
         self.ubo.proj[:] = proj
         self.ubo.modelPrev[:] = self.ubo.model[:]
@@ -280,7 +281,7 @@ class OracleApp:
         u.model[:] = np.eye(4, dtype=np.float32).ravel()
         c = self.camera
         u.view[:] = look_at(c, (c[0], c[1], np.float32(c[2] - np.float32(6.0))), (0.0, 1.0, 0.0))
-        proj = perspective(np.float32(0.20) * 2, np.float32(self.cfg.width) / np.float32(self.cfg.height), 0.1, 10.0)
+        proj = perspective(np.float32(0.20) * 2, np.float32(self.cfg.width) / np.float32(self.cfg.height), self.z_near, self.z_far)
         proj[5] *= -1
         u.proj[:] = proj
 

@@ -113,12 +113,13 @@ class PathTracingApplication:
 
     def __init__(self, backend, width=1000, height=800, maxWaveletIteration=9, plan: StripPlan | None = None,
                  cameraOrigin=(-0.001, 1.0, 6.0), lightPos=(1.0, 1.0, -0.4), lightColor=(0.5, 0.5, 0.5),
-                 group=None):
+                 group=None, z_near=0.1, z_far=10.0):
         self.backend = backend
         self.render_width, self.render_height = width, height          # main.cpp:52-53
         self.maxWaveletIteration = maxWaveletIteration                 # main.cpp:55
         self.plan = plan or StripPlan(height, 1, 0, maxWaveletIteration)
         self.group = group
+        self.z_near, self.z_far = z_near, z_far                        # main.cpp:483 (0.1, 10)
         self.cameraOrigin = np.array(cameraOrigin, np.float32)         # main.cpp:65
         self.lightPos = np.array(lightPos, np.float32)                 # main.cpp:70
         self.lightColor = np.array(lightColor, np.float32)             # main.cpp:72
@@ -141,7 +142,7 @@ class PathTracingApplication:
 
     def _perspective(self):
         proj = abi.perspective(np.float32(FOV) * 2, np.float32(self.render_width) / np.float32(self.render_height),
-                               0.1, 10.0)
+                               self.z_near, self.z_far)
         proj[5] *= -1  # main.cpp:484
         return proj
 
@@ -256,14 +257,19 @@ class PathTracingApplication:
 
 
 def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode="exchange", flags=0,
-             torch_planes=None, debug_mask=0, scene=DEFAULT_SCENE, instance_xforms=None, group=None, **app_kw):
-    """createBuffers + loadMesh + buildAccelerationStructure for one rank."""
+             torch_planes=None, debug_mask=0, scene=DEFAULT_SCENE, instance_xforms=None, group=None, mesh=None,
+             **app_kw):
+    """createBuffers + loadMesh + buildAccelerationStructure for one rank.  `mesh` = (xyz, idx) replaces
+    the OBJ (synthetic scenes of scenes.py)."""
     plan = StripPlan(height, world, rank, iterations, mode)
     if torch_planes is None:
         torch_planes = world > 1 and mode == "exchange"
     be = HipBackend(width, height, plan, max_segments=max_segments, flags=flags, torch_planes=torch_planes,
                     debug_mask=debug_mask)
     app = PathTracingApplication(be, width, height, iterations, plan, group=group, **app_kw)
-    app.loadMesh(scene)
+    if mesh is not None:
+        app.objVertices, app.objIndices = mesh
+    else:
+        app.loadMesh(scene)
     app.buildAccelerationStructure(instance_xforms)
     return app

@@ -304,3 +304,72 @@ def test_errors(hip_lib, cornell):
     bad.struct_size = 4
     with pytest.raises(abi.RtptError):
         abi.Context(bad)
+
+
+# ------------------------------------------------------------------------------ BVH path, larger scenes
+def test_bvh_instanced_scene_frame_parity(hip_lib, oracle, cornell):
+    """2x2x2 lattice of 2x2-tessellated boxes = 1,024 triangles: the BVH traversal, the direct filter
+    kernel (no id-pair table beyond 63 triangles) and u32 ids beyond the reference's fp16 range of
+    exact integers, against the oracle's brute force."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd import scenes
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import HipBackend, PathTracingApplication
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripPlan
+    xyz, idx, _ = cornell
+    vx, ti = scenes.tessellate_quads(xyz, idx, 2)
+    xf = scenes.lattice_xforms(2, 2, 2, 2.5)
+    w, h, seg, n = 96, 64, 3, 3
+    cam = (0.2, 2.3, 9.0)
+    be = HipBackend(w, h, StripPlan(h, 1, 0, n), max_segments=seg,
+                    debug_mask=hip_lib.DEBUG_HIT_ID | hip_lib.DEBUG_PREV_PIXEL)
+    app = PathTracingApplication(be, w, h, n, cameraOrigin=cam, z_far=30.0)
+    app.objVertices, app.objIndices = vx, ti
+    app.buildAccelerationStructure(xf)
+    tris = oracle.flatten(vx, ti, xf)
+    assert len(tris) == 1024
+    ref = oracle.OracleApp(w, h, tris, max_segments=seg, iterations=n, camera=cam, z_far=30.0)
+    ctx = be.ctx
+    for f, (keys, move) in enumerate([((), None), (("A",), (-0.1, 0, 0))]):
+        app.updateScene(keys)
+        app.drawVisbilityBuffer()
+        app.computeTemporalGradient()
+        app.drawSceneToImage()
+        vis, hit, traced = ctx.readback(hip_lib.PLANE_VIS_ID), ctx.readback(hip_lib.PLANE_HIT_ID), ctx.readback(hip_lib.PLANE_IMAGE)
+        depth = ctx.readback(hip_lib.PLANE_DEPTH)
+        app.applyTemporalFiltering()
+        final, pp = ctx.readback(hip_lib.PLANE_IMAGE), ctx.readback(hip_lib.PLANE_PREV_PIXEL)
+        app.copyImageToSwapChainsCurrentImage()
+        app.frameCount += 1
+        fo = ref.draw_scene(move_camera=move)
+        assert vis.max() > 600 and np.array_equal(vis, fo.vis)
+        assert np.array_equal(hit, fo.hit_id)
+        assert np.array_equal(bits(depth), bits(fo.depth))
+        assert np.array_equal(bits(traced), bits(fo.traced))
+        assert np.array_equal(pp, fo.prev_pixel)
+        ok, rel = l2_ok(final, fo.image)
+        assert ok, rel
+    be.close()
+
+
+def test_bvh_million_triangle_rays(hip_lib, oracle, cornell):
+    """BASELINE.json configs[4] geometry: 10x10x10 lattice x 6x6 tessellation = 1,152,000 triangles.
+    The oracle's brute force is O(rays x triangles), so parity is checked on a ray sample."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd import scenes
+    xyz, idx, _ = cornell
+    vx, ti, xf, cam, zfar = scenes.instanced_cornell(xyz, idx)
+    tris = oracle.flatten(vx, ti, xf)
+    assert len(tris) == 1_152_000
+    rng = np.random.default_rng(7)
+    n = 1536
+    o = np.tile(np.array(cam, np.float32), (n, 1))
+    o[n // 2:] = rng.uniform([-11, 0.1, -22], [11, 24, 0.5], (n - n // 2, 3))   # origins inside the lattice
+    d = rng.normal(size=(n, 3))
+    d[: n // 2] = np.array([0, 0, -1.0]) + rng.uniform(-0.2, 0.2, (n // 2, 3))  # camera-like bundle
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    with hip_lib.Context(hip_lib.config_default(64, 64)) as ctx:
+        ctx.scene_upload(vx, ti, xf)
+        ids, ts = ctx.selftest_trace(rays)
+    want_ids, want_ts = oracle.trace_rays(tris, rays)
+    assert np.array_equal(ids, want_ids)
+    assert np.array_equal(bits(ts), bits(want_ts))
+    assert (ids > 0).mean() > 0.5 and ids.max() > 1_000_000
