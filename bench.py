@@ -52,15 +52,16 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
         extra = dict(mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar,
                      lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
     app = make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"],
-                   rank=rank, world=world, mode=args.halo, torch_planes=(world > 1), **extra)
+                   rank=rank, world=world, mode=args.halo,
+                   torch_planes=(dist is not None and args.halo == "exchange"), **extra)
     ctx = app.backend.ctx
 
     def fence():
+        ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
-        ctx.sync()
 
     for _ in range(warmup):
         app.drawScene()
@@ -76,7 +77,7 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
     ctx.timing_enable(False)
     kern = ctx.timing_collect() if collect_kernels else {}
     rays = ctx.raycount()
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -181,7 +182,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k")
-    ap.add_argument("--halo", choices=["exchange", "redundant"], default="exchange")
+    # redundant halo rows are the default: at 4K / 8 ranks a strip is ~0.2 ms of work and five k*61 KB
+    # exchanges per frame are latency-bound; --halo exchange runs the RCCL send/recv path
+    ap.add_argument("--halo", choices=["exchange", "redundant"], default="redundant")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl) and torch-owned planes even with one rank (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -200,10 +205,13 @@ def main():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
     elapsed, rays, kern, plan = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist)
@@ -257,7 +265,7 @@ def main():
             "atrous_frac": round(kr2.get("k_atrous", {}).get("algorithmic_GBps", 0) / HBM_PEAK_GBS, 4)}}
     if world == 1 and rank == 0 and not args.no_cpu_baseline and not wl.get("instanced"):
         result["cpu_baseline"] = cpu_baseline(wl)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
