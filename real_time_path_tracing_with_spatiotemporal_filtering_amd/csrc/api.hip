@@ -71,6 +71,8 @@ struct rtpt_ctx {
 
   // frame state
   bool lut_prev_valid = false;   // D3
+  bool lut_holds_scene[2] = {false, false};  // buffer holds LUT(scene, model = identity): no need to rebuild it
+  bool tables_valid = false;     // normal / id-pair tables match the scene
   bool final_swapped = false;    // the final filter pass already rotated IMAGE <-> FILTERED this frame
   bool image_alias = false;      // between rtpt_end_frame and the next rtpt_raytrace IMAGE reads as PREVIOUS
   int hist_y0 = 0, hist_y1 = 0;  // rows of PREVIOUS holding a valid previous frame
@@ -499,6 +501,8 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   c->use_bvh = (total > 64) || (c->cfg.flags & RTPT_FLAG_FORCE_BVH);
   c->bvh_depth = bvh.max_depth;
   c->lut_prev_valid = false;
+  c->lut_holds_scene[0] = c->lut_holds_scene[1] = false;
+  c->tables_valid = false;
   return RTPT_OK;
 }
 
@@ -511,7 +515,10 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
   if (!is_identity(ubo->model))
     return fail(RTPT_E_INVALID, "ubo.model must be identity (the reference's is, main.cpp:1469; animated models are out of scope)");
   HIP_TRY(hipSetDevice(c->device));
-  {
+  // The LUT is a function of (scene, model) and the model is the identity, so the geometry stage's
+  // per-frame rewrite (visibility.geom.glsl:57-59) produces the same bytes every frame: rebuild only
+  // a buffer that does not hold them yet (after rtpt_scene_upload / rtpt_set_plane).
+  if (!c->lut_holds_scene[c->lut_cur] || !c->tables_valid) {
     Timer tm(c, RTPT_K_LUT);
     rt::LutArgs la;
     la.n_tris = c->n_tris;
@@ -522,6 +529,8 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
     la.pair_tab = static_cast<float*>(c->pair_tab.ptr);
     la.sigma_n = c->cfg.sigma_n;
     rt::launch_lut(la, c->stream);
+    c->lut_holds_scene[c->lut_cur] = true;
+    c->tables_valid = true;
   }
   if ((rc = launch_check("lut"))) return rc;
   if (!c->lut_prev_valid) {
@@ -529,6 +538,7 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
     HIP_TRY(hipMemcpyAsync(c->lut[c->lut_cur ^ 1].ptr, c->lut[c->lut_cur].ptr, c->lut[c->lut_cur].bytes, hipMemcpyDeviceToDevice,
                            c->stream));
     c->lut_prev_valid = true;
+    c->lut_holds_scene[c->lut_cur ^ 1] = true;
   }
   rt::GbufferArgs a;
   a.g = geom(c, y0, y1);
@@ -791,7 +801,11 @@ int rtpt_set_plane(rtpt_ctx* c, rtpt_plane which, const void* src, size_t bytes)
     c->hist_y0 = static_cast<int>(c->cfg.row_begin);
     c->hist_y1 = static_cast<int>(c->cfg.row_end);
   }
-  if (which == RTPT_PLANE_LUT_PREV) c->lut_prev_valid = true;
+  if (which == RTPT_PLANE_LUT_PREV) {
+    c->lut_prev_valid = true;
+    c->lut_holds_scene[c->lut_cur ^ 1] = false;  // injected content: rebuild when it becomes current
+  }
+  if (which == RTPT_PLANE_LUT) c->lut_holds_scene[c->lut_cur] = false;
   return RTPT_OK;
 }
 
