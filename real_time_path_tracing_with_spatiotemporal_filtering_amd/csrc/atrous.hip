@@ -179,44 +179,60 @@ __device__ __forceinline__ void dma_b32(const void* base, uint32_t voff, uint32_
 }
 
 
-// Wave-private "comb" kernel.
+// "Comb" kernel.
 //
-// A wave owns a 64-px-wide column segment and kCombM (= 3; 2/3/4 measured 78/72/72 us at 4K) output rows spaced k apart: y_m = yc + m*k + r.
-// Their tap rows y_m - k, y_m, y_m + k are the kCombM + 2 rows yc + (j-1)*k + r, j = 0..M+1, so each
-// staged row serves up to three outputs (2 rows fetched per output at M = 2 instead of 3).  The wave
-// stages those rows (64 + 2k px: colour, depth, id) into its OWN slice of LDS with LDS-DMA, waits for
-// its own vmcnt, and filters — no workgroup barrier anywhere after the prologue, so waves drift apart
-// and loads, LDS reads and VALU work of different waves overlap.  The horizontal taps x-k / x / x+k
-// are the same staged row read at three lane offsets: 3 vector-memory instructions per staged row
-// instead of 27 per pixel.
+// A wave owns a 64-px-wide column segment and kCombM output rows spaced k apart: y_m = yc + m*k + r
+// (a comb of residue r).  Their tap rows y_m - k, y_m, y_m + k are again rows of the comb, so each
+// staged row serves up to three outputs.  Rows (64 + 2k px: colour+depth cell, id) are staged into
+// LDS with LDS-DMA; the horizontal taps x-k / x / x+k are the same staged row read at three lane
+// offsets: 2 vector-memory instructions per staged row instead of 27 per pixel.
 //
 // Normal weights pow(max(0, dot(n_p, n_q)), sigma_n) (:62) depend only on the id pair, so k_lut
 // tabulates them once per frame ((T+1)^2 floats, same arithmetic) and the block copies the table to
 // LDS: one ds_read_b32 per tap replaces the compare/branch/gather/pow sequence.
 #ifndef RTPT_COMB_M
-#define RTPT_COMB_M 3
+#define RTPT_COMB_M 2
 #endif
 constexpr int kCombM = RTPT_COMB_M;  // output rows per wave
 constexpr int kPairMax = 64;    // ids (T+1) for which the pair table is kept in LDS
 
-template <int CWp, bool FINAL, bool EXACT>  // CWp: staged row stride in cells, >= 64 + 2k (compile time:
-__global__ __launch_bounds__(kThreads) void k_atrous_comb(AtrousArgs a) {  // tap rows become ds_read immediates)
+// The kernel.  The kShWaves waves of a block filter kShWaves CONSECUTIVE chunks of one comb: 4M outputs
+// per column whose tap rows are the 4M+2 rows yg + (j-1)k.  Each distinct row is staged by exactly
+// one wave into a block-shared LDS region and a workgroup barrier publishes it.  (A first version
+// staged M+2 rows per wave privately — no barrier at all — but then a block fetches 4(M+2) rows of
+// which only 4M+2 are distinct, and the duplicates are in flight at the same time so L2 serves few
+// of them: PMC showed 1.74x the algorithmic read bytes reaching the fabric, and at 5.6 TB/s the
+// kernel was fabric-bound at 72-76 us.  Sharing brought it to 66-69 us.  Sweep at 4K, k = 5:
+// (M, waves, 64-px segments per wave row) = (2,4,1) 67 us, (3,4,1) 74, (2,8,1) 68, (1,8,1) 71,
+// (2,4,2) 66-77, (2,8,2) 72-88.)
+#ifndef RTPT_COMB_WAVES
+#define RTPT_COMB_WAVES 4
+#endif
+#ifndef RTPT_COMB_HALVES
+#define RTPT_COMB_HALVES 1
+#endif
+constexpr int kShWaves = RTPT_COMB_WAVES;    // waves (consecutive chunks) per block
+constexpr int kShHalves = RTPT_COMB_HALVES;  // 64-px segments per wave row: the 2k-column halo is paid once per 64*kShHalves px
+constexpr int kShThreads = 64 * kShWaves;
+
+template <int CWp, bool FINAL, bool EXACT>
+__global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int W = a.g.W, H = a.g.H, k = a.k;
-  constexpr int rows = kCombM + 2, cells = rows * CWp;
+  constexpr int rows = kShWaves * kCombM + 2, cells = rows * CWp;  // block-shared rows
   const int NP = static_cast<int>(a.n_tris) + 1;
   const int lane = static_cast<int>(threadIdx.x);
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   float* pairw = reinterpret_cast<float*>(lds_raw);  // [NP][NP]
   const int pair_bytes = (NP * NP * 4 + 15) & ~15;
-  unsigned char* mine = lds_raw + pair_bytes + wave * (cells * 20);
+  unsigned char* mine = lds_raw + pair_bytes;  // one region per block
   const float4* col = reinterpret_cast<const float4*>(mine);                // (r, g, b, depth)
   const uint32_t* ids = reinterpret_cast<const uint32_t*>(mine + 16 * cells);
   const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)mine));
   const uint32_t lds_col = lds0, lds_ids = lds0 + 16u * static_cast<uint32_t>(cells);
 
   // id-pair weight table -> LDS (plain loads; no DMA is in flight yet)
-  for (int i = wave * 64 + lane; i < NP * NP; i += kThreads) pairw[i] = a.pair_tab[i];
+  for (int i = wave * 64 + lane; i < NP * NP; i += kShThreads) pairw[i] = a.pair_tab[i];
   __syncthreads();
 
   // Work list.  A logical block = four CONSECUTIVE chunks (one per wave) of one residue and one
@@ -258,43 +274,52 @@ __global__ __launch_bounds__(kThreads) void k_atrous_comb(AtrousArgs a) {  // ta
       ++r;
     }
   }
-  const int chunk = cg_now * kBlockY + wave;
-  const int yc = a.g.y0 + chunk * (kCombM * k) + r_now;  // first output row of the comb
-  if (yc >= a.g.y1) continue;
-  const int x0 = bx_now * kBlockX;
-  int gx0 = x0 - k + lane, gx1 = x0 - k + 64 + lane;
-  gx0 = gx0 < 0 ? 0 : (gx0 > W - 1 ? W - 1 : gx0);  // :136
-  gx1 = gx1 < 0 ? 0 : (gx1 > W - 1 ? W - 1 : gx1);
-  const uint32_t o16a = static_cast<uint32_t>(gx0) * 16u, o4a = static_cast<uint32_t>(gx0) * 4u;
-  const uint32_t o16b = static_cast<uint32_t>(gx1) * 16u, o4b = static_cast<uint32_t>(gx1) * 4u;
-  // the previous comb's ds_reads have returned (their values were consumed); make that explicit
-  // before the DMA overwrites the cells
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int yg = a.g.y0 + cg_now * (kShWaves * kCombM * k) + r_now;  // first output row of the group
+  if (yg >= a.g.y1) continue;                                      // block-uniform
+  const int x0 = bx_now * (kBlockX * kShHalves);
+  uint32_t o16[kShHalves + 1], o4[kShHalves + 1];  // per-lane source offsets of the full chunks and the tail chunk
 #pragma unroll
-  for (int j = 0; j < rows; j++) {
-    int gy = yc + (j - 1) * k;
+  for (int hf = 0; hf <= kShHalves; hf++) {
+    int gx = x0 - k + hf * 64 + lane;
+    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);  // :136
+    o16[hf] = static_cast<uint32_t>(gx) * 16u;
+    o4[hf] = static_cast<uint32_t>(gx) * 4u;
+  }
+  // every wave is done reading the previous group's rows before anybody overwrites them
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // wave w stages rows w*M+1 .. w*M+M; wave 0 also row 0, the last wave also row 4M+1
+  const int j_lo = wave * kCombM + (wave == 0 ? 0 : 1);
+  const int j_hi = wave * kCombM + kCombM + (wave == kShWaves - 1 ? 1 : 0);
+  for (int j = j_lo; j <= j_hi; j++) {
+    int gy = yg + (j - 1) * k;
     gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);              // :136
     gy = gy < row_lo ? row_lo : (gy > row_hi ? row_hi : gy);  // rows only masked outputs could reach
     const size_t grow = static_cast<size_t>(gy - a.g.row_base) * W;  // wave-uniform
     const float4* rin = a.in + grow;
     const uint32_t* rvis = a.vis + grow;
     const uint32_t cj = static_cast<uint32_t>(j * CWp);
-    dma_b128(rin, o16a, lds_col + cj * 16u);
-    dma_b32(rvis, o4a, lds_ids + cj * 4u);
+#pragma unroll
+    for (int hf = 0; hf < kShHalves; hf++) {
+      dma_b128(rin, o16[hf], lds_col + (cj + 64u * hf) * 16u);
+      dma_b32(rvis, o4[hf], lds_ids + (cj + 64u * hf) * 4u);
+    }
     if (tail_lane) {
-      dma_b128(rin, o16b, lds_col + (cj + 64u) * 16u);
-      dma_b32(rvis, o4b, lds_ids + (cj + 64u) * 4u);
+      dma_b128(rin, o16[kShHalves], lds_col + (cj + 64u * kShHalves) * 16u);
+      dma_b32(rvis, o4[kShHalves], lds_ids + (cj + 64u * kShHalves) * 4u);
     }
   }
-  // only this wave reads these cells: its own vmcnt orders the DMA before the ds_reads below
+  // own DMA landed, then the barrier publishes every wave's rows to the block
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
-  const int x = x0 + lane;
 #pragma unroll
-  for (int m = 0; m < kCombM; m++) {
-    const int y = yc + m * k;
+  for (int mh = 0; mh < kCombM * kShHalves; mh++) {
+    const int m = mh / kShHalves, hf = mh % kShHalves;
+    const int x = x0 + hf * 64 + lane;
+    const int y = yg + (wave * kCombM + m) * k;
     if (x >= W || y >= a.g.y1) continue;
-    const int cc = (m + 1) * CWp + lane + k;
+    const int cc = (wave * kCombM + m + 1) * CWp + hf * 64 + lane + k;
     const float4 cp4 = col[cc];
     const f3 cp = xyz(cp4);
     const float dp = cp4.w;
@@ -404,10 +429,11 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
   dim3 block(kBlockX, kBlockY);
   const int np = static_cast<int>(a.n_tris) + 1;
   if (!a.direct && a.pair_tab && np <= kPairMax && a.k >= 1 && a.k <= 16) {
-    a.tiles_x = (a.g.W + kBlockX - 1) / kBlockX;
+    const int seg_w = kBlockX * kShHalves;
+    a.tiles_x = (a.g.W + seg_w - 1) / seg_w;
     const int nrows = a.g.y1 - a.g.y0;
     const int chunks = (nrows + kCombM * a.k - 1) / (kCombM * a.k);
-    a.tiles_y = (chunks + kBlockY - 1) / kBlockY;         // chunk groups (4 consecutive chunks per block)
+    a.tiles_y = (chunks + kShWaves - 1) / kShWaves;  // chunk groups (kShWaves consecutive chunks per block)
     static int n_cu = 0;
     if (!n_cu) {
       hipDeviceProp_t prop;
@@ -416,38 +442,46 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
       n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     const uint32_t nlb = static_cast<uint32_t>(a.tiles_x) * static_cast<uint32_t>(a.tiles_y) * static_cast<uint32_t>(a.k);
-    // persistent grid: as many blocks per CU as 160 KiB of LDS admits (5 at M = 2, k <= 8)
-    const size_t lds_block = static_cast<size_t>((np * np * 4 + 15) & ~15) +
-                             static_cast<size_t>(kBlockY) * (kCombM + 2) * (a.k <= 4 ? 72 : (a.k <= 8 ? 80 : 96)) * 20;
-    uint32_t per_cu = static_cast<uint32_t>((160u * 1024u) / lds_block);
-    if (per_cu > 8u) per_cu = 8u;
+    // staged row stride (cells): segment + 2k, rounded to the template instances
+    const int need = seg_w + 2 * a.k;
+    const int base_w = seg_w;
+    const int cw = need <= base_w + 8 ? base_w + 8 : (need <= base_w + 16 ? base_w + 16 : base_w + 32);
+    const size_t lds = static_cast<size_t>((np * np * 4 + 15) & ~15) + static_cast<size_t>(kShWaves * kCombM + 2) * cw * 20;
+    // persistent grid: as many blocks per CU as 160 KiB of LDS and 32 waves admit
+    uint32_t per_cu = static_cast<uint32_t>((160u * 1024u) / lds);
+    if (per_cu > 32u / kShWaves) per_cu = 32u / kShWaves;
     if (per_cu < 1u) per_cu = 1u;
     uint32_t per_xcd = static_cast<uint32_t>((n_cu + 7) / 8) * per_cu;
     if (per_xcd > (nlb + 7) / 8) per_xcd = (nlb + 7) / 8;
-    dim3 grid(per_xcd * 8u);
-    // staged row stride: 72 cells for k <= 4, 80 for k <= 8, 96 for k <= 16
-#define RTPT_LAUNCH_COMB(CW)                                                                         \
-  do {                                                                                               \
-    const size_t lds = static_cast<size_t>((np * np * 4 + 15) & ~15) +                               \
-                       static_cast<size_t>(kBlockY) * (kCombM + 2) * (CW) * 20;                      \
-    if (a.exact) {                                                                                   \
-      if (final_pass)                                                                                \
-        hipLaunchKernelGGL((k_atrous_comb<CW, true, true>), grid, block, lds, s, a);                 \
-      else                                                                                           \
-        hipLaunchKernelGGL((k_atrous_comb<CW, false, true>), grid, block, lds, s, a);                \
-    } else {                                                                                         \
-      if (final_pass)                                                                                \
-        hipLaunchKernelGGL((k_atrous_comb<CW, true, false>), grid, block, lds, s, a);                \
-      else                                                                                           \
-        hipLaunchKernelGGL((k_atrous_comb<CW, false, false>), grid, block, lds, s, a);               \
-    }                                                                                                \
+    dim3 grid(per_xcd * 8u), sblock(kBlockX, kShWaves);
+#define RTPT_LAUNCH_COMB(CW)                                                                          \
+  do {                                                                                                \
+    static bool attr = false; /* one per instantiated stride */                                       \
+    if (!attr) {                                                                                      \
+      attr = true;                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    }                                                                                                 \
+    if (a.exact) {                                                                                    \
+      if (final_pass)                                                                                 \
+        hipLaunchKernelGGL((k_atrous_comb_sh<CW, true, true>), grid, sblock, lds, s, a);              \
+      else                                                                                            \
+        hipLaunchKernelGGL((k_atrous_comb_sh<CW, false, true>), grid, sblock, lds, s, a);             \
+    } else {                                                                                          \
+      if (final_pass)                                                                                 \
+        hipLaunchKernelGGL((k_atrous_comb_sh<CW, true, false>), grid, sblock, lds, s, a);             \
+      else                                                                                            \
+        hipLaunchKernelGGL((k_atrous_comb_sh<CW, false, false>), grid, sblock, lds, s, a);            \
+    }                                                                                                 \
   } while (0)
-    if (a.k <= 4)
-      RTPT_LAUNCH_COMB(72);
-    else if (a.k <= 8)
-      RTPT_LAUNCH_COMB(80);
+    if (cw == base_w + 8)
+      RTPT_LAUNCH_COMB(kBlockX * kShHalves + 8);
+    else if (cw == base_w + 16)
+      RTPT_LAUNCH_COMB(kBlockX * kShHalves + 16);
     else
-      RTPT_LAUNCH_COMB(96);
+      RTPT_LAUNCH_COMB(kBlockX * kShHalves + 32);
 #undef RTPT_LAUNCH_COMB
     return;
   }
