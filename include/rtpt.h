@@ -93,9 +93,8 @@ typedef struct rtpt_visibility_data {
 #define RTPT_FLAG_DIRECT_FILTER 0x4u /* a-trous taps by direct global loads instead of the LDS-staged
                                        tile kernel (the fallback for strides whose halo exceeds LDS) */
 
-#define RTPT_FLAG_REGEN_PATHS 0x8u   /* path tracer: per-wave path regeneration (lanes whose path ended
-                                       take the next pixel) instead of one pixel per lane;
-                                       chosen automatically when max_segments >= 16 */
+#define RTPT_FLAG_NO_PATH_COMPACTION 0x8u /* path tracer: keep one pixel per lane for the whole path instead of
+                                            compacting the surviving paths of a tile after every segment */
 
 typedef struct rtpt_config {
   uint32_t struct_size;          /* = sizeof(rtpt_config), ABI guard */

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(PKG_DIR, "librtpt_hip.so")
 HEADER_PATH = os.path.join(REPO_DIR, "include", "rtpt.h")
 
 RTPT_OK, RTPT_E_INVALID, RTPT_E_NOMEM, RTPT_E_DEVICE, RTPT_E_NO_SCENE, RTPT_E_NO_GPU = 0, -1, -2, -3, -4, -5
-FLAG_EXACT_FILTER, FLAG_FORCE_BVH, FLAG_DIRECT_FILTER, FLAG_REGEN_PATHS = 0x1, 0x2, 0x4, 0x8
+FLAG_EXACT_FILTER, FLAG_FORCE_BVH, FLAG_DIRECT_FILTER, FLAG_NO_PATH_COMPACTION = 0x1, 0x2, 0x4, 0x8
 DEBUG_HIT_ID, DEBUG_PREV_PIXEL = 0x1, 0x2
 
 # rtpt_plane

@@ -634,11 +634,9 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   a.raycount = static_cast<unsigned long long*>(c->raycount.ptr);
   a.count_y0 = c->count_y0;
   a.count_y1 = c->count_y1;
-  // measured at 4K on the Cornell box: tile kernel 0.77 / 1.32 / 4.14 ms vs regeneration 1.10 / 1.60 / 2.54 ms
-  // at 4 / 8 / 32 segments
-  a.regen = ((c->cfg.flags & RTPT_FLAG_REGEN_PATHS) || c->cfg.max_segments >= 16) ? 1 : 0;
+  a.compact = (c->cfg.flags & RTPT_FLAG_NO_PATH_COMPACTION) ? 0 : 1;
   a.cull = 0;
-  if (!a.regen && !c->use_bvh && c->width_fits_i16()) {
+  if (!c->use_bvh && c->width_fits_i16()) {
     // K2 camera (raytrace.comp.glsl:314-320): at cameraPos, looking down -z, d = (slope*ux, slope*uy, -1) with
     // ux = (2cx - W)/H, uy = -(2cy - H)/H.  The Gaussian jitter is 0.375 * sqrt(-2 ln u1) <= 0.375 * 13.3 px
     // (u1 >= 1e-38, :87).

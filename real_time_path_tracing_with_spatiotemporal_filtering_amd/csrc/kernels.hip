@@ -344,214 +344,175 @@ __device__ __forceinline__ f3 sky_color(f3 d) {  // raytrace.comp.glsl:95-107
   return f3{0.03f, 0.03f, 0.03f};
 }
 
-// One pixel per lane, 64x4 tiles (the shipping kernel for short paths: at 4 segments the Cornell box
-// averages 2.25 queries per pixel and most waves retire early — light hit and sky end whole waves —
-// so regeneration does not pay, see below).
-template <bool BVH>
+// K2 tile kernel with optional per-segment compaction (PathtraceArgs::compact).
+//
+// A 256-thread block owns a 64x4 pixel tile and advances all of its paths one segment at a time
+// (the segment index is block-uniform).  The PRIMARY segment runs with the lane <-> pixel mapping
+// intact, so a wave's rays are coherent and only the triangles whose screen bounds meet the wave's
+// span are tested.  After every segment the surviving paths (light hit, sky and the segment budget
+// end paths; at 4 segments the Cornell box averages 2.25 queries per pixel) are compacted to the
+// front of the block through LDS, so secondary segments — incoherent anyway — run in full waves and
+// emptied waves skip the segment entirely: 16 wave-segments per tile become ~10.  A path's RNG stream
+// depends only on (x, y, frame, batch) (raytrace.comp.glsl:297) and every path runs the reference's
+// loop body unchanged, so the image is independent of the schedule (bit-exact parity with the oracle).
+// Measured in one process at 4K on the Cornell box (us, 4 / 8 / 32 segments): without compaction
+// 503 / 985 / 3410, with 495 / 925 / 2810 — at 4 segments most waves retire early anyway (sky and the
+// unoccluded light end whole waves), the gain grows with the path length.  (A per-wave path
+// regeneration scheme — finished lanes pick up new pixels — was also built and measured: it mixes
+// primary and secondary rays in every wave, loses the coherent, culled primary segment and ran
+// 1.5x slower at 4 segments; it is not kept.)
+struct PathState {  // SoA in LDS, one slot per thread
+  uint32_t pix[kThreads];   // local pixel index (ty*64 + tx)
+  uint32_t rng[kThreads];
+  float ox[kThreads], oy[kThreads], oz[kThreads];
+  float dx[kThreads], dy[kThreads], dz[kThreads];
+  float ar[kThreads], ag[kThreads], ab[kThreads];
+};
+
+template <bool BVH, bool COMPACT>
 __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
   __shared__ uint32_t stack[BVH ? kBvhMaxDepth * kThreads : 1];
+  __shared__ PathState st;
+  __shared__ float sum_r[kThreads], sum_g[kThreads], sum_b[kThreads];  // per pixel, only used when spp > 1
+  __shared__ uint32_t rng_pix[kThreads];                                // per pixel RNG state between samples
+  __shared__ uint32_t wave_cnt[kBlockY];
   __shared__ unsigned int block_rays;
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const uint32_t lane = threadIdx.x;
   if (tid == 0) block_rays = 0;
-  __syncthreads();
-  const int x = blockIdx.x * kBlockX + threadIdx.x;
-  const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
-  const bool active = (x < a.g.W) && (y < a.g.y1);
+  const int tile_x0 = blockIdx.x * kBlockX, tile_y0 = a.g.y0 + blockIdx.y * kBlockY;
+  const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
+  const f3 light_c = ld3(a.light_c);
   unsigned int rays = 0;
-  unsigned long long cand = 0;  // candidates of this wave's (jittered) primary rays
-  if (!BVH && a.cull)
-    cand = span_candidates(a.bounds, a.scene.n_tris, static_cast<int>(blockIdx.x) * kBlockX, __builtin_amdgcn_readfirstlane(y));
-  if (active) {
-    uint32_t rng = exact::rng_seed(static_cast<uint32_t>(x), static_cast<uint32_t>(y), a.frame, a.batch);
-    const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
-    const f3 light_c = ld3(a.light_c);
-    f3 sum{0.f, 0.f, 0.f};
-    uint32_t first_id = 0;
-    for (uint32_t smp = 0; smp < a.spp; smp++) {
-      // raytrace.comp.glsl:84-92 Box-Muller jitter
-      float u1 = glsl_max(1e-38f, exact::rng_next(rng));
+  unsigned long long cand = 0;  // candidate triangles of this wave's (jittered) primary rays
+  if (!BVH && a.cull) cand = span_candidates(a.bounds, a.scene.n_tris, tile_x0, tile_y0 + wave);
+
+  // per-thread path registers
+  uint32_t pix = static_cast<uint32_t>(tid), rng = 0;
+  f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, -1.f}, acc{1.f, 1.f, 1.f};
+  {
+    const int x = tile_x0 + static_cast<int>(lane), y = tile_y0 + wave;
+    rng = exact::rng_seed(static_cast<uint32_t>(x), static_cast<uint32_t>(y), a.frame, a.batch);  // :297
+    sum_r[tid] = sum_g[tid] = sum_b[tid] = 0.0f;
+  }
+  for (uint32_t smp = 0; smp < a.spp; smp++) {
+    // ---- primary rays: thread tid <-> pixel tid (mapping restored at the start of every sample)
+    if (smp > 0) {
+      __syncthreads();
+      pix = static_cast<uint32_t>(tid);
+      rng = rng_pix[tid];  // the pixel's RNG state after its previous sample (stored at path end)
+    }
+    const int px0 = tile_x0 + static_cast<int>(lane), py0 = tile_y0 + wave;
+    bool alive = (px0 < a.g.W) && (py0 < a.g.y1);
+    if (alive) {
+      float u1 = glsl_max(1e-38f, exact::rng_next(rng));  // :87 Box-Muller
       float u2 = exact::rng_next(rng);
       float rad = exact::sqrt_(-2.0f * exact::log_(u1));
       float sn, cs;
       exact::sincos2pi(u2, sn, cs);
-      float cx = fmaf_(a.jitter, rad * cs, static_cast<float>(x) + 0.5f);  // :314
-      float cy = fmaf_(a.jitter, rad * sn, static_cast<float>(y) + 0.5f);
+      float cx = fmaf_(a.jitter, rad * cs, static_cast<float>(px0) + 0.5f);  // :314
+      float cy = fmaf_(a.jitter, rad * sn, static_cast<float>(py0) + 0.5f);
       float ux = fmaf_(2.0f, cx, -fw) / fh;     // :315
       float uy = -(fmaf_(2.0f, cy, -fh) / fh);  // :316
-      f3 d = exact::normalize(f3{a.slope * ux, a.slope * uy, -1.0f});  // :319-320
-      f3 o = ld3(a.cam);
-      f3 acc{1.f, 1.f, 1.f};
-      for (uint32_t seg = 0; seg < a.max_segments; seg++) {  // :204
+      d = exact::normalize(f3{a.slope * ux, a.slope * uy, -1.0f});  // :319-320
+      o = ld3(a.cam);
+      acc = f3{1.f, 1.f, 1.f};  // :201
+    }
+    for (uint32_t seg = 0; seg < a.max_segments; seg++) {  // :204 (block-uniform)
+      if (alive) {
         HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
-        if (!BVH && a.cull && seg == 0) {
-          // the jittered primary rays of this wave stay inside the padded bounds (see api.hip)
+        if (!BVH && a.cull && seg == 0)
           closest_hit_brute_set(a.scene, cand, o, d, h);
-        } else {
+        else
           closest_hit<BVH>(a.scene, o, d, h, stack, tid);  // :208-222
-        }
-        rays++;
-        if (seg == 0 && smp == 0) first_id = h.id1;
+        const int x = tile_x0 + static_cast<int>(pix & 63u), y = tile_y0 + static_cast<int>(pix >> 6);
+        if (y >= a.count_y0 && y < a.count_y1) rays++;
+        const size_t gi = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
+        if (seg == 0 && smp == 0 && a.hit_id) a.hit_id[gi] = h.id1;
+        bool done;
         if (ray_hits_light(o, d, light_c, a.light_r2)) {  // :226
           acc = acc * (seg == 0 ? ld3(a.light_col_first) : ld3(a.light_col));  // :229,:233
-          break;
-        }
-        if (h.id1 == 0) {
+          done = true;
+        } else if (h.id1 == 0) {
           acc = acc * sky_color(d);  // :266
-          break;
-        }
-        const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
-        float4 s0 = s[0], s1 = s[1], s2 = s[2];
-        float b1 = h.u / h.ad, b2 = h.v / h.ad;
-        float b0 = 1.0f - b1 - b2;                                       // :134
-        f3 pos = bary_point(xyz(s0), xyz(s1), xyz(s2), b0, b1, b2);      // :137
-        f3 n{s0.w, s1.w, s2.w};                                          // :150 (precomputed per triangle)
-        f3 alb = (n.x > 0.99f) ? f3{1.f, 0.f, 0.f} : ((-n.x > 0.99f) ? f3{0.f, 1.f, 0.f} : f3{0.7f, 0.7f, 0.7f});  // :155-163
-        acc = acc * alb;                                                 // :244
-        if (!(exact::dot(n, d) < 0.0f)) n = -n;                          // :247 faceforward
-        o = f3{fmaf_(a.ray_offset, n.x, pos.x), fmaf_(a.ray_offset, n.y, pos.y), fmaf_(a.ray_offset, n.z, pos.z)};  // :250
-        float st, ct;
-        exact::sincos2pi(exact::rng_next(rng), st, ct);                  // :256
-        float u = fmaf_(2.0f, exact::rng_next(rng), -1.0f);              // :257
-        float r = exact::sqrt_(fmaf_(-u, u, 1.0f));                      // :258
-        d = exact::normalize(f3{fmaf_(r, ct, n.x), fmaf_(r, st, n.y), n.z + u});  // :259-261
-      }
-      sum = sum + acc;  // :325
-    }
-    const float ns = static_cast<float>(a.spp);
-    const size_t i = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
-    // :328,:343 — the reference's alpha is 0; here it carries the G-buffer depth for the filter (rgbd)
-    a.image[i] = make_float4(sum.x / ns, sum.y / ns, sum.z / ns, a.depth[i]);
-    if (a.hit_id) a.hit_id[i] = first_id;
-  }
-  // "ray" = one closest-hit query; one 64-bit atomic per block
-  if (y < a.count_y0 || y >= a.count_y1) rays = 0;
-  for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
-  if ((tid & 63) == 0 && rays) atomicAdd(&block_rays, rays);
-  __syncthreads();
-  if (tid == 0 && block_rays) atomicAdd(a.raycount, static_cast<unsigned long long>(block_rays));
-}
-
-// Path regeneration.  Paths end after 1..max_segments closest-hit queries (light, sky, budget), and with
-// one pixel per lane a wave runs until its longest path ends: at 4 segments and ~2.25 queries per pixel
-// 44 % of the lane slots idle.  Here a wave owns kRegenPixels consecutive pixels and keeps its 64 lanes
-// full: every iteration of the wave loop is ONE segment for every live lane, and lanes whose path just
-// ended pick up the next pixel of the wave's range (ballot + prefix count, no atomics, no LDS).  The
-// result is schedule-independent: a path's RNG stream depends only on (x, y, frame, batch)
-// (raytrace.comp.glsl:297) and each lane runs the reference's loop body unchanged.
-// Measured (profiles/): at max_segments = 4 it executes MORE instructions than the tile kernel (527M vs
-// 476M VALU at 4K: every iteration mixes primary and secondary rays, so all 32 triangles take the
-// slow accept path, while the tile kernel's primary segment is coherent) and is 1.5x slower; it is
-// selected only for long paths (PathtraceArgs::regen).
-constexpr uint32_t kRegenPixels = 1024;
-
-template <bool BVH>
-__global__ __launch_bounds__(kThreads) void k_pathtrace_regen(PathtraceArgs a) {
-  __shared__ uint32_t stack[BVH ? kBvhMaxDepth * kThreads : 1];
-  __shared__ unsigned int block_rays;
-  const int tid = threadIdx.y * kBlockX + threadIdx.x;
-  if (tid == 0) block_rays = 0;
-  __syncthreads();
-  const uint32_t W = static_cast<uint32_t>(a.g.W);
-  const uint32_t P = W * static_cast<uint32_t>(a.g.y1 - a.g.y0);
-  const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * kBlockY + threadIdx.y);
-  uint32_t cursor = gw * kRegenPixels;  // wave-uniform
-  const uint32_t end = (cursor + kRegenPixels < P) ? cursor + kRegenPixels : P;
-  const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
-  const f3 light_c = ld3(a.light_c);
-
-  bool alive = false;
-  int x = 0, y = 0;
-  uint32_t rng = 0, seg = 0, smp = 0, first_id = 0;
-  f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, -1.f}, acc{1.f, 1.f, 1.f}, sum{0.f, 0.f, 0.f};
-  unsigned int rays = 0;
-
-  // raytrace.comp.glsl:309-320: jittered primary ray of the next sample
-  auto start_sample = [&]() {
-    float u1 = glsl_max(1e-38f, exact::rng_next(rng));  // :87 Box-Muller
-    float u2 = exact::rng_next(rng);
-    float rad = exact::sqrt_(-2.0f * exact::log_(u1));
-    float sn, cs;
-    exact::sincos2pi(u2, sn, cs);
-    float cx = fmaf_(a.jitter, rad * cs, static_cast<float>(x) + 0.5f);  // :314
-    float cy = fmaf_(a.jitter, rad * sn, static_cast<float>(y) + 0.5f);
-    float ux = fmaf_(2.0f, cx, -fw) / fh;     // :315
-    float uy = -(fmaf_(2.0f, cy, -fh) / fh);  // :316
-    d = exact::normalize(f3{a.slope * ux, a.slope * uy, -1.0f});  // :319-320
-    o = ld3(a.cam);
-    acc = f3{1.f, 1.f, 1.f};  // :201
-    seg = 0;
-  };
-
-  while (true) {
-    // ---- regenerate: dead lanes take the next pixels of this wave's range
-    const unsigned long long dead = __ballot(!alive);
-    if (dead != 0ull && cursor < end) {
-      const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dead >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dead), 0u));
-      if (!alive) {
-        const uint32_t p = cursor + rank;
-        if (p < end) {
-          const uint32_t row = p / W;
-          y = a.g.y0 + static_cast<int>(row);
-          x = static_cast<int>(p - row * W);
-          rng = exact::rng_seed(static_cast<uint32_t>(x), static_cast<uint32_t>(y), a.frame, a.batch);  // :297
-          sum = f3{0.f, 0.f, 0.f};
-          smp = 0;
-          first_id = 0;
-          start_sample();
-          alive = true;
-        }
-      }
-      const uint32_t n_dead = static_cast<uint32_t>(__builtin_popcountll(dead));
-      cursor = (cursor + n_dead < end) ? cursor + n_dead : end;
-    }
-    if (__ballot(alive) == 0ull) break;  // range exhausted and every path finished
-    if (alive) {
-      // ---- one iteration of the segment loop, raytrace.comp.glsl:204-269
-      HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
-      closest_hit<BVH>(a.scene, o, d, h, stack, tid);  // :208-222
-      if (y >= a.count_y0 && y < a.count_y1) rays++;
-      if (seg == 0 && smp == 0) first_id = h.id1;
-      bool path_done;
-      if (ray_hits_light(o, d, light_c, a.light_r2)) {  // :226
-        acc = acc * (seg == 0 ? ld3(a.light_col_first) : ld3(a.light_col));  // :229,:233
-        path_done = true;
-      } else if (h.id1 == 0) {
-        acc = acc * sky_color(d);  // :266
-        path_done = true;
-      } else {
-        const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
-        float4 s0 = s[0], s1 = s[1], s2 = s[2];
-        float b1 = h.u / h.ad, b2 = h.v / h.ad;
-        float b0 = 1.0f - b1 - b2;                                       // :134
-        f3 pos = bary_point(xyz(s0), xyz(s1), xyz(s2), b0, b1, b2);      // :137
-        f3 n{s0.w, s1.w, s2.w};                                          // :150 (precomputed per triangle)
-        f3 alb = (n.x > 0.99f) ? f3{1.f, 0.f, 0.f} : ((-n.x > 0.99f) ? f3{0.f, 1.f, 0.f} : f3{0.7f, 0.7f, 0.7f});  // :155-163
-        acc = acc * alb;                                                 // :244
-        if (!(exact::dot(n, d) < 0.0f)) n = -n;                          // :247 faceforward
-        o = f3{fmaf_(a.ray_offset, n.x, pos.x), fmaf_(a.ray_offset, n.y, pos.y), fmaf_(a.ray_offset, n.z, pos.z)};  // :250
-        float st, ct;
-        exact::sincos2pi(exact::rng_next(rng), st, ct);                  // :256
-        float u = fmaf_(2.0f, exact::rng_next(rng), -1.0f);              // :257
-        float r = exact::sqrt_(fmaf_(-u, u, 1.0f));                      // :258
-        d = exact::normalize(f3{fmaf_(r, ct, n.x), fmaf_(r, st, n.y), n.z + u});  // :259-261
-        seg++;
-        path_done = (seg >= a.max_segments);  // :204 — a path that exhausts its budget returns its throughput (:270)
-      }
-      if (path_done) {
-        sum = sum + acc;  // :325
-        smp++;
-        if (smp < a.spp) {
-          start_sample();
+          done = true;
         } else {
-          const float ns = static_cast<float>(a.spp);
-          const size_t i = static_cast<size_t>(y - a.g.row_base) * W + static_cast<uint32_t>(x);
-          // :328,:343 — the reference's alpha is 0; here it carries the G-buffer depth for the filter (rgbd)
-          a.image[i] = make_float4(sum.x / ns, sum.y / ns, sum.z / ns, a.depth[i]);
-          if (a.hit_id) a.hit_id[i] = first_id;
+          const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
+          float4 s0 = s[0], s1 = s[1], s2 = s[2];
+          float b1 = h.u / h.ad, b2 = h.v / h.ad;
+          float b0 = 1.0f - b1 - b2;                                       // :134
+          f3 pos = bary_point(xyz(s0), xyz(s1), xyz(s2), b0, b1, b2);      // :137
+          f3 n{s0.w, s1.w, s2.w};                                          // :150 (precomputed per triangle)
+          f3 alb = (n.x > 0.99f) ? f3{1.f, 0.f, 0.f} : ((-n.x > 0.99f) ? f3{0.f, 1.f, 0.f} : f3{0.7f, 0.7f, 0.7f});  // :155-163
+          acc = acc * alb;                                                 // :244
+          if (!(exact::dot(n, d) < 0.0f)) n = -n;                          // :247 faceforward
+          o = f3{fmaf_(a.ray_offset, n.x, pos.x), fmaf_(a.ray_offset, n.y, pos.y), fmaf_(a.ray_offset, n.z, pos.z)};  // :250
+          float st_, ct;
+          exact::sincos2pi(exact::rng_next(rng), st_, ct);                 // :256
+          float u = fmaf_(2.0f, exact::rng_next(rng), -1.0f);              // :257
+          float r = exact::sqrt_(fmaf_(-u, u, 1.0f));                      // :258
+          d = exact::normalize(f3{fmaf_(r, ct, n.x), fmaf_(r, st_, n.y), n.z + u});  // :259-261
+          done = (seg + 1 >= a.max_segments);  // budget exhausted: the path returns its throughput (:270)
+        }
+        if (done) {
           alive = false;
+          if (a.spp == 1) {
+            // :328,:343 — alpha carries the G-buffer depth for the filter (rgbd)
+            a.image[gi] = make_float4(acc.x, acc.y, acc.z, a.depth[gi]);
+          } else {
+            sum_r[pix] += acc.x;  // :325 (one path per pixel at a time: no race)
+            sum_g[pix] += acc.y;
+            sum_b[pix] += acc.z;
+            rng_pix[pix] = rng;  // :307 the next sample of this pixel continues the same stream
+          }
         }
       }
+      if (seg + 1 >= a.max_segments) break;
+      if (!COMPACT) {  // short paths: keep the lane <-> pixel mapping, a wave leaves when all its paths ended
+        if (__ballot(alive) == 0ull) break;
+        continue;
+      }
+      // ---- compact the survivors to the front of the block
+      const unsigned long long live = __ballot(alive);
+      if (lane == 0) wave_cnt[wave] = static_cast<uint32_t>(__builtin_popcountll(live));
+      __syncthreads();
+      uint32_t base = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < kBlockY; w++) {
+        const uint32_t c = wave_cnt[w];
+        if (w < wave) base += c;
+        total += c;
+      }
+      if (total == 0) break;  // block-uniform
+      if (alive) {
+        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
+        st.pix[slot] = pix;
+        st.rng[slot] = rng;
+        st.ox[slot] = o.x; st.oy[slot] = o.y; st.oz[slot] = o.z;
+        st.dx[slot] = d.x; st.dy[slot] = d.y; st.dz[slot] = d.z;
+        st.ar[slot] = acc.x; st.ag[slot] = acc.y; st.ab[slot] = acc.z;
+      }
+      __syncthreads();
+      alive = static_cast<uint32_t>(tid) < total;
+      if (alive) {
+        pix = st.pix[tid];
+        rng = st.rng[tid];
+        o = f3{st.ox[tid], st.oy[tid], st.oz[tid]};
+        d = f3{st.dx[tid], st.dy[tid], st.dz[tid]};
+        acc = f3{st.ar[tid], st.ag[tid], st.ab[tid]};
+      }
+      __syncthreads();  // everybody has read its slot before the next compaction writes
+    }
+  }
+  __syncthreads();
+  if (a.spp > 1) {
+    const int x = tile_x0 + static_cast<int>(lane), y = tile_y0 + wave;
+    if (x < a.g.W && y < a.g.y1) {
+      const float ns = static_cast<float>(a.spp);
+      const size_t gi = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
+      a.image[gi] = make_float4(sum_r[tid] / ns, sum_g[tid] / ns, sum_b[tid] / ns, a.depth[gi]);  // :328,:343
     }
   }
   // "ray" = one closest-hit query; one 64-bit atomic per block
@@ -621,19 +582,17 @@ void launch_gradient(const GradientArgs& a, hipStream_t s) {
 }
 void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;
-  const uint64_t px = static_cast<uint64_t>(a.g.W) * static_cast<uint64_t>(a.g.y1 - a.g.y0);
-  const uint64_t waves = (px + kRegenPixels - 1) / kRegenPixels;
-  dim3 grid(static_cast<uint32_t>((waves + kBlockY - 1) / kBlockY)), block(kBlockX, kBlockY);
-  if (a.regen) {
+  dim3 block(kBlockX, kBlockY);
+  if (a.compact) {
     if (a.scene.use_bvh)
-      hipLaunchKernelGGL(k_pathtrace_regen<true>, grid, block, 0, s, a);
+      hipLaunchKernelGGL((k_pathtrace<true, true>), grid_for(a.g), block, 0, s, a);
     else
-      hipLaunchKernelGGL(k_pathtrace_regen<false>, grid, block, 0, s, a);
+      hipLaunchKernelGGL((k_pathtrace<false, true>), grid_for(a.g), block, 0, s, a);
   } else {
     if (a.scene.use_bvh)
-      hipLaunchKernelGGL(k_pathtrace<true>, grid_for(a.g), block, 0, s, a);
+      hipLaunchKernelGGL((k_pathtrace<true, false>), grid_for(a.g), block, 0, s, a);
     else
-      hipLaunchKernelGGL(k_pathtrace<false>, grid_for(a.g), block, 0, s, a);
+      hipLaunchKernelGGL((k_pathtrace<false, false>), grid_for(a.g), block, 0, s, a);
   }
 }
 void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s) {

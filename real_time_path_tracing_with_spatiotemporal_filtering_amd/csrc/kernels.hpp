@@ -88,8 +88,8 @@ struct PathtraceArgs {
   uint32_t* hit_id;  // nullable
   unsigned long long* raycount;
   int32_t count_y0, count_y1;  // rows whose queries are counted
-  int32_t regen;               // 1: path-regeneration kernel (long paths)
-  int32_t cull;                // 1: bounds[] is valid for the primary segment (tile kernel only)
+  int32_t compact;             // 1: compact surviving paths to the front of the block after every segment
+  int32_t cull;                // 1: bounds[] is valid for the primary segment
   TriBounds bounds[kCullMaxTris];
 };
 

@@ -99,7 +99,7 @@ def test_closest_hit_ids_bit_exact(hip_lib, oracle, cornell, flags):
 
 
 # ------------------------------------------------------------------------------ per pass, frames 0..2
-@pytest.mark.parametrize("flags", [0, 2, 8, 10])  # brute force / BVH / path regeneration / both
+@pytest.mark.parametrize("flags", [0, 2, 8, 10])  # brute force / BVH / no path compaction / both
 def test_frame_sequence_parity(hip_lib, oracle, cornell, flags):
     """frames 0-1 static, light.x -0.1 on frame 2 (SURVEY 8d config 1 script), camera x +0.1 on 3, z +0.1 on 4"""
     app, ref = make_pair(hip_lib, oracle, cornell, flags=flags)
