@@ -67,15 +67,18 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
         app.drawScene()
     fence()
     ctx.reset_counters()
-    ctx.timing_enable(collect_kernels)
+    # per-kernel HIP events on the launch stream, sampled: bracketing every launch costs ~6 % of the frame
+    timing_period = 8 if steps >= 32 else 1
+    ctx.timing_enable(timing_period if collect_kernels else 0)
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         app.drawScene()
     fence()
     elapsed = time.perf_counter() - t0
-    ctx.timing_enable(False)
+    ctx.timing_enable(0)
     kern = ctx.timing_collect() if collect_kernels else {}
+    timed_frames = max(1, len([f for f in range(steps) if f % timing_period == 0])) if collect_kernels else steps
     rays = ctx.raycount()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -86,12 +89,13 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
         rays = int(r.item())
     plan = app.plan
     app.backend.close()
-    return elapsed, rays, kern, plan
+    return elapsed, rays, kern, plan, timed_frames
 
 
 def kernel_report(kern, wl, plan, steps):
     """per-kernel average launch duration (HIP events on the launch stream) and algorithmic GB/s"""
     W = wl["width"]
+    steps = max(1, kern.get("k_pathtrace", (0.0, steps))[1])  # sampled frames = launches of the once-per-frame kernel
     rows = {
         "k_gbuffer": plan.gbuffer_rows(), "k_gradient": plan.gradient_rows(), "k_pathtrace": plan.raytrace_rows(),
         "k_atrous_final": plan.filter_rows(wl["iterations"]),
@@ -214,11 +218,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
-    elapsed, rays, kern, plan = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist)
+    elapsed, rays, kern, plan, timed_frames = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist)
     ms_per_step = elapsed / args.steps * 1e3
     result = None
     if rank == 0:
-        kr = kernel_report(kern, wl, plan, args.steps)
+        kr = kernel_report(kern, wl, plan, timed_frames)
         at = kr.get("k_atrous", {})
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -257,8 +261,8 @@ def main():
             result["pathtrace_kernel_mray_s"] = round(rays / args.steps / (pt["avg_us"] * 1e-6) / 1e6, 1)
 
     if world == 1 and rank == 0 and not args.no_secondary and args.workload == "4k":
-        e2, r2, k2, p2 = run_gpu(WORKLOADS["1080p"], args, 0, 1, args.steps, args.warmup, torch, None)
-        kr2 = kernel_report(k2, WORKLOADS["1080p"], p2, args.steps)
+        e2, r2, k2, p2, tf2 = run_gpu(WORKLOADS["1080p"], args, 0, 1, args.steps, args.warmup, torch, None)
+        kr2 = kernel_report(k2, WORKLOADS["1080p"], p2, tf2)
         result["also"] = {"cornell-1080p-1spp-4seg-5atrous": {
             "value": round(r2 / e2 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
             "atrous_GBps": kr2.get("k_atrous", {}).get("algorithmic_GBps"),

@@ -295,8 +295,9 @@ class Context:
         return int(self.readback(PLANE_RAYCOUNT)[0])
 
     # -- timing
-    def timing_enable(self, on: bool):
-        _check(self._lib.rtpt_timing_enable(self._h, 1 if on else 0))
+    def timing_enable(self, period):
+        """0/False off; n: bracket the kernels of every n-th frame with HIP events (True == 1)."""
+        _check(self._lib.rtpt_timing_enable(self._h, int(period)))
 
     def timing_collect(self):
         ms = (C.c_double * K_COUNT)()

@@ -81,7 +81,9 @@ struct rtpt_ctx {
   int count_y0 = 0, count_y1 = 0;  // rows counted into RAYCOUNT
 
   // timing
-  bool timing = false;
+  int timing_period = 0;          // 0 off, n: kernels of every n-th frame are bracketed by events
+  uint64_t frames_ended = 0;
+  bool timing_now() const { return timing_period > 0 && (frames_ended % static_cast<uint64_t>(timing_period)) == 0; }
   std::vector<TimedLaunch> timed;
   std::vector<hipEvent_t> event_pool;
 
@@ -153,7 +155,7 @@ struct Timer {
   rtpt_ctx* c;
   bool on;
   TimedLaunch t;
-  Timer(rtpt_ctx* ctx, int kernel) : c(ctx), on(ctx->timing) {
+  Timer(rtpt_ctx* ctx, int kernel) : c(ctx), on(ctx->timing_now()) {
     if (!on) return;
     t.kernel = kernel;
     for (hipEvent_t* e : {&t.start, &t.stop}) {
@@ -753,6 +755,7 @@ int rtpt_end_frame(rtpt_ctx* c) {
   c->lut_cur ^= 1;
   c->lut_prev_valid = c->n_tris != 0;
   c->final_swapped = false;
+  c->frames_ended++;
   return RTPT_OK;
 }
 
@@ -825,7 +828,7 @@ int rtpt_set_count_rows(rtpt_ctx* c, uint32_t y0, uint32_t y1) {
 // ------------------------------------------------------------------------------------------ timing
 int rtpt_timing_enable(rtpt_ctx* c, int enable) {
   if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
-  c->timing = enable != 0;
+  c->timing_period = enable > 0 ? enable : 0;
   return RTPT_OK;
 }
 
