@@ -11,9 +11,14 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("k_pathtrace", "k_atrous<true", "k_atrous<false", "k_atrous", "k_gbuffer", "k_gradient", "k_lut"):
+    import re
+    if "k_atrous" in name:
+        # k_atrous_comb_sh<CW, FINAL, EXACT> / k_atrous<FINAL, EXACT>
+        m = re.search(r"k_atrous(?:_comb_sh<\d+, |<)(true|false)", name)
+        return "k_atrous_final" if (m and m.group(1) == "true") else "k_atrous"
+    for k in ("k_pathtrace", "k_gbuffer", "k_gradient", "k_lut", "k_pair_weights"):
         if k in name:
-            return {"k_atrous<true": "k_atrous_final", "k_atrous<false": "k_atrous"}.get(k, k)
+            return k
     return None
 
 
