@@ -206,6 +206,7 @@ rt::SceneView scene_view(const rtpt_ctx* c) {
   s.nodes = static_cast<const rt::BvhNode*>(c->nodes.ptr);
   s.n_tris = c->n_tris;
   s.use_bvh = c->use_bvh ? 1u : 0u;
+  s.stack_depth = static_cast<uint32_t>(c->bvh_depth + 2 < 8 ? 8 : c->bvh_depth + 2);
   return s;
 }
 

@@ -114,47 +114,64 @@ __device__ __forceinline__ bool slab(const float* mn, const float* mx, f3 inv, f
 }
 
 // General scenes: per-lane depth-first traversal of the child-pair BVH with the node stack in LDS
-// (stack[level][thread]: consecutive lanes hit consecutive banks).
+// (stack[level][thread]: consecutive lanes hit consecutive banks; the stack is sized to the depth of
+// the tree that was built, PathtraceArgs/SceneView::stack_depth).
+//
+// "while-while" form: the inner loop only walks interior nodes; a leaf child that must be visited is
+// pushed (or becomes `cur`) as a leaf reference and is tested in the outer loop.  In the first version
+// every iteration fetched a node AND ran the triangle loops of whichever children were leaves under
+// a divergent branch; PMC showed ~37 % lane utilisation on the 1.15M-triangle scene.  Here lanes that
+// reach a leaf wait at the loop exit and the wave tests leaves together.
+//   child reference: bit 31 clear = interior node index; bit 31 set = leaf, (first << 2) | (count - 1);
+//   kBvhEmpty = absent child; kSentinel = empty stack.
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kSentinel = 0xFFFFFFFEu;
+
+__device__ __forceinline__ uint32_t child_ref(uint32_t idx, uint32_t cnt) {
+  return cnt ? (kLeafBit | (idx << 2) | (cnt - 1u)) : idx;  // idx == kBvhEmpty stays kBvhEmpty (cnt == 0)
+}
+
 __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d, HitRec& h, uint32_t* stack,
                                                int tid) {
   f3 inv{fast::rcp_(d.x), fast::rcp_(d.y), fast::rcp_(d.z)};
   f3 oi{-o.x * inv.x, -o.y * inv.y, -o.z * inv.z};
   int sp = 0;
-  uint32_t node = 0;
-  while (true) {
-    const BvhNode nd = sc.nodes[node];
-    float tl, tr;
-    bool hl = (nd.lidx != kBvhEmpty) && slab(nd.lmin, nd.lmax, inv, oi, h.t, tl);
-    bool hr = (nd.ridx != kBvhEmpty) && slab(nd.rmin, nd.rmax, inv, oi, h.t, tr);
-    if (hl && nd.lcnt) {
-      for (uint32_t j = 0; j < nd.lcnt; j++) {
-        const float4* r = sc.isect_leaf + 3 * (nd.lidx + j);
-        tri_test<true>(o, d, r[0], r[1], r[2], sc.leaf_ids[nd.lidx + j] + 1, h);
+  uint32_t cur = 0;  // root pair
+  while (cur != kSentinel) {
+    while (!(cur & kLeafBit)) {  // interior (kSentinel and kBvhEmpty have bit 31 set)
+      const BvhNode nd = sc.nodes[cur];
+      float tl, tr;
+      const uint32_t cl = child_ref(nd.lidx, nd.lcnt), cr = child_ref(nd.ridx, nd.rcnt);
+      const bool hl = (cl != kBvhEmpty) && slab(nd.lmin, nd.lmax, inv, oi, h.t, tl);
+      const bool hr = (cr != kBvhEmpty) && slab(nd.rmin, nd.rmax, inv, oi, h.t, tr);
+      if (hl && hr) {
+        const bool left_first = tl <= tr;
+        stack[sp * kThreads + tid] = left_first ? cr : cl;
+        sp++;
+        cur = left_first ? cl : cr;
+      } else if (hl) {
+        cur = cl;
+      } else if (hr) {
+        cur = cr;
+      } else if (sp > 0) {
+        sp--;
+        cur = stack[sp * kThreads + tid];
+      } else {
+        cur = kSentinel;
       }
-      hl = false;
     }
-    if (hr && nd.rcnt) {
-      for (uint32_t j = 0; j < nd.rcnt; j++) {
-        const float4* r = sc.isect_leaf + 3 * (nd.ridx + j);
-        tri_test<true>(o, d, r[0], r[1], r[2], sc.leaf_ids[nd.ridx + j] + 1, h);
+    if (cur != kSentinel) {  // a leaf
+      const uint32_t first = (cur & ~kLeafBit) >> 2, cnt = (cur & 3u) + 1u;
+      for (uint32_t j = 0; j < cnt; j++) {
+        const float4* r = sc.isect_leaf + 3 * static_cast<size_t>(first + j);
+        tri_test<true>(o, d, r[0], r[1], r[2], sc.leaf_ids[first + j] + 1, h);
       }
-      hr = false;
-    }
-    if (hl && hr) {
-      bool left_first = tl <= tr;
-      uint32_t near = left_first ? nd.lidx : nd.ridx;
-      uint32_t far = left_first ? nd.ridx : nd.lidx;
-      stack[sp * kThreads + tid] = far;
-      sp++;
-      node = near;
-    } else if (hl) {
-      node = nd.lidx;
-    } else if (hr) {
-      node = nd.ridx;
-    } else {
-      if (sp == 0) break;
-      sp--;
-      node = stack[sp * kThreads + tid];
+      if (sp > 0) {
+        sp--;
+        cur = stack[sp * kThreads + tid];
+      } else {
+        cur = kSentinel;
+      }
     }
   }
 }
@@ -241,7 +258,7 @@ __global__ void k_pair_weights(LutArgs a) {
 // ------------------------------------------------------------------------------------------
 template <bool BVH>
 __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
-  __shared__ uint32_t stack[BVH ? kBvhMaxDepth * kThreads : 1];
+  extern __shared__ uint32_t stack[];  // BVH: stack_depth x 256 entries (dynamic); unused otherwise
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
   const int x = blockIdx.x * kBlockX + threadIdx.x;
   const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
@@ -371,7 +388,7 @@ struct PathState {  // SoA in LDS, one slot per thread
 
 template <bool BVH, bool COMPACT>
 __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
-  __shared__ uint32_t stack[BVH ? kBvhMaxDepth * kThreads : 1];
+  extern __shared__ uint32_t stack[];  // BVH: stack_depth x 256 entries (dynamic); unused otherwise
   __shared__ PathState st;
   __shared__ float sum_r[kThreads], sum_g[kThreads], sum_b[kThreads];  // per pixel, only used when spp > 1
   __shared__ uint32_t rng_pix[kThreads];                                // per pixel RNG state between samples
@@ -546,7 +563,7 @@ __global__ void k_selftest_math(int op, const float* in, float* out, size_t n) {
 template <bool BVH>
 __global__ __launch_bounds__(kThreads) void k_selftest_trace(SceneView sc, const float* rays, size_t n, float tmax,
                                                              uint32_t* out_id, float* out_t) {
-  __shared__ uint32_t stack[BVH ? kBvhMaxDepth * kThreads : 1];
+  extern __shared__ uint32_t stack[];  // BVH: stack_depth x 256 entries (dynamic); unused otherwise
   size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (i >= n) return;
   f3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
@@ -572,7 +589,7 @@ void launch_lut(const LutArgs& a, hipStream_t s) {
 void launch_gbuffer(const GbufferArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;
   if (a.scene.use_bvh)
-    hipLaunchKernelGGL(k_gbuffer<true>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
+    hipLaunchKernelGGL(k_gbuffer<true>, grid_for(a.g), dim3(kBlockX, kBlockY), a.scene.stack_depth * kThreads * 4, s, a);
   else
     hipLaunchKernelGGL(k_gbuffer<false>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
 }
@@ -585,12 +602,12 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
   dim3 block(kBlockX, kBlockY);
   if (a.compact) {
     if (a.scene.use_bvh)
-      hipLaunchKernelGGL((k_pathtrace<true, true>), grid_for(a.g), block, 0, s, a);
+      hipLaunchKernelGGL((k_pathtrace<true, true>), grid_for(a.g), block, a.scene.stack_depth * kThreads * 4, s, a);
     else
       hipLaunchKernelGGL((k_pathtrace<false, true>), grid_for(a.g), block, 0, s, a);
   } else {
     if (a.scene.use_bvh)
-      hipLaunchKernelGGL((k_pathtrace<true, false>), grid_for(a.g), block, 0, s, a);
+      hipLaunchKernelGGL((k_pathtrace<true, false>), grid_for(a.g), block, a.scene.stack_depth * kThreads * 4, s, a);
     else
       hipLaunchKernelGGL((k_pathtrace<false, false>), grid_for(a.g), block, 0, s, a);
   }
@@ -604,7 +621,7 @@ void launch_selftest_trace(const SceneView& scene, const float* rays, size_t n, 
   if (!n) return;
   dim3 grid((n + kThreads - 1) / kThreads), block(kThreads);
   if (scene.use_bvh)
-    hipLaunchKernelGGL(k_selftest_trace<true>, grid, block, 0, s, scene, rays, n, tmax, out_id, out_t);
+    hipLaunchKernelGGL(k_selftest_trace<true>, grid, block, scene.stack_depth * kThreads * 4, s, scene, rays, n, tmax, out_id, out_t);
   else
     hipLaunchKernelGGL(k_selftest_trace<false>, grid, block, 0, s, scene, rays, n, tmax, out_id, out_t);
 }

@@ -20,6 +20,7 @@ struct SceneView {
   const BvhNode* nodes;
   uint32_t n_tris;
   uint32_t use_bvh;  // 0: brute force over isect_id, 1: BVH traversal
+  uint32_t stack_depth;  // BVH traversal stack entries per lane (tree depth + 2)
 };
 
 // Screen-space bounds of every triangle of a small scene (<= 64), computed on the host per call and
