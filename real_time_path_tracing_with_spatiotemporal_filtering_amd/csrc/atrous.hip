@@ -3,8 +3,10 @@
 // colour; the FINAL variants fuse reprojection + temporal blend (:213-263).
 //
 //   k_atrous_comb   the shipping kernel: wave-private LDS staging by LDS-DMA, comb row assignment
-//   k_atrous        direct global-load kernel: fallback for scenes whose id-pair weight table does
-//                   not fit LDS (> 63 triangles) and for RTPT_FLAG_DIRECT_FILTER
+//   k_atrous        direct global-load kernel: scenes whose id-pair weight table does not fit LDS
+//                   (> 63 triangles; a comb variant gathering per-id normals from an 18 MB table was
+//                   measured SLOWER on the 1.15M-triangle scene: 197 vs 149 us), strides k > 16, and
+//                   RTPT_FLAG_DIRECT_FILTER
 //
 // Measured on MI355X at 3840x2160 (profiles/): the direct kernel is bound by the vector-memory pipe
 // (27 load instructions per pixel: 107 us even with every tap an L1 hit); tile kernels with a
