@@ -53,7 +53,7 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
                      lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
     app = make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"],
                    rank=rank, world=world, mode=args.halo,
-                   torch_planes=(dist is not None and args.halo == "exchange"), **extra)
+                   torch_planes=(dist is not None), **extra)
     ctx = app.backend.ctx
 
     def fence():

@@ -167,6 +167,13 @@ int rtpt_bind_plane(rtpt_ctx* ctx, rtpt_plane which, void* device_ptr, size_t by
 int rtpt_plane_ptr(rtpt_ctx* ctx, rtpt_plane which, void** device_ptr);
 int rtpt_plane_bytes(const rtpt_ctx* ctx, rtpt_plane which, size_t* bytes);
 
+/* Multi-GPU strips: the final filter pass fetches previousFrameImage at the REPROJECTED pixel
+ * (temporalFiltering.comp.glsl:253), which under camera motion can lie in another rank's strip.
+ * The host all-gathers the strips of the previous frame into one buffer covering frame rows
+ * [row_begin,row_end) and registers it here; the final pass then reads history from it instead of
+ * the context's own PREVIOUS plane.  NULL returns to the PREVIOUS plane. */
+int rtpt_set_external_history(rtpt_ctx* ctx, const void* device_ptr, uint32_t row_begin, uint32_t row_end);
+
 /* ---- scene ---------------------------------------------------------------------------- */
 
 /* loadMesh's RT arrays (main.cpp:416-428: objVertices tightly packed xyz, objIndices u32) +

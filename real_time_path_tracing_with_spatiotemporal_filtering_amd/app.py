@@ -100,6 +100,22 @@ class HipBackend:
                 return t[y0 - base:y1 - base]
         raise RuntimeError("colour plane is not one of the bound torch tensors")
 
+    # history all-gather support (multi-rank, moving camera) ----------------------------------
+    def history_full(self):
+        """torch tensor [H, W, 4] that receives every rank's final strip (allocated on first use)"""
+        if getattr(self, "_hist_full", None) is None:
+            import torch
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self._hist_full = torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=dev)
+        return self._hist_full
+
+    def use_external_history(self, on: bool):
+        if on:
+            t = self.history_full()
+            self.ctx.set_external_history(t.data_ptr(), 0, self.height)
+        else:
+            self.ctx.set_external_history(None)
+
     def readback_rows(self, plane: int, y0: int, y1: int) -> np.ndarray:
         base = self.ctx.cfg.row_begin
         return self.ctx.readback(plane)[y0 - base:y1 - base]
@@ -232,11 +248,36 @@ class PathTracingApplication:
             if self.plan.world > 1 and self.plan.mode == "exchange":
                 in_plane = abi.PLANE_IMAGE if (k & 1) else abi.PLANE_FILTERED
                 exchange_halo(self.plan, k, lambda a, b: self.backend.color_rows(in_plane, a, b), self.group)
+            if self.plan.world > 1 and k == self.maxWaveletIteration and (k & 1):
+                self._prepare_history()
             self.backend.temporal_filter(pc, self.ubo, *self.plan.filter_rows(k))
 
     def copyImageToSwapChainsCurrentImage(self):
         """main.cpp:1308-1406 minus the swapchain: the history hand-over (:1364-1372)."""
         self.backend.end_frame()
+
+    def _camera_static(self):
+        u = self.ubo
+        return list(u.view) == list(u.viewPrev) and list(u.proj) == list(u.projPrev)
+
+    def _prepare_history(self):
+        """With several ranks the final pass may fetch history at a reprojected pixel of another strip
+        (temporalFiltering.comp.glsl:253).  While the camera rests the reprojection is the identity and
+        the strip-local PREVIOUS plane is enough; in a frame where view/proj differ from viewPrev/projPrev
+        every rank's finished strip of the previous frame (still in PREVIOUS) is all-gathered first."""
+        be = self.backend
+        if self.frameCount == 0 or self._camera_static():
+            be.use_external_history(False)
+            return
+        import torch.distributed as dist
+        full = be.history_full()
+        H, R = self.plan.height, self.plan.world
+        o0, o1 = self.plan.own
+        full[o0:o1].copy_(be.color_rows(abi.PLANE_PREVIOUS, o0, o1))
+        for r in range(R):  # strips may differ by a row (H % R), so one broadcast per owner instead of all_gather
+            a, b = StripPlan.bounds(H, R, r)
+            dist.broadcast(full[a:b], src=r, group=self.group)
+        be.use_external_history(True)
 
     def drawScene(self, keys=()):
         """main.cpp:1090-1113."""
@@ -263,7 +304,7 @@ def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode=
     the OBJ (synthetic scenes of scenes.py)."""
     plan = StripPlan(height, world, rank, iterations, mode)
     if torch_planes is None:
-        torch_planes = world > 1 and mode == "exchange"
+        torch_planes = world > 1  # halo exchange and the history all-gather move rows of torch-owned planes
     be = HipBackend(width, height, plan, max_segments=max_segments, flags=flags, torch_planes=torch_planes,
                     debug_mask=debug_mask)
     app = PathTracingApplication(be, width, height, iterations, plan, group=group, **app_kw)

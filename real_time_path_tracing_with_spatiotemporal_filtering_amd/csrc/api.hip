@@ -78,6 +78,8 @@ struct rtpt_ctx {
   int hist_y0 = 0, hist_y1 = 0;  // rows of PREVIOUS holding a valid previous frame
   int final_y0 = 0, final_y1 = 0;
   uint32_t debug_mask = 0;
+  const void* ext_history = nullptr;  // rtpt_set_external_history
+  int ext_hist_y0 = 0, ext_hist_y1 = 0;
   int count_y0 = 0, count_y1 = 0;  // rows counted into RAYCOUNT
 
   // timing
@@ -418,6 +420,16 @@ int rtpt_bind_plane(rtpt_ctx* c, rtpt_plane which, void* device_ptr, size_t byte
   return RTPT_OK;
 }
 
+int rtpt_set_external_history(rtpt_ctx* c, const void* device_ptr, uint32_t row_begin, uint32_t row_end) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  if (device_ptr && (row_begin >= row_end || row_end > c->cfg.height)) return fail(RTPT_E_INVALID, "bad history row range");
+  if (device_ptr && (reinterpret_cast<uintptr_t>(device_ptr) & 15u)) return fail(RTPT_E_INVALID, "history buffer must be 16-byte aligned");
+  c->ext_history = device_ptr;
+  c->ext_hist_y0 = static_cast<int>(row_begin);
+  c->ext_hist_y1 = static_cast<int>(row_end);
+  return RTPT_OK;
+}
+
 int rtpt_enable_debug(rtpt_ctx* c, uint32_t mask) {
   if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
@@ -716,6 +728,12 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
     a.hist_row_base = static_cast<int32_t>(c->cfg.row_begin);
     a.hist_y0 = c->hist_y0;
     a.hist_y1 = c->hist_y1;
+    if (c->ext_history) {  // all-gathered previous frame (multi-GPU strips)
+      a.history = static_cast<const float4*>(c->ext_history);
+      a.hist_row_base = c->ext_hist_y0;
+      a.hist_y0 = c->ext_hist_y0;
+      a.hist_y1 = c->ext_hist_y1;
+    }
   }
   {
     Timer tm(c, final_pass ? RTPT_K_ATROUS_FINAL : RTPT_K_ATROUS);

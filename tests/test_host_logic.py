@@ -31,6 +31,9 @@ class Recorder:
     def end_frame(self):
         self.calls.append(("end_frame",))
 
+    def use_external_history(self, on):
+        self.calls.append(("ext_history", bool(on)))
+
 
 def pc_of(raw):
     return abi.PushConstants.from_buffer_copy(raw)
@@ -107,6 +110,7 @@ def test_strip_rank_row_ranges_reach_the_backend():
     app.drawScene()
     o0, o1 = plan.own
     assert (o0, o1) == (810, 1080)
+    assert ("ext_history", False) in be.calls     # frame 0 / resting camera: strip-local history
     calls = {c[0]: c for c in be.calls if c[0] != "filter"}
     assert calls["gbuffer"][-2:] == (o0 - 15, o1 + 15)
     assert calls["gradient"][-2:] == (o0, o1)

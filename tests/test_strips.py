@@ -76,6 +76,9 @@ class OracleBackend:
         self.grad = np.zeros((H, W, 4), np.float32)
         self.lut = self.lut_prev = None
         self.rays = 0
+        self.width, self.height = width, height
+        self._hist_full = None
+        self._ext = False
 
     def scene_upload(self, xyz, idx, xforms=None):
         self.tris = self.O.flatten(xyz, idx, xforms)
@@ -107,8 +110,9 @@ class OracleBackend:
     def temporal_filter(self, pc, ubo, y0, y1):
         k, n = pc.waveletIteration, pc.maxWaveletIteration
         src, dst = (abi.PLANE_IMAGE, abi.PLANE_FILTERED) if k & 1 else (abi.PLANE_FILTERED, abi.PLANE_IMAGE)
+        hist = self._hist_full.numpy() if self._ext else self.color[self.role[abi.PLANE_PREVIOUS]]
         out = self.O.atrous(self.cfg, self._opc(pc), self._oubo(ubo), self.color[self.role[src]], self.depth, self.vis,
-                            self.lut, self.lut_prev, self.wp, self.color[self.role[abi.PLANE_PREVIOUS]], y0, y1)
+                            self.lut, self.lut_prev, self.wp, hist, y0, y1)
         self.color[self.role[dst]][y0:y1] = out[y0:y1]
         if k == n and k & 1:   # D1: the blend becomes `image`
             self.role[abi.PLANE_IMAGE], self.role[abi.PLANE_FILTERED] = self.role[abi.PLANE_FILTERED], self.role[abi.PLANE_IMAGE]
@@ -120,12 +124,21 @@ class OracleBackend:
     def color_rows(self, plane, y0, y1):
         return self.torch_color[self.role[plane]][y0:y1]
 
+    def history_full(self):
+        import torch
+        if self._hist_full is None:
+            self._hist_full = torch.zeros((self.height, self.width, 4), dtype=torch.float32)
+        return self._hist_full
+
+    def use_external_history(self, on):
+        self._ext = bool(on)
+
     def final_image(self):
         return self.color[self.role[abi.PLANE_PREVIOUS]]
 
 
-W, H, SEG, N, FRAMES = 48, 40, 2, 5, 3
-KEYS = [(), ("J",), ("D",)]
+W, H, SEG, N, FRAMES = 48, 40, 2, 5, 5
+KEYS = [(), ("J",), ("D",), ("E",), ()]   # light move, lateral and VERTICAL camera moves (history crosses strips), rest
 
 
 def _run_rank(rank, world, mode, port, out_dir):
