@@ -232,32 +232,35 @@ def test_spp_4(hip_lib, oracle, cornell):
 # ------------------------------------------------------------------------------ strips on one GPU
 @pytest.mark.parametrize("mode", ["redundant", "exchange"])
 def test_strips_equal_single_frame(hip_lib, oracle, cornell, mode):
-    """two/three virtual ranks as separate contexts on one GPU == the single-context frame, bit for bit
-    (exchange mode: the halo rows are copied between contexts by the test instead of RCCL)."""
+    """two/three virtual ranks as separate contexts on one GPU == the single-context frame, bit for bit.
+    The test plays the network: in exchange mode it copies the k halo rows between contexts instead of
+    RCCL, and in frames where the camera moved it assembles the previous frame from every rank's strip
+    and registers it with rtpt_set_external_history (the all-gather of app._prepare_history)."""
+    import torch
     from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
     w, h, n = 96, 72, 5
+    keys = [(), (), ("E",), ("Q", "A")]   # vertical camera moves: the reprojected pixel leaves the strip
     single = make_app(w, h, max_segments=3, iterations=n)
     for R in (2, 3):
         ranks = [make_app(w, h, max_segments=3, iterations=n, rank=r, world=R, mode=mode, torch_planes=False)
                  for r in range(R)]
-        single.frameCount = 0
-        for frame in range(2):
-            for a in [single] + ranks:
-                a.frameCount = frame
-            single.updateScene()
-            single.drawVisbilityBuffer()
-            single.computeTemporalGradient()
-            single.drawSceneToImage()
-            single.applyTemporalFiltering()
-            want = single.backend.ctx.readback(abi.PLANE_IMAGE)
-            single.copyImageToSwapChainsCurrentImage()
+        ref_app = make_app(w, h, max_segments=3, iterations=n)
+        hist_dev = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(R)]
+        for frame, key in enumerate(keys):
+            ref_app.updateScene(key)
+            ref_app.drawVisbilityBuffer()
+            ref_app.computeTemporalGradient()
+            ref_app.drawSceneToImage()
+            ref_app.applyTemporalFiltering()
+            want = ref_app.backend.ctx.readback(abi.PLANE_IMAGE)
+            ref_app.copyImageToSwapChainsCurrentImage()
+            ref_app.frameCount += 1
             for a in ranks:
-                a.updateScene()
+                a.updateScene(key)
                 a.drawVisbilityBuffer()
                 a.computeTemporalGradient()
                 a.drawSceneToImage()
-            pcs = [a.pushConstants for a in ranks]
             for k in range(1, n + 1):
                 for a in ranks:
                     a.pushConstants.maxWaveletIteration = n
@@ -271,6 +274,19 @@ def test_strips_equal_single_frame(hip_lib, oracle, cornell, mode):
                             base = a.backend.ctx.cfg.row_begin
                             buf[recv_rows[0] - base:recv_rows[1] - base] = pb[recv_rows[0] - pbase:recv_rows[1] - pbase]
                         a.backend.ctx.set_plane(plane, buf)
+                if k == n:
+                    moved = not ranks[0]._camera_static()
+                    if frame > 0 and moved:
+                        prev = np.zeros((h, w, 4), np.float32)
+                        for a in ranks:
+                            o0, o1 = a.plan.own
+                            prev[o0:o1] = a.backend.readback_rows(abi.PLANE_PREVIOUS, o0, o1)
+                        for a, t in zip(ranks, hist_dev):
+                            t.copy_(torch.from_numpy(prev))
+                            a.backend.ctx.set_external_history(t.data_ptr(), 0, h)
+                    else:
+                        for a in ranks:
+                            a.backend.ctx.set_external_history(None)
                 for a in ranks:
                     a.backend.temporal_filter(a.pushConstants, a.ubo, *a.plan.filter_rows(k))
             got = np.zeros_like(want)
@@ -278,9 +294,12 @@ def test_strips_equal_single_frame(hip_lib, oracle, cornell, mode):
                 o0, o1 = a.plan.own
                 got[o0:o1] = a.backend.readback_rows(abi.PLANE_IMAGE, o0, o1)
                 a.copyImageToSwapChainsCurrentImage()
+                a.frameCount += 1
             assert np.array_equal(bits(got), bits(want)), (mode, R, frame)
         for a in ranks:
             a.backend.close()
+        ref_app.backend.close()
+    single.backend.close()
 
 
 def test_errors(hip_lib, cornell):
