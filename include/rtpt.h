@@ -96,6 +96,18 @@ typedef struct rtpt_visibility_data {
 #define RTPT_FLAG_NO_PATH_COMPACTION 0x8u /* path tracer: keep one pixel per lane for the whole path instead of
                                             compacting the surviving paths of a tile after every segment */
 
+/* Extension modes — NOT reference behaviour, default off.  They switch on the pieces of the textbook
+ * A-SVGF that the reference declares but leaves unused; any of them routes K3 to a
+ * generic direct-load kernel.  They cannot be parity-checked against the reference; tests/ check them
+ * against the oracle's restatement of the same definitions. */
+#define RTPT_FLAG_EXT_ADAPTIVE_ALPHA 0x10u /* alpha = (1-g)*alpha + g, g = temporalGradient.r
+                                              (temporalFiltering.comp.glsl:247-248, commented out there) */
+#define RTPT_FLAG_EXT_GAUSS5 0x20u         /* 5x5 taps weighted by gaussianKernel2D/273 (:93-99, unused there) */
+#define RTPT_FLAG_EXT_POW2_STRIDE 0x40u    /* tap stride 2^(k-1) instead of k (:135) */
+#define RTPT_FLAG_EXT_DISOCCLUSION 0x80u   /* blend history only where the reprojected pixel of the previous
+                                              frame's id plane (previousVisibilityBuffer, main.cpp:1367: copied,
+                                              never read) shows the same primitive */
+
 typedef struct rtpt_config {
   uint32_t struct_size;          /* = sizeof(rtpt_config), ABI guard */
   uint32_t width, height;        /* full frame; main.cpp:52-53 (1000x800) */

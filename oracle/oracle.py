@@ -28,7 +28,11 @@ class OracleConfig(C.Structure):
         ("alpha", C.c_float), ("light_radius", C.c_float), ("light_intensity", C.c_float),
         ("first_hit_light_divisor", C.c_float), ("fov_slope", C.c_float),
         ("pixel_jitter", C.c_float), ("ray_offset", C.c_float), ("ray_tmax", C.c_float),
+        ("ext_flags", C.c_uint32),
     ]
+
+
+EXT_ADAPTIVE_ALPHA, EXT_GAUSS5, EXT_POW2_STRIDE, EXT_DISOCCLUSION = 0x10, 0x20, 0x40, 0x80
 
 
 class PushConstants(C.Structure):
@@ -208,15 +212,20 @@ def raytrace(cfg, pc: PushConstants, tris, y0=0, y1=None, want_hit_id=True):
 
 
 def atrous(cfg, pc: PushConstants, ubo: Ubo, img_in, depth, vis, lut_, lut_prev, worldpos, history,
-           y0=0, y1=None, want_prev_pixel=False):
+           y0=0, y1=None, want_prev_pixel=False, gradient=None, prev_vis=None):
     W, H = cfg.width, cfg.height
     y1 = H if y1 is None else y1
     out = np.zeros((H, W, 4), np.float32)
     pp = np.zeros((H, W, 2), np.int32) if want_prev_pixel else None
     if history is None:
         history = np.zeros((H, W, 4), np.float32)
-    lib().oracle_atrous(C.byref(cfg), C.byref(pc), C.byref(ubo), _p(img_in), _p(depth), _p(vis), _p(lut_),
-                        _p(lut_prev), _p(worldpos), _p(history), C.c_uint32(y0), C.c_uint32(y1), _p(out), _p(pp))
+    if prev_vis is None:
+        prev_vis = np.zeros((H, W), np.uint32)
+    if gradient is None:
+        gradient = np.zeros((H, W, 4), np.float32)
+    lib().oracle_atrous_ext(C.byref(cfg), C.byref(pc), C.byref(ubo), _p(img_in), _p(depth), _p(vis), _p(lut_),
+                            _p(lut_prev), _p(worldpos), _p(history), _p(gradient), _p(prev_vis),
+                            C.c_uint32(y0), C.c_uint32(y1), _p(out), _p(pp))
     return (out, pp) if want_prev_pixel else out
 
 
@@ -244,9 +253,11 @@ class OracleApp:
     of scope)."""
 
     def __init__(self, width, height, tris, max_segments=32, iterations=9,
-                 camera=(-0.001, 1.0, 6.0), light=(1.0, 1.0, -0.4), light_color=(0.5, 0.5, 0.5), z_near=0.1, z_far=10.0):
+                 camera=(-0.001, 1.0, 6.0), light=(1.0, 1.0, -0.4), light_color=(0.5, 0.5, 0.5), z_near=0.1, z_far=10.0,
+                 ext_flags=0):
         self.cfg = config_default(width, height)
         self.cfg.max_segments = max_segments
+        self.cfg.ext_flags = ext_flags
         self.iterations = iterations          # main.cpp:55
         self.tris = np.ascontiguousarray(tris, np.float32)
         self.camera = np.array(camera, np.float32)   # main.cpp:65
@@ -272,6 +283,7 @@ class OracleApp:
         self.pc.lightPosPrev[:] = (0.0, 0.0, 0.0)
         self.history = None
         self.lut_prev = None
+        self.prev_vis = None
 
     def update_ubo(self):  # main.cpp:1463-1475
         u = self.ubo
@@ -320,11 +332,13 @@ class OracleApp:
             self.pc.waveletIteration = k
             if k == self.iterations:
                 cur, pp = atrous(cfg, self.pc, self.ubo, cur, depth, vis, lut_, self.lut_prev, wp, self.history,
-                                 want_prev_pixel=True)
+                                 want_prev_pixel=True, gradient=grad, prev_vis=self.prev_vis)
             else:
-                cur = atrous(cfg, self.pc, self.ubo, cur, depth, vis, lut_, self.lut_prev, wp, self.history)
+                cur = atrous(cfg, self.pc, self.ubo, cur, depth, vis, lut_, self.lut_prev, wp, self.history,
+                             gradient=grad, prev_vis=self.prev_vis)
         # history hand-over main.cpp:1361-1372
         self.history = cur
         self.lut_prev = lut_
+        self.prev_vis = vis  # main.cpp:1367
         self.frame += 1
         return FrameOut(vis, wp, depth, grad, traced, hid, cur, pp, rays, lut_)

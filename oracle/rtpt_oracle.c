@@ -37,6 +37,7 @@ void oracle_config_default(oracle_config* c, uint32_t w, uint32_t h) {
   c->pixel_jitter = 0.375f;          /* :314 */
   c->ray_offset = 0.0001f;           /* :250 */
   c->ray_tmax = 10000.0f;            /* :216 */
+  c->ext_flags = 0;
 }
 
 /* ---------------------------------------------------------------- numerics exports */
@@ -501,16 +502,30 @@ static inline vec3 normal_from_id(const float* lut, uint32_t id) {
   return v3_normalize(v3_cross(v3_sub(b, a), v3_sub(c, a)));
 }
 
+/* gaussianKernel2D, temporalFiltering.comp.glsl:93-99 (sum 273) */
+static const float k_gauss5[5][5] = {{1, 4, 7, 4, 1}, {4, 16, 26, 16, 4}, {7, 26, 41, 26, 7}, {4, 16, 26, 16, 4}, {1, 4, 7, 4, 1}};
+
 void oracle_atrous(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
                    const float* in, const float* depth, const uint32_t* vis, const float* lut,
                    const float* lut_prev, const float* worldpos, const float* history,
                    uint32_t y0, uint32_t y1, float* out, int32_t* prev_pixel) {
+  oracle_atrous_ext(cfg, pc, ubo, in, depth, vis, lut, lut_prev, worldpos, history, NULL, NULL, y0, y1, out, prev_pixel);
+}
+
+void oracle_atrous_ext(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
+                       const float* in, const float* depth, const uint32_t* vis, const float* lut,
+                       const float* lut_prev, const float* worldpos, const float* history,
+                       const float* gradient, const uint32_t* prev_vis,
+                       uint32_t y0, uint32_t y1, float* out, int32_t* prev_pixel) {
+  const uint32_t ext = cfg->ext_flags;
+  const int R = (ext & ORACLE_EXT_GAUSS5) ? 2 : 1;
   const int W = (int)cfg->width, H = (int)cfg->height;
-  const int k = pc->waveletIteration, max_it = pc->maxWaveletIteration; /* :208-209 */
+  const int kk = pc->waveletIteration, max_it = pc->maxWaveletIteration; /* :208-209 */
+  const int k = (ext & ORACLE_EXT_POW2_STRIDE) ? (1 << (kk - 1)) : kk;   /* tap stride */
   /* main.cpp:1264-1281: on even k colorImage is filteredImageBuffer, so the blend of an even
    * final pass lands in a buffer nothing reads ("must be an odd number", main.cpp:55) and
    * `image` keeps the plain filtered colour: only an odd final pass blends observably. */
-  const int final_pass = (k == max_it) && (k & 1);
+  const int final_pass = (kk == max_it) && (kk & 1);
   float PVp[16];
   if (final_pass) mat4_mul(ubo->projPrev, ubo->viewPrev, PVp); /* :180 projMatrix * viewMatrix */
   const float h = 1.0f / 9.0f;                    /* :145 */
@@ -524,8 +539,8 @@ void oracle_atrous(const oracle_config* cfg, const oracle_push_constants* pc, co
       vec3 np = normal_from_id(lut, vis[ip]);                  /* :125-127 */
       vec3 num = v3(0.f, 0.f, 0.f);
       float den = 0.f;
-      for (int i = -1; i < 2; i++)     /* :132 */
-        for (int j = -1; j < 2; j++) { /* :133 */
+      for (int i = -R; i <= R; i++)     /* :132 (-1..1; -2..2 with the 5x5 table) */
+        for (int j = -R; j <= R; j++) { /* :133 */
           int qx = x + i * k, qy = y + j * k; /* :135 */
           qx = qx < 0 ? 0 : (qx > W - 1 ? W - 1 : qx); /* :136 */
           qy = qy < 0 ? 0 : (qy > H - 1 ? H - 1 : qy);
@@ -537,7 +552,7 @@ void oracle_atrous(const oracle_config* cfg, const oracle_push_constants* pc, co
           float wd = dm_exp(-fabsf(dp - dq) / cfg->sigma_z);                 /* :67-68 */
           float wl = dm_exp(-v3_length(v3_sub(cp, cq)) / cfg->sigma_l);      /* :73 */
           float w = (wn * wd) * wl;                                          /* :77 */
-          float hw = h * w;
+          float hw = ((ext & ORACLE_EXT_GAUSS5) ? k_gauss5[i + 2][j + 2] * (1.0f / 273.0f) : h) * w;
           num = v3(dm_fma(hw, cq.x, num.x), dm_fma(hw, cq.y, num.y), dm_fma(hw, cq.z, num.z)); /* :146 */
           den = den + hw;                                                     /* :147 */
         }
@@ -564,14 +579,24 @@ void oracle_atrous(const oracle_config* cfg, const oracle_push_constants* pc, co
       }
       if (prev_pixel) { prev_pixel[2 * ip] = ppx; prev_pixel[2 * ip + 1] = ppy; }
       vec3 blend;
-      if (pc->frameNumber > 0) { /* :251 */
+      int use_history = pc->frameNumber > 0; /* :251 */
+      const int inside = (ppx >= 0 && ppx < W && ppy >= 0 && ppy < H);
+      if (use_history && (ext & ORACLE_EXT_DISOCCLUSION)) /* extension: same primitive at the reprojected pixel */
+        use_history = inside && prev_vis[(uint64_t)ppy * W + ppx] == id;
+      if (use_history) {
         vec3 hc = v3(0.f, 0.f, 0.f); /* D2: out-of-image history reads as 0 */
-        if (ppx >= 0 && ppx < W && ppy >= 0 && ppy < H) {
+        if (inside) {
           uint64_t ih = (uint64_t)ppy * W + ppx;
           hc = v3(history[4 * ih], history[4 * ih + 1], history[4 * ih + 2]);
         }
-        blend = v3(dm_fma(filtered.x, cfg->alpha, hc.x * one_minus_alpha), dm_fma(filtered.y, cfg->alpha, hc.y * one_minus_alpha),
-                   dm_fma(filtered.z, cfg->alpha, hc.z * one_minus_alpha)); /* :254 */
+        float alpha = cfg->alpha, oma = one_minus_alpha;
+        if (ext & ORACLE_EXT_ADAPTIVE_ALPHA) { /* :247-248, commented out in the reference */
+          float g = gradient[4 * ip];
+          alpha = dm_fma(1.0f - g, alpha, g);
+          oma = 1.0f - alpha;
+        }
+        blend = v3(dm_fma(filtered.x, alpha, hc.x * oma), dm_fma(filtered.y, alpha, hc.y * oma),
+                   dm_fma(filtered.z, alpha, hc.z * oma)); /* :254 */
       } else {
         blend = filtered; /* :258 */
       }

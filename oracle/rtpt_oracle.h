@@ -29,7 +29,16 @@ typedef struct oracle_config {
   float pixel_jitter;            /* :314 */
   float ray_offset;              /* :250 */
   float ray_tmax;                /* :216 */
+  uint32_t ext_flags;            /* opt-in extension modes (not reference behaviour), see ORACLE_EXT_* */
 } oracle_config;
+
+/* Extension modes = the pieces of the textbook A-SVGF that sit unused or commented out in the reference's
+ * own sources.  Default off; they cannot be parity-checked against the reference. */
+#define ORACLE_EXT_ADAPTIVE_ALPHA 0x10u /* temporalFiltering.comp.glsl:247-248 (commented out): alpha = (1-g)*alpha + g */
+#define ORACLE_EXT_GAUSS5 0x20u         /* gaussianKernel2D, temporalFiltering.comp.glsl:93-99 (declared, unused): 5x5 taps */
+#define ORACLE_EXT_POW2_STRIDE 0x40u    /* tap stride 2^(k-1) instead of k (:135) */
+#define ORACLE_EXT_DISOCCLUSION 0x80u   /* previousVisibilityBuffer (main.cpp:375,:1367: copied every frame, never read):
+                                           history is used only where the reprojected pixel showed the same primitive */
 
 /* PushConstants, main.cpp:35-49 (112 bytes, same layout as the shaders) */
 typedef struct oracle_push_constants {
@@ -109,6 +118,13 @@ void oracle_atrous(const oracle_config* cfg, const oracle_push_constants* pc, co
                    const float* in, const float* depth, const uint32_t* vis, const float* lut,
                    const float* lut_prev, const float* worldpos, const float* history,
                    uint32_t y0, uint32_t y1, float* out, int32_t* prev_pixel);
+/* same with the extension inputs: gradient plane (K1 output) and the previous frame's id plane (nullable
+ * unless the corresponding ORACLE_EXT_* flag is set) */
+void oracle_atrous_ext(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
+                       const float* in, const float* depth, const uint32_t* vis, const float* lut,
+                       const float* lut_prev, const float* worldpos, const float* history,
+                       const float* gradient, const uint32_t* prev_vis,
+                       uint32_t y0, uint32_t y1, float* out, int32_t* prev_pixel);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,9 @@ HEADER_PATH = os.path.join(REPO_DIR, "include", "rtpt.h")
 
 RTPT_OK, RTPT_E_INVALID, RTPT_E_NOMEM, RTPT_E_DEVICE, RTPT_E_NO_SCENE, RTPT_E_NO_GPU = 0, -1, -2, -3, -4, -5
 FLAG_EXACT_FILTER, FLAG_FORCE_BVH, FLAG_DIRECT_FILTER, FLAG_NO_PATH_COMPACTION = 0x1, 0x2, 0x4, 0x8
+# extension modes (not reference behaviour, see include/rtpt.h)
+FLAG_EXT_ADAPTIVE_ALPHA, FLAG_EXT_GAUSS5, FLAG_EXT_POW2_STRIDE, FLAG_EXT_DISOCCLUSION = 0x10, 0x20, 0x40, 0x80
+FLAG_EXT_MASK = 0xF0
 DEBUG_HIT_ID, DEBUG_PREV_PIXEL = 0x1, 0x2
 
 # rtpt_plane

@@ -302,7 +302,7 @@ def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode=
              **app_kw):
     """createBuffers + loadMesh + buildAccelerationStructure for one rank.  `mesh` = (xyz, idx) replaces
     the OBJ (synthetic scenes of scenes.py)."""
-    plan = StripPlan(height, world, rank, iterations, mode)
+    plan = StripPlan(height, world, rank, iterations, mode, flags & 0xF0)
     if torch_planes is None:
         torch_planes = world > 1  # halo exchange and the history all-gather move rows of torch-owned planes
     be = HipBackend(width, height, plan, max_segments=max_segments, flags=flags, torch_planes=torch_planes,

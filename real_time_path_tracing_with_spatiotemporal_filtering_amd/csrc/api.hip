@@ -678,12 +678,16 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
   if (rc) return rc;
   const int k = pc->waveletIteration, max_it = pc->maxWaveletIteration;
   if (k < 1 || max_it < 1 || k > max_it) return fail(RTPT_E_INVALID, "need 1 <= waveletIteration <= maxWaveletIteration");
-  // taps reach rows y +- k (clamped to the frame, temporalFiltering.comp.glsl:135-136): they must be stored here
+  const uint32_t ext = c->cfg.flags & rt::kExtMask;
+  if ((ext & rt::kExtPow2Stride) && k > 24) return fail(RTPT_E_INVALID, "RTPT_FLAG_EXT_POW2_STRIDE supports at most 24 iterations");
+  const int stride = (ext & rt::kExtPow2Stride) ? (1 << (k - 1)) : k;
+  const int64_t reach = static_cast<int64_t>(stride) * ((ext & rt::kExtGauss5) ? 2 : 1);
+  // taps reach rows y +- reach (clamped to the frame, temporalFiltering.comp.glsl:135-136): they must be stored here
   {
-    const int64_t lo = std::max<int64_t>(0, static_cast<int64_t>(y0) - k);
-    const int64_t hi = std::min<int64_t>(c->cfg.height, static_cast<int64_t>(y1) + k);
+    const int64_t lo = std::max<int64_t>(0, static_cast<int64_t>(y0) - reach);
+    const int64_t hi = std::min<int64_t>(c->cfg.height, static_cast<int64_t>(y1) + reach);
     if (y1 > y0 && (lo < c->cfg.row_begin || hi > c->cfg.row_end))
-      return fail(RTPT_E_INVALID, "filter taps at stride " + std::to_string(k) + " leave the stored rows (missing halo)");
+      return fail(RTPT_E_INVALID, "filter taps reaching " + std::to_string(reach) + " rows leave the stored rows (missing halo)");
   }
   // main.cpp:1264-1281: odd k reads `image`, writes `filteredImageBuffer`; even k the reverse.
   // An even final pass blends into a buffer nothing reads (main.cpp:55 "must be an odd number"),
@@ -698,6 +702,8 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
   std::memset(&a, 0, sizeof a);
   a.g = geom(c, y0, y1);
   a.k = k;
+  a.stride = stride;
+  a.ext = ext;
   a.exact = (c->cfg.flags & RTPT_FLAG_EXACT_FILTER) ? 1 : 0;
   a.direct = (c->cfg.flags & RTPT_FLAG_DIRECT_FILTER) ? 1 : 0;
   a.n_tris = c->n_tris;
@@ -728,6 +734,10 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
     a.hist_row_base = static_cast<int32_t>(c->cfg.row_begin);
     a.hist_y0 = c->hist_y0;
     a.hist_y1 = c->hist_y1;
+    a.gradient = static_cast<const float4*>(c->gradient.ptr);
+    a.prev_vis = static_cast<const uint32_t*>(c->vis[c->vis_cur ^ 1].ptr);
+    a.pvis_y0 = c->hist_y0;
+    a.pvis_y1 = c->hist_y1;
     if (c->ext_history) {  // all-gathered previous frame (multi-GPU strips)
       a.history = static_cast<const float4*>(c->ext_history);
       a.hist_row_base = c->ext_hist_y0;

@@ -166,6 +166,102 @@ __global__ __launch_bounds__(kThreads) void k_atrous(AtrousArgs a) {
 }
 
 
+// Extension modes (RTPT_FLAG_EXT_*): the pieces of the textbook A-SVGF the reference declares but does not
+// use — the 5x5 gaussianKernel2D table (temporalFiltering.comp.glsl:93-99), 2^(k-1) tap stride, the
+// gradient-adaptive alpha (:247-248, commented out) and a disocclusion test on previousVisibilityBuffer
+// (main.cpp:1367: copied every frame, never read).  Opt-in and outside the reference's behaviour, so this is
+// one generic direct-load kernel (same tap arithmetic as k_atrous) rather than a tuned one.
+__constant__ float kGauss5[5][5] = {{1, 4, 7, 4, 1}, {4, 16, 26, 16, 4}, {7, 26, 41, 26, 7}, {4, 16, 26, 16, 4}, {1, 4, 7, 4, 1}};
+
+template <bool FINAL, bool EXACT>
+__global__ __launch_bounds__(kThreads) void k_atrous_ext(AtrousArgs a) {
+  int bx, by;
+  xcd_strip_tile(a.tiles_x, a.tiles_y, bx, by);
+  const int ty = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const int x = bx * kBlockX + static_cast<int>(threadIdx.x);
+  const int y = a.g.y0 + by * kBlockY + ty;
+  if (x >= a.g.W || y >= a.g.y1) return;
+  const int W = a.g.W, H = a.g.H, k = a.stride;
+  const bool gauss = (a.ext & kExtGauss5) != 0;
+  const int R = gauss ? 2 : 1;
+  const size_t rowp = static_cast<size_t>(y - a.g.row_base) * W;
+  const float4 cp4 = a.in[rowp + x];
+  const f3 cp = xyz(cp4);
+  const float dp = cp4.w;  // rgbd
+  const uint32_t idp = a.vis[rowp + x];
+  const float4 np4 = a.normal_tab[idp];
+  const f3 np = xyz(np4);
+  f3 num{0.f, 0.f, 0.f};
+  float den = 0.f;
+  for (int i = -R; i <= R; i++) {    // :132
+    for (int j = -R; j <= R; j++) {  // :133
+      int qx = x + i * k, qy = y + j * k;  // :135
+      qx = qx < 0 ? 0 : (qx > W - 1 ? W - 1 : qx);  // :136
+      qy = qy < 0 ? 0 : (qy > H - 1 ? H - 1 : qy);
+      const size_t rowq = static_cast<size_t>(qy - a.g.row_base) * W;
+      const float4 cq4 = a.in[rowq + qx];
+      const f3 cq = xyz(cq4);
+      const float dq = cq4.w;
+      const uint32_t idq = a.vis[rowq + qx];
+      const f3 nq = xyz(a.normal_tab[idq]);
+      const float wn = exact::powi(glsl_max(0.0f, exact::dot(np, nq)), a.sigma_n);  // :62
+      const f3 dc = cp - cq;
+      float w;
+      if (EXACT) {
+        const float wd = exact::exp_(-__builtin_fabsf(dp - dq) / a.sigma_z);  // :67-68
+        const float wl = exact::exp_(-exact::length(dc) / a.sigma_l);         // :73
+        w = (wn * wd) * wl;                                                   // :77
+      } else {
+        const float e = fmaf_(__builtin_fabsf(dp - dq), a.cz, fast::sqrt_(exact::dot(dc, dc)) * a.cl);
+        w = wn * __builtin_amdgcn_exp2f(e);
+      }
+      const float h = gauss ? kGauss5[i + 2][j + 2] * (1.0f / 273.0f) : 1.0f / 9.0f;  // :145
+      const float hw = h * w;
+      num = f3{fmaf_(hw, cq.x, num.x), fmaf_(hw, cq.y, num.y), fmaf_(hw, cq.z, num.z)};  // :146
+      den = den + hw;                                                                    // :147
+    }
+  }
+  const f3 filtered = f3{num.x / den, num.y / den, num.z / den};  // :150
+  if (!FINAL) {
+    a.out[rowp + x] = make_float4(filtered.x, filtered.y, filtered.z, dp);
+    return;
+  }
+  int ppx = x, ppy = y;
+  if (!(idp < 1)) {
+    const f3 wp = xyz(a.worldpos[rowp + x]);
+    const f3 va = xyz(a.lut_prev[3 * idp]), vb = xyz(a.lut_prev[3 * idp + 1]), vc = xyz(a.lut_prev[3 * idp + 2]);
+    const f3 bc = bary_coords(wp, va, vb, vc);
+    const f3 wpp = bary_mix(bc, va, vb, vc);
+    const float clx = exact::mat_row_point(a.PVprev, 0, wpp), cly = exact::mat_row_point(a.PVprev, 1, wpp),
+                clw = exact::mat_row_point(a.PVprev, 3, wpp);
+    const float ndx = clx / clw, ndy = cly / clw;
+    ppx = exact::f2i(fmaf_(ndx, 0.5f, 0.5f) * static_cast<float>(W));
+    ppy = exact::f2i(fmaf_(ndy, 0.5f, 0.5f) * static_cast<float>(H));
+  }
+  if (a.prev_pixel) a.prev_pixel[rowp + x] = make_int2(ppx, ppy);
+  bool use_history = a.frame > 0;  // :251
+  const bool inside = ppx >= 0 && ppx < W && ppy >= 0 && ppy < H;
+  if (use_history && (a.ext & kExtDisocclusion)) {
+    // same primitive at the reprojected pixel; rows this context does not hold count as disoccluded
+    use_history = inside && ppy >= a.pvis_y0 && ppy < a.pvis_y1 &&
+                  a.prev_vis[static_cast<size_t>(ppy - a.g.row_base) * W + ppx] == idp;
+  }
+  f3 blend = filtered;  // :258
+  if (use_history) {
+    f3 hc{0.f, 0.f, 0.f};  // D2
+    if (ppx >= 0 && ppx < W && ppy >= a.hist_y0 && ppy < a.hist_y1)
+      hc = xyz(a.history[static_cast<size_t>(ppy - a.hist_row_base) * W + ppx]);
+    float alpha = a.alpha, oma = 1.0f - a.alpha;
+    if (a.ext & kExtAdaptiveAlpha) {  // :247-248
+      const float g = a.gradient[rowp + x].x;
+      alpha = fmaf_(1.0f - g, alpha, g);
+      oma = 1.0f - alpha;
+    }
+    blend = f3{fmaf_(filtered.x, alpha, hc.x * oma), fmaf_(filtered.y, alpha, hc.y * oma), fmaf_(filtered.z, alpha, hc.z * oma)};  // :254
+  }
+  a.out[rowp + x] = make_float4(blend.x, blend.y, blend.z, 0.0f);
+}
+
 // LDS-DMA issued from inline asm.  hipcc models `__builtin_amdgcn_global_load_lds` as an LDS store and
 // puts `s_waitcnt vmcnt(0)` in front of every later ds_read that may alias it — with a ring buffer
 // that is every read, which drains the prefetch each step.  Hidden in asm, the DMA is invisible to
@@ -430,6 +526,24 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
   a.cl = -1.44269504088896341f / a.sigma_l;
   dim3 block(kBlockX, kBlockY);
   const int np = static_cast<int>(a.n_tris) + 1;
+  if (a.ext) {
+    const dim3 g2 = grid_for(a.g);
+    a.tiles_x = static_cast<int32_t>(g2.x);
+    a.tiles_y = static_cast<int32_t>(g2.y);
+    dim3 grid(g2.x * g2.y);
+    if (a.exact) {
+      if (final_pass)
+        hipLaunchKernelGGL((k_atrous_ext<true, true>), grid, block, 0, s, a);
+      else
+        hipLaunchKernelGGL((k_atrous_ext<false, true>), grid, block, 0, s, a);
+    } else {
+      if (final_pass)
+        hipLaunchKernelGGL((k_atrous_ext<true, false>), grid, block, 0, s, a);
+      else
+        hipLaunchKernelGGL((k_atrous_ext<false, false>), grid, block, 0, s, a);
+    }
+    return;
+  }
   if (!a.direct && a.pair_tab && np <= kPairMax && a.k >= 1 && a.k <= 16) {
     const int seg_w = kBlockX * kShHalves;
     a.tiles_x = (a.g.W + seg_w - 1) / seg_w;

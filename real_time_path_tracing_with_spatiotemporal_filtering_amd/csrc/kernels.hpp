@@ -121,7 +121,16 @@ struct AtrousArgs {
   int2* prev_pixel;      // nullable
   int32_t hist_row_base;          // first frame row stored by the history plane
   int32_t hist_y0, hist_y1;       // frame rows of the history plane that hold a valid previous frame
+  // extension modes (RTPT_FLAG_EXT_*; 0 = the reference's filter).  Any bit routes to k_atrous_ext.
+  uint32_t ext;
+  int32_t stride;                 // tap stride (k, or 2^(k-1) with RTPT_FLAG_EXT_POW2_STRIDE)
+  const float4* gradient;         // K1 output (adaptive alpha)
+  const uint32_t* prev_vis;       // previous frame's id plane, rows [pvis_y0,pvis_y1) valid, stored from g.row_base
+  int32_t pvis_y0, pvis_y1;
 };
+
+constexpr uint32_t kExtAdaptiveAlpha = 0x10u, kExtGauss5 = 0x20u, kExtPow2Stride = 0x40u, kExtDisocclusion = 0x80u;
+constexpr uint32_t kExtMask = 0xF0u;
 
 struct ScenePrepArgs {
   uint32_t n_tris;

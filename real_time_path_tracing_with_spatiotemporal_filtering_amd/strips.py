@@ -28,6 +28,13 @@ class StripPlan:
     rank: int
     iterations: int          # maxWaveletIteration (main.cpp:55)
     mode: str = "exchange"   # "exchange" | "redundant"
+    ext_flags: int = 0       # RTPT_FLAG_EXT_* (extension modes change how far the taps of iteration k reach)
+
+    def reach(self, k: int) -> int:
+        """rows above/below a pixel that iteration k reads: k for the reference's 3x3 linear-stride taps
+        (temporalFiltering.comp.glsl:135); radius 2 with EXT_GAUSS5, stride 2^(k-1) with EXT_POW2_STRIDE."""
+        stride = (1 << (k - 1)) if (self.ext_flags & 0x40) else k
+        return stride * (2 if (self.ext_flags & 0x20) else 1)
 
     def __post_init__(self):
         if self.mode not in ("exchange", "redundant"):
@@ -52,7 +59,9 @@ class StripPlan:
         if self.world == 1:
             return 0
         n = self.iterations
-        return n if self.mode == "exchange" else n * (n + 1) // 2
+        if self.mode == "exchange":
+            return max(self.reach(k) for k in range(1, n + 1))
+        return sum(self.reach(k) for k in range(1, n + 1))
 
     @property
     def stored(self):
@@ -74,15 +83,13 @@ class StripPlan:
     def raytrace_rows(self):
         if self.world == 1 or self.mode == "exchange":
             return self.own
-        n = self.iterations
-        return self._grow(n * (n + 1) // 2)
+        return self._grow(sum(self.reach(k) for k in range(1, self.iterations + 1)))
 
     def filter_rows(self, k: int):
         """rows iteration k must produce on this rank."""
         if self.world == 1 or self.mode == "exchange":
             return self.own
-        n = self.iterations
-        remaining = sum(range(k + 1, n + 1))
+        remaining = sum(self.reach(j) for j in range(k + 1, self.iterations + 1))
         return self._grow(remaining)
 
     # ---- exchange mode: what travels before iteration k
@@ -100,16 +107,17 @@ class StripPlan:
         o0, o1 = self.own
         out = []
         up, down = self.neighbours()
+        r = self.reach(k)
         if up is not None:
             u0, u1 = self.bounds(self.height, self.world, up)
-            if u1 - u0 < k or o1 - o0 < k:
-                raise ValueError(f"strip shorter than the stride-{k} halo")
-            out.append((up, (o0, o0 + k), (o0 - k, o0)))
+            if u1 - u0 < r or o1 - o0 < r:
+                raise ValueError(f"strip shorter than the {r}-row halo of iteration {k}")
+            out.append((up, (o0, o0 + r), (o0 - r, o0)))
         if down is not None:
             d0, d1 = self.bounds(self.height, self.world, down)
-            if d1 - d0 < k or o1 - o0 < k:
-                raise ValueError(f"strip shorter than the stride-{k} halo")
-            out.append((down, (o1 - k, o1), (o1, o1 + k)))
+            if d1 - d0 < r or o1 - o0 < r:
+                raise ValueError(f"strip shorter than the {r}-row halo of iteration {k}")
+            out.append((down, (o1 - r, o1), (o1, o1 + r)))
         return out
 
 

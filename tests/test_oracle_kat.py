@@ -158,3 +158,85 @@ def test_even_final_iteration_does_not_blend(oracle, cornell):
     pc.waveletIteration = 2
     b = oracle.atrous(app.cfg, pc, app.ubo, a, f1.depth, f1.vis, f1.lut, f1.lut, f1.worldpos, None)
     np.testing.assert_array_equal(b, f1.image)
+
+
+# ------------------------------------------------------------------------------ extension modes (oracle side)
+def _ext_inputs(oracle, w=24, h=20, seed=3):
+    rng = np.random.default_rng(seed)
+    cfg = oracle.config_default(w, h)
+    img = rng.random((h, w, 4), dtype=np.float32)
+    img[..., 3] = 0
+    depth = np.full((h, w), 0.5, np.float32)
+    vis = np.ones((h, w), np.uint32)
+    lut = np.zeros((2, 12), np.float32)
+    lut[1, 0:3] = (0, 0, 1)          # vertex a
+    lut[1, 4:7] = (1, 0, 1)          # vertex b
+    lut[1, 8:11] = (0, 1, 1)         # vertex c
+    return cfg, img, depth, vis, lut
+
+
+def test_ext_flags_default_off_and_gauss5_flat_field(oracle):
+    """a constant image stays constant under any tap set; with equal guides the 5x5 table reduces to the
+    normalised gaussianKernel2D (sum 273, temporalFiltering.comp.glsl:93-99)"""
+    cfg, img, depth, vis, lut = _ext_inputs(oracle)
+    assert cfg.ext_flags == 0
+    pc, ubo = oracle.PushConstants(), oracle.Ubo()
+    pc.waveletIteration, pc.maxWaveletIteration = 1, 3
+    wp = np.zeros_like(img)
+    flat = np.full_like(img, 0.25)
+    flat[..., 3] = 0
+    for ext in (oracle.EXT_GAUSS5, oracle.EXT_POW2_STRIDE, oracle.EXT_GAUSS5 | oracle.EXT_POW2_STRIDE):
+        cfg.ext_flags = ext
+        out = oracle.atrous(cfg, pc, ubo, flat, depth, vis, lut, lut, wp, flat)
+        assert np.allclose(out[..., :3], 0.25, rtol=1e-6)
+    # one bright pixel, huge sigma_l => pure spatial kernel: the response IS the table
+    cfg.ext_flags = oracle.EXT_GAUSS5
+    cfg.sigma_l = 1e30
+    imp = np.zeros_like(img)
+    imp[10, 12, :3] = 273.0
+    out = oracle.atrous(cfg, pc, ubo, imp, depth, vis, lut, lut, wp, imp)
+    table = np.array([[1, 4, 7, 4, 1], [4, 16, 26, 16, 4], [7, 26, 41, 26, 7], [4, 16, 26, 16, 4], [1, 4, 7, 4, 1]], np.float32)
+    assert np.allclose(out[8:13, 10:15, 0], table, rtol=1e-5)
+    # stride 2^(k-1): iteration 3 taps land 4 pixels apart
+    cfg.ext_flags = oracle.EXT_POW2_STRIDE
+    pc.waveletIteration = 3
+    pc.maxWaveletIteration = 4
+    out = oracle.atrous(cfg, pc, ubo, imp, depth, vis, lut, lut, wp, imp)
+    ys, xs = np.nonzero(out[..., 0])
+    assert sorted(set(ys)) == [6, 10, 14] and sorted(set(xs)) == [8, 12, 16]
+
+
+def test_ext_adaptive_alpha_and_disocclusion(oracle):
+    cfg, img, depth, vis, lut = _ext_inputs(oracle)
+    w, h = cfg.width, cfg.height
+    pc, ubo = oracle.PushConstants(), oracle.Ubo()
+    pc.waveletIteration = pc.maxWaveletIteration = 1
+    pc.frameNumber = 3
+    # identity reprojection: background pixels (id 0) keep their own coordinate (:213-217)
+    vis0 = np.zeros((h, w), np.uint32)
+    wp = np.zeros_like(img)
+    hist = np.full_like(img, 2.0)
+    base = oracle.atrous(cfg, pc, ubo, img, depth, vis0, lut, lut, wp, hist)
+    filt_only = oracle.atrous(cfg, oracle.PushConstants.from_buffer_copy(bytes(pc)), ubo, img, depth, vis0, lut, lut, wp, hist)
+    assert base.tobytes() == filt_only.tobytes()
+    pc0 = oracle.PushConstants.from_buffer_copy(bytes(pc))
+    pc0.frameNumber = 0
+    filtered = oracle.atrous(cfg, pc0, ubo, img, depth, vis0, lut, lut, wp, hist)   # frame 0: no blend (:258)
+    cfg.ext_flags = oracle.EXT_ADAPTIVE_ALPHA
+    g = np.zeros_like(img)
+    out0 = oracle.atrous(cfg, pc, ubo, img, depth, vis0, lut, lut, wp, hist, gradient=g)
+    assert out0.tobytes() == base.tobytes(), "gradient 0 keeps the constant alpha"
+    g[..., 0] = 1.0
+    out1 = oracle.atrous(cfg, pc, ubo, img, depth, vis0, lut, lut, wp, hist, gradient=g)
+    assert out1.tobytes() == filtered.tobytes(), "gradient 1 drops the history"
+    g[..., 0] = 0.5
+    outh = oracle.atrous(cfg, pc, ubo, img, depth, vis0, lut, lut, wp, hist, gradient=g)
+    a = np.float32(0.5) * np.float32(0.3) + np.float32(0.5)
+    assert np.allclose(outh[..., :3], filtered[..., :3] * a + 2.0 * (1 - a), rtol=1e-6)
+    # disocclusion: history only where the previous id plane agrees
+    cfg.ext_flags = oracle.EXT_DISOCCLUSION
+    pv = np.zeros((h, w), np.uint32)
+    pv[:, w // 2:] = 7
+    outd = oracle.atrous(cfg, pc, ubo, img, depth, vis0, lut, lut, wp, hist, prev_vis=pv)
+    assert outd[:, :w // 2].tobytes() == base[:, :w // 2].tobytes()
+    assert outd[:, w // 2:].tobytes() == filtered[:, w // 2:].tobytes()

@@ -40,6 +40,27 @@ def test_plan_covers_frame_and_halos(H, R, N, mode):
     assert rows == list(range(H))
 
 
+@pytest.mark.parametrize("ext", [0x20, 0x40, 0x60])
+@pytest.mark.parametrize("mode", ["exchange", "redundant"])
+def test_plan_with_extension_reach(ext, mode):
+    H, R, N = 2160, 4, 5
+    for r in range(R):
+        p = StripPlan(H, R, r, N, mode, ext)
+        s0, s1 = p.stored
+        prev = p.raytrace_rows()
+        for k in range(1, N + 1):
+            reach = ((1 << (k - 1)) if ext & 0x40 else k) * (2 if ext & 0x20 else 1)
+            assert p.reach(k) == reach
+            f0, f1 = p.filter_rows(k)
+            assert s0 <= max(0, f0 - reach) and min(H, f1 + reach) <= s1
+            if mode == "redundant":
+                assert prev[0] <= max(0, f0 - reach) and min(H, f1 + reach) <= prev[1]
+                prev = (f0, f1)
+            else:
+                for _, send, recv in p.exchange_rows(k):
+                    assert send[1] - send[0] == recv[1] - recv[0] == reach
+
+
 def test_exchange_lists_are_symmetric():
     H, R, N = 240, 4, 5
     plans = [StripPlan(H, R, r, N, "exchange") for r in range(R)]
@@ -66,6 +87,7 @@ class OracleBackend:
         self.O, self.plan = O, plan
         self.cfg = O.config_default(width, height)
         self.cfg.max_segments = max_segments
+        self.cfg.ext_flags = plan.ext_flags
         W, H = width, height
         self.color = [np.zeros((H, W, 4), np.float32) for _ in range(3)]
         self.torch_color = [torch.from_numpy(c) for c in self.color]
@@ -112,7 +134,7 @@ class OracleBackend:
         src, dst = (abi.PLANE_IMAGE, abi.PLANE_FILTERED) if k & 1 else (abi.PLANE_FILTERED, abi.PLANE_IMAGE)
         hist = self._hist_full.numpy() if self._ext else self.color[self.role[abi.PLANE_PREVIOUS]]
         out = self.O.atrous(self.cfg, self._opc(pc), self._oubo(ubo), self.color[self.role[src]], self.depth, self.vis,
-                            self.lut, self.lut_prev, self.wp, hist, y0, y1)
+                            self.lut, self.lut_prev, self.wp, hist, y0, y1, gradient=self.grad)
         self.color[self.role[dst]][y0:y1] = out[y0:y1]
         if k == n and k & 1:   # D1: the blend becomes `image`
             self.role[abi.PLANE_IMAGE], self.role[abi.PLANE_FILTERED] = self.role[abi.PLANE_FILTERED], self.role[abi.PLANE_IMAGE]
@@ -141,7 +163,7 @@ W, H, SEG, N, FRAMES = 48, 40, 2, 5, 5
 KEYS = [(), ("J",), ("D",), ("E",), ()]   # light move, lateral and VERTICAL camera moves (history crosses strips), rest
 
 
-def _run_rank(rank, world, mode, port, out_dir):
+def _run_rank(rank, world, mode, port, out_dir, ext=0):
     import sys
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -149,7 +171,7 @@ def _run_rank(rank, world, mode, port, out_dir):
     O.set_threads(2)
     if world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    plan = StripPlan(H, world, rank, N, mode)
+    plan = StripPlan(H, world, rank, N, mode, ext)
     be = OracleBackend(O, W, H, SEG, plan)
     app = PathTracingApplication(be, W, H, N, plan)
     app.loadMesh(SCENE)
@@ -159,7 +181,7 @@ def _run_rank(rank, world, mode, port, out_dir):
         app.drawScene(KEYS[f])
         o0, o1 = plan.own
         frames.append(be.final_image()[o0:o1].copy())
-    np.savez(os.path.join(out_dir, f"{mode}_{world}_{rank}.npz"), *frames, rays=np.array([be.rays]))
+    np.savez(os.path.join(out_dir, f"{mode}{ext}_{world}_{rank}.npz"), *frames, rays=np.array([be.rays]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -171,14 +193,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,mode", [(2, "exchange"), (2, "redundant"), (3, "exchange")])
-def test_gloo_ranks_reproduce_the_single_rank_frame(tmp_path, oracle, world, mode):
+# ext 0x30 / 0x70: extension modes (adaptive alpha + 5x5 taps [+ 2^(k-1) stride]) widen the halo (StripPlan.reach)
+@pytest.mark.parametrize("world,mode,ext", [(2, "exchange", 0), (2, "redundant", 0), (3, "exchange", 0),
+                                            (2, "exchange", 0x30), (2, "redundant", 0x70)])
+def test_gloo_ranks_reproduce_the_single_rank_frame(tmp_path, oracle, world, mode, ext):
     import torch.multiprocessing as mp
-    single = tmp_path / f"{mode}_1_0.npz"
-    _run_rank(0, 1, mode, 0, str(tmp_path))
-    mp.spawn(_run_rank, args=(world, mode, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    single = tmp_path / f"{mode}{ext}_1_0.npz"
+    _run_rank(0, 1, mode, 0, str(tmp_path), ext)
+    mp.spawn(_run_rank, args=(world, mode, _free_port(), str(tmp_path), ext), nprocs=world, join=True)
     ref = np.load(single)
-    parts = [np.load(tmp_path / f"{mode}_{world}_{r}.npz") for r in range(world)]
+    parts = [np.load(tmp_path / f"{mode}{ext}_{world}_{r}.npz") for r in range(world)]
     for f in range(FRAMES):
         want = ref[f"arr_{f}"]
         got = np.concatenate([p[f"arr_{f}"] for p in parts], axis=0)
