@@ -191,6 +191,9 @@ def main():
     ap.add_argument("--halo", choices=["exchange", "redundant"], default="redundant")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl) and torch-owned planes even with one rank (rehearsal)")
+    ap.add_argument("--emulate-strip", default=None, metavar="R/N",
+                    help="diagnostic: this single process runs rank R's strip of an N-rank job (redundant halo, no "
+                         "communication is needed while the camera rests) and prints its per-frame time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -218,6 +221,14 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
+    if args.emulate_strip:
+        r, n = map(int, args.emulate_strip.split("/"))
+        args.halo = "redundant"
+        elapsed, rays, kern, plan, timed_frames = run_gpu(wl, args, r, n, args.steps, args.warmup, torch, None)
+        print(json.dumps({"emulated_strip": args.emulate_strip, "rows_owned": plan.own, "rows_stored": plan.stored,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "rays_per_frame": rays / args.steps,
+                          "kernels": kernel_report(kern, wl, plan, timed_frames)}))
+        return
     elapsed, rays, kern, plan, timed_frames = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist)
     ms_per_step = elapsed / args.steps * 1e3
     result = None
