@@ -7,6 +7,8 @@ FILTER_TOL: per-pixel L2 error of the filtered RGB <= 1e-5 * (1 + ||oracle RGB||
 only promises ~3 ulp on exp and leaves pow unspecified; v_exp_f32/v_sqrt_f32/v_rcp_f32 are 1 ulp.)
 With RTPT_FLAG_EXACT_FILTER the filter is bit-exact too.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -235,6 +237,45 @@ def test_ragged_sizes_and_border_clamp(hip_lib, oracle, cornell):
         ok, rel = l2_ok(got.reshape(h, w, 4), fo.image)
         assert ok, (w, h, rel)
         assert np.array_equal(app.backend.ctx.readback(hip_lib.PLANE_PREV_VIS_ID).reshape(h, w), fo.vis)
+
+
+def test_full_size_4k_frames_against_oracle(hip_lib, oracle, cornell):
+    """BASELINE configs[2] at its real size (3840x2160, 4 segments, N = 5): two frames, light moved in the second,
+    every observable against the oracle — not a property, the comparison itself (the oracle needs ~1 s per frame
+    on the box's host cores)."""
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    app, ref = make_pair(hip_lib, oracle, cornell, w=3840, h=2160, seg=4, n=5)
+    try:
+        ctx = app.backend.ctx
+        total_rays = 0
+        for keys, light_move in (((), None), (("J",), (-0.1, 0, 0))):
+            app.updateScene(keys)
+            app.drawVisbilityBuffer()
+            app.computeTemporalGradient()
+            app.drawSceneToImage()
+            vis = ctx.readback(hip_lib.PLANE_VIS_ID)
+            hit = ctx.readback(hip_lib.PLANE_HIT_ID)
+            traced = ctx.readback(hip_lib.PLANE_IMAGE)
+            grad = ctx.readback(hip_lib.PLANE_GRADIENT)
+            rays = ctx.raycount()
+            app.applyTemporalFiltering()
+            final = ctx.readback(hip_lib.PLANE_IMAGE)
+            pp = ctx.readback(hip_lib.PLANE_PREV_PIXEL)
+            app.copyImageToSwapChainsCurrentImage()
+            app.frameCount += 1
+            fo = ref.draw_scene(move_light=light_move)
+            assert np.array_equal(vis, fo.vis)
+            assert np.array_equal(hit, fo.hit_id)
+            assert np.array_equal(bits(traced), bits(fo.traced))
+            assert np.array_equal(bits(grad), bits(fo.gradient))
+            assert np.array_equal(pp, fo.prev_pixel)
+            ok, rel = l2_ok(final, fo.image)
+            assert ok, rel
+            total_rays += fo.rays
+            assert rays == total_rays
+    finally:
+        oracle.set_threads(min(8, os.cpu_count() or 1))
+        app.backend.close()
 
 
 def test_reference_default_config_32_segments(hip_lib, oracle, cornell):
