@@ -163,6 +163,13 @@ int rtpt_config_default(rtpt_config* cfg, uint32_t width, uint32_t height);
 int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out);
 /* freeRessources (main.cpp:1477-1528) */
 int rtpt_destroy(rtpt_ctx* ctx);
+/* The reference re-creates its size-dependent resources when the framebuffer changes
+ * (framebufferResizeCallback main.cpp:275-278, swapChain.acquireAutoResize :1310).  Re-allocates every
+ * per-pixel plane for a width x height frame storing rows [row_begin,row_end) (0,0 = the whole frame),
+ * zeroes them and restarts the history (the next final pass is a frame-0 pass for the blend unless the
+ * caller injects PREVIOUS); the uploaded scene, LUTs and configuration constants are kept.  Planes bound
+ * with rtpt_bind_plane are dropped and must be bound again.  Blocks until the stream is idle. */
+int rtpt_resize(rtpt_ctx* ctx, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end);
 /* last error message of this thread's most recent failing call (ctx may be NULL) */
 const char* rtpt_last_error(const rtpt_ctx* ctx);
 

@@ -77,7 +77,7 @@ assert C.sizeof(PushConstants) == 112 and C.sizeof(Ubo) == 384
 
 # every symbol include/rtpt.h declares (tests check the header and this list agree)
 SYMBOLS = [
-    "rtpt_config_default", "rtpt_create", "rtpt_destroy", "rtpt_last_error", "rtpt_set_stream", "rtpt_bind_plane",
+    "rtpt_config_default", "rtpt_create", "rtpt_destroy", "rtpt_resize", "rtpt_last_error", "rtpt_set_stream", "rtpt_bind_plane",
     "rtpt_plane_ptr", "rtpt_plane_bytes", "rtpt_set_external_history", "rtpt_scene_upload", "rtpt_gbuffer", "rtpt_temporal_gradient",
     "rtpt_raytrace", "rtpt_temporal_filter", "rtpt_end_frame", "rtpt_sync", "rtpt_readback", "rtpt_set_plane",
     "rtpt_reset_counters", "rtpt_set_count_rows", "rtpt_enable_debug", "rtpt_timing_enable", "rtpt_timing_collect", "rtpt_kernel_name",
@@ -106,6 +106,7 @@ def load() -> C.CDLL:
         "rtpt_config_default": [C.POINTER(Config), u32, u32],
         "rtpt_create": [C.POINTER(Config), C.POINTER(vp)],
         "rtpt_destroy": [vp],
+        "rtpt_resize": [vp, u32, u32, u32, u32],
         "rtpt_set_stream": [vp, vp],
         "rtpt_bind_plane": [vp, C.c_int, vp, sz],
         "rtpt_plane_ptr": [vp, C.c_int, C.POINTER(vp)],
@@ -220,6 +221,11 @@ class Context:
     @property
     def rows(self) -> int:
         return self.cfg.row_end - self.cfg.row_begin
+
+    def resize(self, width: int, height: int, row_begin: int = 0, row_end: int = 0):
+        _check(self._lib.rtpt_resize(self._h, width, height, row_begin, row_end))
+        self.cfg.width, self.cfg.height = width, height
+        self.cfg.row_begin, self.cfg.row_end = (row_begin, row_end) if (row_begin or row_end) else (0, height)
 
     # -- configuration
     def set_stream(self, stream_handle: int | None):

@@ -296,6 +296,46 @@ int rtpt_config_default(rtpt_config* cfg, uint32_t width, uint32_t height) {
   return RTPT_OK;
 }
 
+// (re)allocate every per-pixel plane for c->cfg's frame and row range and reset the frame state; the scene
+// (triangles, BVH, LUTs, tables) is untouched.  Caller-bound planes (rtpt_bind_plane) are dropped.
+static int alloc_planes(rtpt_ctx* c) {
+  const size_t px = c->pixels();
+  int rc = RTPT_OK;
+  for (int i = 0; i < 3 && rc == RTPT_OK; i++) rc = alloc_buf(c->color[i], px * 16);
+  for (int i = 0; i < 2 && rc == RTPT_OK; i++) rc = alloc_buf(c->vis[i], px * 4);
+  if (rc == RTPT_OK) rc = alloc_buf(c->worldpos, px * 16);
+  if (rc == RTPT_OK) rc = alloc_buf(c->gradient, px * 16);
+  if (rc == RTPT_OK) rc = alloc_buf(c->depth, px * 4);
+  if (rc == RTPT_OK && !c->raycount.ptr) rc = alloc_buf(c->raycount, 8);
+  if (rc == RTPT_OK && (c->debug_mask & RTPT_DEBUG_HIT_ID)) rc = alloc_buf(c->hit_id, px * 4);
+  if (rc == RTPT_OK && (c->debug_mask & RTPT_DEBUG_PREV_PIXEL)) rc = alloc_buf(c->prev_pixel, px * 8);
+  if (rc != RTPT_OK) return rc;
+  // Vulkan images start undefined; zero them so readback before the first frame is defined
+  for (int i = 0; i < 3; i++) (void)hipMemsetAsync(c->color[i].ptr, 0, px * 16, c->stream);
+  for (int i = 0; i < 2; i++) (void)hipMemsetAsync(c->vis[i].ptr, 0, px * 4, c->stream);
+  (void)hipMemsetAsync(c->worldpos.ptr, 0, px * 16, c->stream);
+  (void)hipMemsetAsync(c->gradient.ptr, 0, px * 16, c->stream);
+  (void)hipMemsetAsync(c->depth.ptr, 0, px * 4, c->stream);
+  (void)hipMemsetAsync(c->raycount.ptr, 0, 8, c->stream);
+  if (c->hit_id.ptr) (void)hipMemsetAsync(c->hit_id.ptr, 0, px * 4, c->stream);
+  if (c->prev_pixel.ptr) (void)hipMemsetAsync(c->prev_pixel.ptr, 0, px * 8, c->stream);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return fail(RTPT_E_DEVICE, std::string("initial clear: ") + hipGetErrorString(e));
+  for (int i = 0; i < 3; i++) {
+    c->color_of_role[i] = i;
+    c->alpha_depth[i] = false;
+  }
+  c->vis_cur = 0;
+  c->final_swapped = false;
+  c->image_alias = false;
+  c->hist_y0 = c->hist_y1 = 0;
+  c->final_y0 = c->final_y1 = 0;
+  c->ext_history = nullptr;
+  c->count_y0 = static_cast<int>(c->cfg.row_begin);
+  c->count_y1 = static_cast<int>(c->cfg.row_end);
+  return RTPT_OK;
+}
+
 int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   if (!cfg || !out) return fail(RTPT_E_INVALID, "NULL argument");
   *out = nullptr;
@@ -329,29 +369,10 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   c->stream = c->own_stream;
   c->count_y0 = static_cast<int>(cfg->row_begin);
   c->count_y1 = static_cast<int>(cfg->row_end);
-  const size_t px = c->pixels();
-  int rc = RTPT_OK;
-  for (int i = 0; i < 3 && rc == RTPT_OK; i++) rc = alloc_buf(c->color[i], px * 16);
-  for (int i = 0; i < 2 && rc == RTPT_OK; i++) rc = alloc_buf(c->vis[i], px * 4);
-  if (rc == RTPT_OK) rc = alloc_buf(c->worldpos, px * 16);
-  if (rc == RTPT_OK) rc = alloc_buf(c->gradient, px * 16);
-  if (rc == RTPT_OK) rc = alloc_buf(c->depth, px * 4);
-  if (rc == RTPT_OK) rc = alloc_buf(c->raycount, 8);
+  int rc = alloc_planes(c);
   if (rc != RTPT_OK) {
     rtpt_destroy(c);
     return rc;
-  }
-  // Vulkan images start undefined; zero them so readback before the first frame is defined
-  for (int i = 0; i < 3; i++) (void)hipMemsetAsync(c->color[i].ptr, 0, px * 16, c->stream);
-  for (int i = 0; i < 2; i++) (void)hipMemsetAsync(c->vis[i].ptr, 0, px * 4, c->stream);
-  (void)hipMemsetAsync(c->worldpos.ptr, 0, px * 16, c->stream);
-  (void)hipMemsetAsync(c->gradient.ptr, 0, px * 16, c->stream);
-  (void)hipMemsetAsync(c->depth.ptr, 0, px * 4, c->stream);
-  (void)hipMemsetAsync(c->raycount.ptr, 0, 8, c->stream);
-  e = hipStreamSynchronize(c->stream);
-  if (e != hipSuccess) {
-    rtpt_destroy(c);
-    return fail(RTPT_E_DEVICE, std::string("initial clear: ") + hipGetErrorString(e));
   }
   *out = c;
   return RTPT_OK;
@@ -374,6 +395,26 @@ int rtpt_destroy(rtpt_ctx* c) {
     free_buf(*b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+  return RTPT_OK;
+}
+
+int rtpt_resize(rtpt_ctx* c, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  if (row_begin == 0 && row_end == 0) row_end = height;
+  if (width == 0 || height == 0 || row_begin >= row_end || row_end > height) return fail(RTPT_E_INVALID, "bad frame / row range");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  rtpt_config old = c->cfg;
+  c->cfg.width = width;
+  c->cfg.height = height;
+  c->cfg.row_begin = row_begin;
+  c->cfg.row_end = row_end;
+  int rc = alloc_planes(c);
+  if (rc != RTPT_OK) {  // leave a usable context behind if the old size still fits
+    c->cfg = old;
+    (void)alloc_planes(c);
+    return rc;
+  }
   return RTPT_OK;
 }
 

@@ -386,6 +386,36 @@ def test_strips_equal_single_frame(hip_lib, oracle, cornell, mode):
     single.backend.close()
 
 
+def test_resize_keeps_scene_and_restarts_history(hip_lib, oracle, cornell):
+    """rtpt_resize (framebuffer resize, main.cpp:275-278/:1310): new planes, same scene; the frames after it equal
+    a freshly created context of the new size, whose first final pass has no history (frameNumber is the caller's)."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    app = make_app(96, 64, max_segments=3, iterations=3, debug_mask=hip_lib.DEBUG_HIT_ID | hip_lib.DEBUG_PREV_PIXEL)
+    app.drawScene()
+    app.drawScene()
+    ctx = app.backend.ctx
+    ctx.resize(160, 100)
+    assert ctx.readback(hip_lib.PLANE_PREVIOUS).shape == (100, 160, 4) and not ctx.readback(hip_lib.PLANE_PREVIOUS).any()
+    fresh = make_app(160, 100, max_segments=3, iterations=3, debug_mask=hip_lib.DEBUG_HIT_ID | hip_lib.DEBUG_PREV_PIXEL)
+    ref = oracle.OracleApp(160, 100, cornell[2], max_segments=3, iterations=3)
+    # drive the resized context with the fresh app's host state (same push constants / UBO for the new aspect)
+    resized = fresh.backend.ctx
+    fresh.backend.ctx = ctx
+    for f in range(3):
+        fresh.drawScene(("J",) if f == 1 else ())
+        fo = ref.draw_scene(move_light=(-0.1, 0, 0) if f == 1 else None)
+        assert np.array_equal(ctx.readback(hip_lib.PLANE_PREV_VIS_ID), fo.vis)
+        assert np.array_equal(ctx.readback(hip_lib.PLANE_HIT_ID), fo.hit_id)
+        ok, rel = l2_ok(ctx.readback(hip_lib.PLANE_PREVIOUS), fo.image)
+        assert ok, (f, rel)
+    with pytest.raises(hip_lib.RtptError):
+        ctx.resize(0, 10)
+    with pytest.raises(hip_lib.RtptError):
+        ctx.resize(64, 64, 10, 80)
+    resized.close()
+    app.backend.close()
+
+
 def test_errors(hip_lib, cornell):
     from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
     xyz, idx, _ = cornell
