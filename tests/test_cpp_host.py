@@ -33,13 +33,9 @@ def test_no_gpu_is_an_error(app_binary):
     assert out.returncode == 1 and "no CPU fallback" in out.stderr
 
 
-def read_pfm(path):
-    with open(path, "rb") as f:
-        assert f.readline().strip() == b"PF"
-        w, h = map(int, f.readline().split())
-        assert float(f.readline()) < 0  # little endian
-        data = np.frombuffer(f.read(), np.float32).reshape(h, w, 3)
-    return data[::-1]
+def read_pfm(path):  # the C++ host's --dump and output.py agree on the format
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.output import read_pfm as rd
+    return rd(str(path))
 
 
 @pytest.mark.gpu
