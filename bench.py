@@ -37,12 +37,13 @@ WORKLOADS = {
     # 8 segments (divergent-traversal stress; BVH path, direct filter kernel)
     "instanced": dict(width=3840, height=2160, max_segments=8, iterations=5, instanced=True),
 }
+PREWARM_SECONDS = 0.3
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # algorithmic bytes per pixel per launch (SURVEY.md 8d / BASELINE.md 3)
 BYTES_PER_PX = {"k_atrous": 40, "k_atrous_final": 72, "k_gradient": 36, "k_gbuffer": 24, "k_pathtrace": 16}
 
 
-def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=True):
+def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=True, in_flight=1):
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE, make_app
     extra = {}
     if wl.get("instanced"):
@@ -53,20 +54,32 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
                      lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
     app = make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"],
                    rank=rank, world=world, mode=args.halo,
-                   torch_planes=(dist is not None), **extra)
-    ctx = app.backend.ctx
+                   torch_planes=(dist is not None), frames_in_flight=in_flight, **extra)
+    ctxs = [b.ctx for b in app.backend.be] if in_flight == 2 else [app.backend.ctx]
+    ctx = ctxs[0]
+    collect_kernels = collect_kernels and in_flight == 1  # overlapping frames stretch every kernel's duration
 
     def fence():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    # device wake-up, untimed and before the W warm-up steps: a cold MI355X runs its first ~50 ms of kernels
+    # 20 % slower (in-process A/B: the first 400 frames of a 270-row strip take 0.212 ms each, every later batch
+    # 0.173 ms), which a 36 ms timed region at 8 ranks would otherwise measure instead of the kernels
+    t_wake = time.perf_counter()
+    while time.perf_counter() - t_wake < PREWARM_SECONDS:
+        for _ in range(8):
+            app.drawScene()
+        ctx.sync()
     for _ in range(warmup):
         app.drawScene()
     fence()
-    ctx.reset_counters()
+    for c in ctxs:
+        c.reset_counters()
     # per-kernel HIP events on the launch stream, sampled: bracketing every launch costs ~6 % of the frame
     timing_period = 8 if steps >= 32 else 1
     ctx.timing_enable(timing_period if collect_kernels else 0)
@@ -79,7 +92,7 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
     ctx.timing_enable(0)
     kern = ctx.timing_collect() if collect_kernels else {}
     timed_frames = max(1, len([f for f in range(steps) if f % timing_period == 0])) if collect_kernels else steps
-    rays = ctx.raycount()
+    rays = sum(c.raycount() for c in ctxs)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,6 +207,9 @@ def main():
     ap.add_argument("--emulate-strip", default=None, metavar="R/N",
                     help="diagnostic: this single process runs rank R's strip of an N-rank job (redundant halo, no "
                          "communication is needed while the camera rests) and prints its per-frame time")
+    ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=1,
+                    help="2: the timed run itself uses app.PipelinedBackend (no per-kernel timing, roofline null); "
+                         "the default run reports it under also.two_frames_in_flight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -224,12 +240,14 @@ def main():
     if args.emulate_strip:
         r, n = map(int, args.emulate_strip.split("/"))
         args.halo = "redundant"
-        elapsed, rays, kern, plan, timed_frames = run_gpu(wl, args, r, n, args.steps, args.warmup, torch, None)
-        print(json.dumps({"emulated_strip": args.emulate_strip, "rows_owned": plan.own, "rows_stored": plan.stored,
+        elapsed, rays, kern, plan, timed_frames = run_gpu(wl, args, r, n, args.steps, args.warmup, torch, None,
+                                                          in_flight=args.frames_in_flight)
+        _RESULT_LINE.append(json.dumps({"emulated_strip": args.emulate_strip, "rows_owned": plan.own, "rows_stored": plan.stored,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "rays_per_frame": rays / args.steps,
                           "kernels": kernel_report(kern, wl, plan, timed_frames)}))
         return
-    elapsed, rays, kern, plan, timed_frames = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist)
+    elapsed, rays, kern, plan, timed_frames = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist,
+                                                      in_flight=args.frames_in_flight)
     ms_per_step = elapsed / args.steps * 1e3
     result = None
     if rank == 0:
@@ -258,7 +276,8 @@ def main():
             "config": {"workload": f"cornell-{args.workload}-1spp-{wl['max_segments']}seg-{wl['iterations']}atrous",
                        "width": wl["width"], "height": wl["height"], "max_segments": wl["max_segments"],
                        "atrous_iterations": wl["iterations"], "triangles": 1152000 if wl.get("instanced") else 32,
-                       "parallelism": f"row-strips x{world}" + (f" ({args.halo} halo)" if world > 1 else "")},
+                       "parallelism": f"row-strips x{world}" + (f" ({args.halo} halo)" if world > 1 else ""),
+                       "frames_in_flight": args.frames_in_flight},
             "rays_per_frame": round(rays / args.steps, 1),
             "roofline": {"kernel": "k_atrous (one a-trous iteration, k < N)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -271,21 +290,48 @@ def main():
         if pt:
             result["pathtrace_kernel_mray_s"] = round(rays / args.steps / (pt["avg_us"] * 1e-6) / 1e6, 1)
 
+    if not args.no_secondary and args.frames_in_flight == 1:
+        # the same workload with two frames in flight (app.PipelinedBackend): throughput only, the per-kernel
+        # durations above come from the serial run because overlapping frames stretch every kernel
+        e3, r3, _, _, _ = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist, collect_kernels=False,
+                                  in_flight=2)
+        if rank == 0:
+            result.setdefault("also", {})["two_frames_in_flight"] = {
+                "value": round(r3 / e3 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e3 / args.steps * 1e3, 4),
+                "fps": round(args.steps / e3, 1)}
     if world == 1 and rank == 0 and not args.no_secondary and args.workload == "4k":
         e2, r2, k2, p2, tf2 = run_gpu(WORKLOADS["1080p"], args, 0, 1, args.steps, args.warmup, torch, None)
         kr2 = kernel_report(k2, WORKLOADS["1080p"], p2, tf2)
-        result["also"] = {"cornell-1080p-1spp-4seg-5atrous": {
+        result.setdefault("also", {})["cornell-1080p-1spp-4seg-5atrous"] = {
             "value": round(r2 / e2 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
             "atrous_GBps": kr2.get("k_atrous", {}).get("algorithmic_GBps"),
-            "atrous_frac": round(kr2.get("k_atrous", {}).get("algorithmic_GBps", 0) / HBM_PEAK_GBS, 4)}}
+            "atrous_frac": round(kr2.get("k_atrous", {}).get("algorithmic_GBps", 0) / HBM_PEAK_GBS, 4)}
     if world == 1 and rank == 0 and not args.no_cpu_baseline and not wl.get("instanced"):
         result["cpu_baseline"] = cpu_baseline(wl)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        _RESULT_LINE.append(json.dumps(result))
 
+
+def _main_with_clean_stdout():
+    """stdout carries exactly one JSON line: RCCL prints a version banner to fd 1 when its first communicator
+    comes up, so fd 1 points at stderr while the benchmark runs and is restored for the result line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        main()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+        if _RESULT_LINE:
+            print(_RESULT_LINE[0], flush=True)
+
+
+_RESULT_LINE = []
 
 if __name__ == "__main__":
-    main()
+    _main_with_clean_stdout()

@@ -193,6 +193,14 @@ int rtpt_plane_bytes(const rtpt_ctx* ctx, rtpt_plane which, size_t* bytes);
  * the context's own PREVIOUS plane.  NULL returns to the PREVIOUS plane. */
 int rtpt_set_external_history(rtpt_ctx* ctx, const void* device_ptr, uint32_t row_begin, uint32_t row_end);
 
+/* Two frames in flight.  The reference serialises everything with vkQueueWaitIdle (main.cpp:110-111); the only
+ * dependency between consecutive frames of this path is the final pass's history fetch, so a host may render
+ * even frames in one context and odd frames in another (each on its own stream) and hand the finished frame
+ * across: rtpt_stream_wait(ctx, other) makes everything submitted to `ctx` from now on start only after
+ * everything submitted to `other` so far has finished (an event, no host block); the history itself is passed
+ * with rtpt_set_external_history(ctx, <other's PREVIOUS plane>, ...).  Same device only. */
+int rtpt_stream_wait(rtpt_ctx* ctx, rtpt_ctx* other);
+
 /* ---- scene ---------------------------------------------------------------------------- */
 
 /* loadMesh's RT arrays (main.cpp:416-428: objVertices tightly packed xyz, objIndices u32) +

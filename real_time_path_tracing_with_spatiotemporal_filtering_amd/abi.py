@@ -78,7 +78,7 @@ assert C.sizeof(PushConstants) == 112 and C.sizeof(Ubo) == 384
 # every symbol include/rtpt.h declares (tests check the header and this list agree)
 SYMBOLS = [
     "rtpt_config_default", "rtpt_create", "rtpt_destroy", "rtpt_resize", "rtpt_last_error", "rtpt_set_stream", "rtpt_bind_plane",
-    "rtpt_plane_ptr", "rtpt_plane_bytes", "rtpt_set_external_history", "rtpt_scene_upload", "rtpt_gbuffer", "rtpt_temporal_gradient",
+    "rtpt_plane_ptr", "rtpt_plane_bytes", "rtpt_set_external_history", "rtpt_stream_wait", "rtpt_scene_upload", "rtpt_gbuffer", "rtpt_temporal_gradient",
     "rtpt_raytrace", "rtpt_temporal_filter", "rtpt_end_frame", "rtpt_sync", "rtpt_readback", "rtpt_set_plane",
     "rtpt_reset_counters", "rtpt_set_count_rows", "rtpt_enable_debug", "rtpt_timing_enable", "rtpt_timing_collect", "rtpt_kernel_name",
     "rtpt_selftest_math", "rtpt_selftest_trace", "rtpt_util_look_at", "rtpt_util_perspective", "rtpt_util_load_obj",
@@ -112,6 +112,7 @@ def load() -> C.CDLL:
         "rtpt_plane_ptr": [vp, C.c_int, C.POINTER(vp)],
         "rtpt_plane_bytes": [vp, C.c_int, C.POINTER(sz)],
         "rtpt_set_external_history": [vp, vp, u32, u32],
+        "rtpt_stream_wait": [vp, vp],
         "rtpt_scene_upload": [vp, vp, u32, vp, u32, vp, u32],
         "rtpt_gbuffer": [vp, C.POINTER(Ubo), u32, u32],
         "rtpt_temporal_gradient": [vp, C.POINTER(PushConstants), u32, u32],
@@ -246,6 +247,10 @@ class Context:
 
     def set_external_history(self, device_ptr: int | None, row_begin: int = 0, row_end: int = 0):
         _check(self._lib.rtpt_set_external_history(self._h, C.c_void_p(device_ptr or 0), row_begin, row_end))
+
+    def stream_wait(self, other: "Context"):
+        """work submitted to this context from now on starts after everything submitted to `other` so far"""
+        _check(self._lib.rtpt_stream_wait(self._h, other._h))
 
     def enable_debug(self, mask: int):
         _check(self._lib.rtpt_enable_debug(self._h, mask))

@@ -79,6 +79,7 @@ struct rtpt_ctx {
   int final_y0 = 0, final_y1 = 0;
   uint32_t debug_mask = 0;
   const void* ext_history = nullptr;  // rtpt_set_external_history
+  hipEvent_t handoff_event = nullptr; // rtpt_stream_wait(x, this): recorded on this context's stream
   int ext_hist_y0 = 0, ext_hist_y1 = 0;
   int count_y0 = 0, count_y1 = 0;  // rows counted into RAYCOUNT
 
@@ -387,6 +388,7 @@ int rtpt_destroy(rtpt_ctx* c) {
     (void)hipEventDestroy(t.stop);
   }
   for (auto& e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->handoff_event) (void)hipEventDestroy(c->handoff_event);
   for (auto& b : c->color) free_buf(b);
   for (auto& b : c->vis) free_buf(b);
   for (auto& b : c->lut) free_buf(b);
@@ -468,6 +470,17 @@ int rtpt_set_external_history(rtpt_ctx* c, const void* device_ptr, uint32_t row_
   c->ext_history = device_ptr;
   c->ext_hist_y0 = static_cast<int>(row_begin);
   c->ext_hist_y1 = static_cast<int>(row_end);
+  return RTPT_OK;
+}
+
+int rtpt_stream_wait(rtpt_ctx* c, rtpt_ctx* other) {
+  if (!c || !other) return fail(RTPT_E_INVALID, "NULL argument");
+  if (c == other || c->stream == other->stream) return RTPT_OK;  // one stream is already in order
+  if (c->device != other->device) return fail(RTPT_E_INVALID, "rtpt_stream_wait: the contexts are on different devices");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!other->handoff_event) HIP_TRY(hipEventCreateWithFlags(&other->handoff_event, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(other->handoff_event, other->stream));
+  HIP_TRY(hipStreamWaitEvent(c->stream, other->handoff_event, 0));
   return RTPT_OK;
 }
 

@@ -386,6 +386,41 @@ def test_strips_equal_single_frame(hip_lib, oracle, cornell, mode):
     single.backend.close()
 
 
+@pytest.mark.parametrize("exact", [0, 1])
+def test_two_frames_in_flight(hip_lib, oracle, cornell, exact):
+    """even/odd frames in two contexts on two streams, the finished frame handed across with rtpt_stream_wait +
+    rtpt_set_external_history: the same frames as the serial host (bit-exact with the exact filter)"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    w, h = 200, 120
+    app = make_app(w, h, max_segments=4, iterations=5, flags=exact, frames_in_flight=2)
+    ref = oracle.OracleApp(w, h, cornell[2], max_segments=4, iterations=5)
+    script = [((), None, None), ((), None, None), (("J",), None, (-0.1, 0, 0)), (("D",), (0.1, 0, 0), None),
+              (("E",), (0, 0.1, 0), None), ((), None, None), ((), None, None)]
+    outs = []
+    for keys, _, _ in script:   # enqueue everything first: the frames really overlap on the GPU
+        app.drawScene(keys)
+        outs.append(app.backend.prev.ctx.plane_ptr(hip_lib.PLANE_PREVIOUS))
+    # only the last two frames are still resident (one per context); check the whole history through them:
+    # the temporal blend makes frame f depend on every earlier frame
+    total = 0
+    for i, (keys, cam, light) in enumerate(script):
+        fo = ref.draw_scene(move_camera=cam, move_light=light)
+        total += fo.rays
+        if i == len(script) - 2:
+            before_last = fo.image
+    last = app.backend.final_image_rows(0, h)
+    prev = app.backend.cur.readback_rows(hip_lib.PLANE_PREVIOUS, 0, h)   # the frame before the last one
+    assert app.backend.raycount() == total
+    if exact:
+        assert np.array_equal(bits(last), bits(fo.image))
+        assert np.array_equal(bits(prev), bits(before_last))
+    else:
+        for got, want in ((last, fo.image), (prev, before_last)):
+            ok, rel = l2_ok(got, want)
+            assert ok, rel
+    app.backend.close()
+
+
 def test_resize_keeps_scene_and_restarts_history(hip_lib, oracle, cornell):
     """rtpt_resize (framebuffer resize, main.cpp:275-278/:1310): new planes, same scene; the frames after it equal
     a freshly created context of the new size, whose first final pass has no history (frameNumber is the caller's)."""

@@ -158,12 +158,18 @@ class OracleBackend:
     def final_image(self):
         return self.color[self.role[abi.PLANE_PREVIOUS]]
 
+    # two frames in flight (PipelinedBackend): history handed over from the other backend
+    def set_history_from(self, other, y0, y1):
+        import torch
+        self._hist_full = torch.from_numpy(other.color[other.role[abi.PLANE_PREVIOUS]])
+        self._ext = True
+
 
 W, H, SEG, N, FRAMES = 48, 40, 2, 5, 5
 KEYS = [(), ("J",), ("D",), ("E",), ()]   # light move, lateral and VERTICAL camera moves (history crosses strips), rest
 
 
-def _run_rank(rank, world, mode, port, out_dir, ext=0):
+def _run_rank(rank, world, mode, port, out_dir, ext=0, in_flight=1):
     import sys
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -172,7 +178,11 @@ def _run_rank(rank, world, mode, port, out_dir, ext=0):
     if world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     plan = StripPlan(H, world, rank, N, mode, ext)
-    be = OracleBackend(O, W, H, SEG, plan)
+    if in_flight == 2:
+        from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import PipelinedBackend
+        be = PipelinedBackend([OracleBackend(O, W, H, SEG, plan), OracleBackend(O, W, H, SEG, plan)])
+    else:
+        be = OracleBackend(O, W, H, SEG, plan)
     app = PathTracingApplication(be, W, H, N, plan)
     app.loadMesh(SCENE)
     app.buildAccelerationStructure()
@@ -180,8 +190,11 @@ def _run_rank(rank, world, mode, port, out_dir, ext=0):
     for f in range(FRAMES):
         app.drawScene(KEYS[f])
         o0, o1 = plan.own
-        frames.append(be.final_image()[o0:o1].copy())
-    np.savez(os.path.join(out_dir, f"{mode}{ext}_{world}_{rank}.npz"), *frames, rays=np.array([be.rays]))
+        last = be.prev if in_flight == 2 else be
+        frames.append(last.final_image()[o0:o1].copy())
+    rays = sum(b.rays for b in be.be) if in_flight == 2 else be.rays
+    tag = "p" if in_flight == 2 else ""
+    np.savez(os.path.join(out_dir, f"{mode}{ext}{tag}_{world}_{rank}.npz"), *frames, rays=np.array([rays]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -208,4 +221,22 @@ def test_gloo_ranks_reproduce_the_single_rank_frame(tmp_path, oracle, world, mod
         got = np.concatenate([p[f"arr_{f}"] for p in parts], axis=0)
         assert got.shape == want.shape == (H, W, 4)
         assert got.tobytes() == want.tobytes(), f"frame {f}: strips differ from the single-rank frame"
+    assert sum(int(p["rays"][0]) for p in parts) == int(ref["rays"][0])
+
+
+@pytest.mark.parametrize("world,mode", [(1, "redundant"), (2, "redundant"), (2, "exchange")])
+def test_two_frames_in_flight_equal_one(tmp_path, oracle, world, mode):
+    """PipelinedBackend (even/odd frames in two backends, history handed across) reproduces the serial frames,
+    alone and on two gloo ranks, including the frames in which the camera moves (history all-gather)"""
+    import torch.multiprocessing as mp
+    _run_rank(0, 1, mode, 0, str(tmp_path))
+    if world == 1:
+        _run_rank(0, 1, mode, 0, str(tmp_path), 0, 2)
+    else:
+        mp.spawn(_run_rank, args=(world, mode, _free_port(), str(tmp_path), 0, 2), nprocs=world, join=True)
+    ref = np.load(tmp_path / f"{mode}0_1_0.npz")
+    parts = [np.load(tmp_path / f"{mode}0p_{world}_{r}.npz") for r in range(world)]
+    for f in range(FRAMES):
+        got = np.concatenate([p[f"arr_{f}"] for p in parts], axis=0)
+        assert got.tobytes() == ref[f"arr_{f}"].tobytes(), f"frame {f}"
     assert sum(int(p["rays"][0]) for p in parts) == int(ref["rays"][0])
