@@ -62,13 +62,16 @@ void PathTracingApplication::createBuffers() {
   check(rtpt_config_default(&cfg, opt_.width, opt_.height), "rtpt_config_default");
   cfg.max_segments = opt_.max_segments;
   cfg.flags = opt_.flags;
-  check(rtpt_create(&cfg, &ctx_), "createBuffers");
+  if (opt_.frames_in_flight != 1 && opt_.frames_in_flight != 2) throw std::runtime_error("frames_in_flight must be 1 or 2");
+  for (int i = 0; i < opt_.frames_in_flight; i++) check(rtpt_create(&cfg, &ctxs_[i]), "createBuffers");
+  ctx_ = last_ = ctxs_[0];
 }
 
 void PathTracingApplication::buildAccelerationStructure() {
-  check(rtpt_scene_upload(ctx_, objVertices.data(), static_cast<uint32_t>(objVertices.size() / 3), objIndices.data(),
-                          static_cast<uint32_t>(objIndices.size() / 3), nullptr, 0),
-        "buildAccelerationStructure");
+  for (int i = 0; i < opt_.frames_in_flight; i++)
+    check(rtpt_scene_upload(ctxs_[i], objVertices.data(), static_cast<uint32_t>(objVertices.size() / 3), objIndices.data(),
+                            static_cast<uint32_t>(objIndices.size() / 3), nullptr, 0),
+          "buildAccelerationStructure");
 }
 
 void PathTracingApplication::initializeSceneConstants() {
@@ -130,6 +133,13 @@ void PathTracingApplication::applyTemporalFiltering() {
   pushConstants.maxWaveletIteration = opt_.maxWaveletIteration;   // :1258
   for (int k = 1; k <= opt_.maxWaveletIteration; k++) {           // :1259
     pushConstants.waveletIteration = k;                           // :1260
+    if (opt_.frames_in_flight == 2 && k == opt_.maxWaveletIteration && (k & 1) && frameCount > 0) {
+      // the blend reads the previous frame, which the other context finished (or is finishing) on its own stream
+      void* prev = nullptr;
+      check(rtpt_stream_wait(ctx_, last_), "rtpt_stream_wait");
+      check(rtpt_plane_ptr(last_, RTPT_PLANE_PREVIOUS, &prev), "rtpt_plane_ptr");
+      check(rtpt_set_external_history(ctx_, prev, 0, opt_.height), "rtpt_set_external_history");
+    }
     // the descriptor swap of :1264-1281 is the ping-pong rule inside rtpt_temporal_filter
     check(rtpt_temporal_filter(ctx_, &pushConstants, &ubo, 0, 0), "applyTemporalFiltering");
   }
@@ -137,6 +147,8 @@ void PathTracingApplication::applyTemporalFiltering() {
 
 void PathTracingApplication::copyImageToSwapChainsCurrentImage() {
   check(rtpt_end_frame(ctx_), "copyImageToSwapChainsCurrentImage");  // history hand-over, :1364-1372
+  last_ = ctx_;
+  ctx_ = ctxs_[(frameCount + 1) % static_cast<uint32_t>(opt_.frames_in_flight)];
 }
 
 void PathTracingApplication::drawScene(const std::string& keys) {
@@ -150,22 +162,32 @@ void PathTracingApplication::drawScene(const std::string& keys) {
 }
 
 void PathTracingApplication::freeRessources() {
-  if (ctx_) rtpt_destroy(ctx_);
-  ctx_ = nullptr;
+  for (auto& c : ctxs_) {
+    if (c) rtpt_destroy(c);
+    c = nullptr;
+  }
+  ctx_ = last_ = nullptr;
 }
 
-void PathTracingApplication::sync() { check(rtpt_sync(ctx_), "rtpt_sync"); }
+void PathTracingApplication::sync() {
+  for (int i = 0; i < opt_.frames_in_flight; i++) check(rtpt_sync(ctxs_[i]), "rtpt_sync");
+}
 
 std::vector<float> PathTracingApplication::readImage() {
   std::vector<float> img(static_cast<size_t>(opt_.width) * opt_.height * 4);
-  check(rtpt_readback(ctx_, RTPT_PLANE_IMAGE, img.data(), img.size() * sizeof(float)), "rtpt_readback");
+  // after rtpt_end_frame IMAGE and PREVIOUS hold the same pixels (main.cpp:1364)
+  check(rtpt_readback(last_, RTPT_PLANE_PREVIOUS, img.data(), img.size() * sizeof(float)), "rtpt_readback");
   return img;
 }
 
 uint64_t PathTracingApplication::rayCount() {
-  uint64_t n = 0;
-  check(rtpt_readback(ctx_, RTPT_PLANE_RAYCOUNT, &n, sizeof n), "rtpt_readback");
-  return n;
+  uint64_t total = 0;
+  for (int i = 0; i < opt_.frames_in_flight; i++) {
+    uint64_t n = 0;
+    check(rtpt_readback(ctxs_[i], RTPT_PLANE_RAYCOUNT, &n, sizeof n), "rtpt_readback");
+    total += n;
+  }
+  return total;
 }
 
 void PathTracingApplication::writePFM(const std::string& path) {

@@ -18,6 +18,7 @@ struct Options {
   int maxWaveletIteration = 9;          // main.cpp:55
   uint32_t max_segments = 32;           // raytrace.comp.glsl:204
   uint32_t flags = 0;
+  int frames_in_flight = 1;             // 2: even/odd frames in two contexts on two streams (rtpt_stream_wait)
   std::string scene;                    // scenes/CornellBox-Original-Merged.obj (main.cpp:417)
 };
 
@@ -59,7 +60,11 @@ class PathTracingApplication {
  private:
   void check(int rc, const char* what);
   Options opt_;
+  // frames_in_flight contexts; frame f is built in ctxs_[f % n].  ctx_ = the context of the frame being built
+  // (between frames: of the next frame); last_ = the context holding the last finished frame.
+  rtpt_ctx* ctxs_[2] = {nullptr, nullptr};
   rtpt_ctx* ctx_ = nullptr;
+  rtpt_ctx* last_ = nullptr;
   std::vector<float> objVertices;              // main.cpp:255
   std::vector<uint32_t> objIndices;            // main.cpp:256
   float cameraOrigin[3] = {-0.001f, 1.0f, 6.0f};  // main.cpp:65

@@ -15,6 +15,7 @@ static void usage(const char* argv0) {
   std::printf(
       "usage: %s [--width W] [--height H] [--frames N] [--segments S] [--iterations K]\n"
       "          [--scene file.obj] [--script \"keys0,keys1,...\"] [--dump out.pfm] [--exact-filter]\n"
+      "          [--frames-in-flight 1|2]\n"
       "          [--flags N   (RTPT_FLAG_* bits of include/rtpt.h, e.g. 0xF0 = all extension modes)]\n"
       "  keys per frame are the reference's GLFW keys: WASDQE move the camera, IJKLUO the light\n"
       "  defaults are the reference's constants: 1000x800, 32 segments, 9 iterations (main.cpp:52-55)\n",
@@ -46,6 +47,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--script")) script_arg = need("--script");
     else if (!std::strcmp(argv[i], "--dump")) dump = need("--dump");
     else if (!std::strcmp(argv[i], "--exact-filter")) opt.flags |= RTPT_FLAG_EXACT_FILTER;
+    else if (!std::strcmp(argv[i], "--frames-in-flight")) opt.frames_in_flight = std::atoi(need("--frames-in-flight"));
     else if (!std::strcmp(argv[i], "--flags") && i + 1 < argc) opt.flags |= static_cast<uint32_t>(std::strtoul(argv[++i], nullptr, 0));
     else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) { usage(argv[0]); return 0; }
     else { std::fprintf(stderr, "unknown option %s\n", argv[i]); usage(argv[0]); return 2; }
