@@ -66,6 +66,7 @@ struct rtpt_ctx {
   uint32_t n_tris = 0;
   Buf tris, leaf_order, isect_id, isect_leaf, shade, nodes;
   bool use_bvh = false;
+  rt::BvhGrid bvh_grid{};
   int bvh_depth = 0;
   std::vector<float> host_tris;  // flattened world-space triangles, kept for small scenes (screen bounds)
 
@@ -206,7 +207,11 @@ rt::SceneView scene_view(const rtpt_ctx* c) {
   s.isect_leaf = static_cast<const float4*>(c->isect_leaf.ptr);
   s.leaf_ids = static_cast<const uint32_t*>(c->leaf_order.ptr);
   s.shade = static_cast<const float4*>(c->shade.ptr);
-  s.nodes = static_cast<const rt::BvhNode*>(c->nodes.ptr);
+  s.nodes = static_cast<const rt::BvhNodeQ*>(c->nodes.ptr);
+  for (int a = 0; a < 3; a++) {
+    s.bvh_origin[a] = c->bvh_grid.origin[a];
+    s.bvh_cell[a] = c->bvh_grid.cell[a];
+  }
   s.n_tris = c->n_tris;
   s.use_bvh = c->use_bvh ? 1u : 0u;
   s.stack_depth = static_cast<uint32_t>(c->bvh_depth + 2 < 8 ? 8 : c->bvh_depth + 2);
@@ -543,14 +548,16 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   if ((rc = alloc_buf(c->isect_id, static_cast<size_t>(total) * 48))) return rc;
   if ((rc = alloc_buf(c->isect_leaf, static_cast<size_t>(total) * 48))) return rc;
   if ((rc = alloc_buf(c->shade, static_cast<size_t>(total) * 48))) return rc;
-  if ((rc = alloc_buf(c->nodes, bvh.nodes.size() * sizeof(rt::BvhNode)))) return rc;
+  std::vector<rt::BvhNodeQ> nodes_h;
+  c->bvh_grid = rt::pack_quantised_nodes(bvh, nodes_h);
+  if ((rc = alloc_buf(c->nodes, nodes_h.size() * sizeof(rt::BvhNodeQ)))) return rc;
   if ((rc = alloc_buf(c->normal_tab, (static_cast<size_t>(total) + 1) * 16))) return rc;
   if ((rc = alloc_buf(c->pair_tab, total + 1 <= 64 ? (static_cast<size_t>(total) + 1) * (total + 1) * 4 : 0))) return rc;
   for (int i = 0; i < 2; i++)
     if ((rc = alloc_buf(c->lut[i], (static_cast<size_t>(total) + 1) * sizeof(rtpt_visibility_data)))) return rc;
   HIP_TRY(hipMemcpyAsync(c->tris.ptr, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->leaf_order.ptr, bvh.leaf_order.data(), static_cast<size_t>(total) * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->nodes.ptr, bvh.nodes.data(), bvh.nodes.size() * sizeof(rt::BvhNode), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->nodes.ptr, nodes_h.data(), nodes_h.size() * sizeof(rt::BvhNodeQ), hipMemcpyHostToDevice, c->stream));
   for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(c->lut[i].ptr, 0, c->lut[i].bytes, c->stream));
   rt::ScenePrepArgs sp;
   sp.n_tris = total;

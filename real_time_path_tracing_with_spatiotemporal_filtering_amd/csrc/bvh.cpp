@@ -239,4 +239,63 @@ void build_bvh(const float* tris, uint32_t n, Bvh& out, float pad_rel) {
   (void)root;  // n > kBvhMaxLeaf: the root is interior and is node 0 by construction
 }
 
+
+BvhGrid pack_quantised_nodes(const Bvh& bvh, std::vector<BvhNodeQ>& out) {
+  double lo[3], hi[3];
+  for (int a = 0; a < 3; a++) {
+    lo[a] = bvh.scene_min[a];
+    hi[a] = bvh.scene_max[a];
+  }
+  for (const BvhNode& n : bvh.nodes)  // padded boxes exceed the scene bounds slightly
+    for (int a = 0; a < 3; a++) {
+      if (n.lidx != kBvhEmpty) {
+        lo[a] = std::min<double>(lo[a], n.lmin[a]);
+        hi[a] = std::max<double>(hi[a], n.lmax[a]);
+      }
+      if (n.ridx != kBvhEmpty) {
+        lo[a] = std::min<double>(lo[a], n.rmin[a]);
+        hi[a] = std::max<double>(hi[a], n.rmax[a]);
+      }
+    }
+  BvhGrid g;
+  double cell[3];
+  for (int a = 0; a < 3; a++) {
+    const double ext = std::max(hi[a] - lo[a], 1e-20);
+    // one grid step of slack at either end absorbs the binary32 rounding of origin and cell
+    g.cell[a] = static_cast<float>(ext / 65533.0);
+    g.origin[a] = static_cast<float>(lo[a] - static_cast<double>(g.cell[a]));
+    cell[a] = g.cell[a];
+  }
+  auto qdown = [&](float x, int a) -> uint16_t {
+    double q = std::floor((static_cast<double>(x) - static_cast<double>(g.origin[a])) / cell[a]);
+    // the decoded value origin + q*cell is formed in binary32 on the device: step down while it is not below x
+    while (q > 0 && static_cast<double>(g.origin[a]) + q * cell[a] > static_cast<double>(x)) q -= 1;
+    return static_cast<uint16_t>(std::min(65535.0, std::max(0.0, q)));
+  };
+  auto qup = [&](float x, int a) -> uint16_t {
+    double q = std::ceil((static_cast<double>(x) - static_cast<double>(g.origin[a])) / cell[a]);
+    while (q < 65535 && static_cast<double>(g.origin[a]) + q * cell[a] < static_cast<double>(x)) q += 1;
+    return static_cast<uint16_t>(std::min(65535.0, std::max(0.0, q)));
+  };
+  auto ref = [](uint32_t idx, uint32_t cnt) -> uint32_t {
+    if (idx == kBvhEmpty) return kBvhEmpty;
+    return cnt ? (0x80000000u | (idx << 2) | (cnt - 1u)) : idx;
+  };
+  out.resize(bvh.nodes.size());
+  for (size_t i = 0; i < bvh.nodes.size(); i++) {
+    const BvhNode& n = bvh.nodes[i];
+    BvhNodeQ& h = out[i];
+    const bool le = n.lidx == kBvhEmpty, re = n.ridx == kBvhEmpty;
+    for (int a = 0; a < 3; a++) {
+      h.box[a] = le ? 0 : qdown(n.lmin[a], a);
+      h.box[3 + a] = le ? 0 : qup(n.lmax[a], a);
+      h.box[6 + a] = re ? 0 : qdown(n.rmin[a], a);
+      h.box[9 + a] = re ? 0 : qup(n.rmax[a], a);
+    }
+    h.lref = ref(n.lidx, n.lcnt);
+    h.rref = ref(n.ridx, n.rcnt);
+  }
+  return g;
+}
+
 }  // namespace rt

@@ -101,10 +101,13 @@ __device__ __forceinline__ void closest_hit_brute_set(const SceneView& sc, unsig
   }
 }
 
-__device__ __forceinline__ bool slab(const float* mn, const float* mx, f3 inv, f3 oi, float tbest, float& tnear) {
-  float t0x = fmaf_(mn[0], inv.x, oi.x), t1x = fmaf_(mx[0], inv.x, oi.x);
-  float t0y = fmaf_(mn[1], inv.y, oi.y), t1y = fmaf_(mx[1], inv.y, oi.y);
-  float t0z = fmaf_(mn[2], inv.z, oi.z), t1z = fmaf_(mx[2], inv.z, oi.z);
+// slab test; the box corners arrive as 16-bit grid indices converted to float (bvh.hpp): inv carries the cell
+// size and oi the grid origin, so the distances are ordinary ray parameters
+__device__ __forceinline__ bool slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, f3 inv, f3 oi, float tbest,
+                                     float& tnear) {
+  float t0x = fmaf_(mnx, inv.x, oi.x), t1x = fmaf_(mxx, inv.x, oi.x);
+  float t0y = fmaf_(mny, inv.y, oi.y), t1y = fmaf_(mxy, inv.y, oi.y);
+  float t0z = fmaf_(mnz, inv.z, oi.z), t1z = fmaf_(mxz, inv.z, oi.z);
   float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
                              __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
   float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
@@ -124,26 +127,43 @@ __device__ __forceinline__ bool slab(const float* mn, const float* mx, f3 inv, f
 // reach a leaf wait at the loop exit and the wave tests leaves together.
 //   child reference: bit 31 clear = interior node index; bit 31 set = leaf, (first << 2) | (count - 1);
 //   kBvhEmpty = absent child; kSentinel = empty stack.
+// Nodes are 32 bytes (two dwordx4 per visit): boxes on the scene's 16-bit grid, rounded outward — they only
+// order and cull; the triangle test is binary32 on the exact records.
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kSentinel = 0xFFFFFFFEu;
 
-__device__ __forceinline__ uint32_t child_ref(uint32_t idx, uint32_t cnt) {
-  return cnt ? (kLeafBit | (idx << 2) | (cnt - 1u)) : idx;  // idx == kBvhEmpty stays kBvhEmpty (cnt == 0)
-}
-
 __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d, HitRec& h, uint32_t* stack,
                                                int tid) {
-  f3 inv{fast::rcp_(d.x), fast::rcp_(d.y), fast::rcp_(d.z)};
-  f3 oi{-o.x * inv.x, -o.y * inv.y, -o.z * inv.z};
+  // A ray with a NaN component cannot hit anything (every comparison of tri_test fails, D7) — but min/max drop
+  // NaNs, so every box would "pass" and that one lane would walk all of the scene: on the 1.15M-triangle lattice
+  // single frames took 38-47 ms instead of 6.3 because of a handful of such paths.
+  if (__builtin_isunordered(o.x, d.x) || __builtin_isunordered(o.y, d.y) || __builtin_isunordered(o.z, d.z)) return;
+  // A direction component that is exactly 0 (axis-parallel rays do occur: d = (0,0,1) was measured) would make
+  // that axis' slab distances inf - inf = NaN, which min/max drop: the axis stops culling and the ray visits
+  // every node ahead of it (34 755 node visits for one ray, 45 ms for the frame).  With |d| clamped to 1e-20 the
+  // distances are +-huge with the right signs — the padded boxes keep every face of a box the ray can hit
+  // further than the rounding error from the ray's coordinate — so the parallel axis culls correctly.
+  auto nz = [](float v) { return __builtin_fabsf(v) < 1e-20f ? __builtin_copysignf(1e-20f, v) : v; };
+  const f3 rd{fast::rcp_(nz(d.x)), fast::rcp_(nz(d.y)), fast::rcp_(nz(d.z))};
+  // x = origin + q * cell  =>  t = (x - o) / d = q * (cell / d) + (origin - o) / d
+  const f3 inv{sc.bvh_cell[0] * rd.x, sc.bvh_cell[1] * rd.y, sc.bvh_cell[2] * rd.z};
+  const f3 oi{(sc.bvh_origin[0] - o.x) * rd.x, (sc.bvh_origin[1] - o.y) * rd.y, (sc.bvh_origin[2] - o.z) * rd.z};
   int sp = 0;
   uint32_t cur = 0;  // root pair
   while (cur != kSentinel) {
     while (!(cur & kLeafBit)) {  // interior (kSentinel and kBvhEmpty have bit 31 set)
-      const BvhNode nd = sc.nodes[cur];
+      const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + cur);
+      const uint4 a = np[0], b = np[1];
+      const uint32_t cl = b.z, cr = b.w;
+      const float tb = h.t;
       float tl, tr;
-      const uint32_t cl = child_ref(nd.lidx, nd.lcnt), cr = child_ref(nd.ridx, nd.rcnt);
-      const bool hl = (cl != kBvhEmpty) && slab(nd.lmin, nd.lmax, inv, oi, h.t, tl);
-      const bool hr = (cr != kBvhEmpty) && slab(nd.rmin, nd.rmax, inv, oi, h.t, tr);
+      auto lo16 = [](uint32_t w) { return static_cast<float>(w & 0xFFFFu); };
+      auto hi16 = [](uint32_t w) { return static_cast<float>(w >> 16); };
+      // both boxes are tested unconditionally (an absent child holds a zero box) so that the node is two
+      // independent 16-byte loads, not a load, a branch on the reference and another load
+      const bool sl = slab(lo16(a.x), hi16(a.x), lo16(a.y), hi16(a.y), lo16(a.z), hi16(a.z), inv, oi, tb, tl);
+      const bool sr = slab(lo16(a.w), hi16(a.w), lo16(b.x), hi16(b.x), lo16(b.y), hi16(b.y), inv, oi, tb, tr);
+      const bool hl = sl & (cl != kBvhEmpty), hr = sr & (cr != kBvhEmpty);
       if (hl && hr) {
         const bool left_first = tl <= tr;
         stack[sp * kThreads + tid] = left_first ? cr : cl;

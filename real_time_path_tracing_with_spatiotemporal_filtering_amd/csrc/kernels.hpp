@@ -17,7 +17,8 @@ struct SceneView {
   const float4* isect_leaf;  // BVH leaf order
   const uint32_t* leaf_ids;  // triangle id of each leaf slot
   const float4* shade;       // id order
-  const BvhNode* nodes;
+  const BvhNodeQ* nodes;     // 32-byte child-pair nodes, boxes on a 16-bit grid (bvh.hpp)
+  float bvh_origin[3], bvh_cell[3];
   uint32_t n_tris;
   uint32_t use_bvh;  // 0: brute force over isect_id, 1: BVH traversal
   uint32_t stack_depth;  // BVH traversal stack entries per lane (tree depth + 2)

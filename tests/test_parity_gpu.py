@@ -533,11 +533,25 @@ def test_bvh_million_triangle_rays(hip_lib, oracle, cornell):
     d = rng.normal(size=(n, 3))
     d[: n // 2] = np.array([0, 0, -1.0]) + rng.uniform(-0.2, 0.2, (n // 2, 3))  # camera-like bundle
     d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # axis-parallel directions (a component exactly 0: the slab test must still cull on that axis — one ray with
+    # d = (0,0,1) once cost a frame 45 ms), directions with a NaN (cannot hit, must not walk the scene), and rays
+    # lying in the plane of a wall
+    axis = np.array([[0, 0, 1], [0, 0, -1], [0, 1, 0], [0, -1, 0], [1, 0, 0], [-1, 0, 0], [0, 0.6, 0.8], [0.6, 0, -0.8]], np.float32)
+    k = 256
+    d[n - k:] = axis[np.arange(k) % len(axis)]
+    d[n - 8:n - 4, 0] = np.nan
+    o[n - 4:] = np.float32(np.nan)
     rays = np.concatenate([o, d], 1).astype(np.float32)
+    import time
     with hip_lib.Context(hip_lib.config_default(64, 64)) as ctx:
         ctx.scene_upload(vx, ti, xf)
         ids, ts = ctx.selftest_trace(rays)
+        t0 = time.perf_counter()
+        ids, ts = ctx.selftest_trace(rays)
+        dt = time.perf_counter() - t0
     want_ids, want_ts = oracle.trace_rays(tris, rays)
     assert np.array_equal(ids, want_ids)
     assert np.array_equal(bits(ts), bits(want_ts))
     assert (ids > 0).mean() > 0.5 and ids.max() > 1_000_000
+    assert (ids[n - 8:] == 0).all(), "NaN rays hit nothing"
+    assert dt < 0.02, f"1536 rays took {dt * 1e3:.1f} ms: some ray is walking the whole tree"
