@@ -408,10 +408,18 @@ struct PathState {  // SoA in LDS, one slot per thread
 
 template <bool BVH, bool COMPACT>
 __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
-  extern __shared__ uint32_t stack[];  // BVH: stack_depth x 256 entries (dynamic); unused otherwise
-  __shared__ PathState st;
-  __shared__ float sum_r[kThreads], sum_g[kThreads], sum_b[kThreads];  // per pixel, only used when spp > 1
-  __shared__ uint32_t rng_pix[kThreads];                                // per pixel RNG state between samples
+  // dynamic LDS, two tenants that are never live together: the BVH node stack (stack_depth x 256 entries, only
+  // inside closest_hit) and the compaction exchange buffer (only between the barriers of the compaction step).
+  // Sharing it takes the BVH kernel from 41 to 30 KB per block: 5 instead of 3 resident blocks per CU for a
+  // kernel that PMC shows waiting on memory for 78 % of its wave-cycles.
+  extern __shared__ __attribute__((aligned(16))) uint32_t stack[];
+  PathState& st = *reinterpret_cast<PathState*>(stack);
+  // per-pixel sample accumulators and RNG state between samples: behind the shared region, allocated (by
+  // launch_pathtrace) only when spp > 1 — the reference runs 1 spp (raytrace.comp.glsl:306)
+  float* const sum_r = reinterpret_cast<float*>(stack + a.multi_off);
+  float* const sum_g = sum_r + kThreads;
+  float* const sum_b = sum_g + kThreads;
+  uint32_t* const rng_pix = reinterpret_cast<uint32_t*>(sum_b + kThreads);
   __shared__ uint32_t wave_cnt[kBlockY];
   __shared__ unsigned int block_rays;
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
   {
     const int x = tile_x0 + static_cast<int>(lane), y = tile_y0 + wave;
     rng = exact::rng_seed(static_cast<uint32_t>(x), static_cast<uint32_t>(y), a.frame, a.batch);  // :297
-    sum_r[tid] = sum_g[tid] = sum_b[tid] = 0.0f;
+    if (a.spp > 1) sum_r[tid] = sum_g[tid] = sum_b[tid] = 0.0f;
   }
   for (uint32_t smp = 0; smp < a.spp; smp++) {
     // ---- primary rays: thread tid <-> pixel tid (mapping restored at the start of every sample)
@@ -620,16 +628,21 @@ void launch_gradient(const GradientArgs& a, hipStream_t s) {
 void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;
   dim3 block(kBlockX, kBlockY);
+  const size_t stack_bytes = a.scene.use_bvh ? static_cast<size_t>(a.scene.stack_depth) * kThreads * 4 : 0;
+  size_t dyn = stack_bytes > sizeof(PathState) ? stack_bytes : sizeof(PathState);  // shared by both tenants
+  PathtraceArgs b = a;
+  b.multi_off = static_cast<uint32_t>(dyn / 4);
+  if (a.spp > 1) dyn += 4 * kThreads * 4;  // sum_r, sum_g, sum_b, rng_pix
   if (a.compact) {
     if (a.scene.use_bvh)
-      hipLaunchKernelGGL((k_pathtrace<true, true>), grid_for(a.g), block, a.scene.stack_depth * kThreads * 4, s, a);
+      hipLaunchKernelGGL((k_pathtrace<true, true>), grid_for(a.g), block, dyn, s, b);
     else
-      hipLaunchKernelGGL((k_pathtrace<false, true>), grid_for(a.g), block, 0, s, a);
+      hipLaunchKernelGGL((k_pathtrace<false, true>), grid_for(a.g), block, dyn, s, b);
   } else {
     if (a.scene.use_bvh)
-      hipLaunchKernelGGL((k_pathtrace<true, false>), grid_for(a.g), block, a.scene.stack_depth * kThreads * 4, s, a);
+      hipLaunchKernelGGL((k_pathtrace<true, false>), grid_for(a.g), block, dyn, s, b);
     else
-      hipLaunchKernelGGL((k_pathtrace<false, false>), grid_for(a.g), block, 0, s, a);
+      hipLaunchKernelGGL((k_pathtrace<false, false>), grid_for(a.g), block, dyn, s, b);
   }
 }
 void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s) {

@@ -92,6 +92,7 @@ struct PathtraceArgs {
   int32_t count_y0, count_y1;  // rows whose queries are counted
   int32_t compact;             // 1: compact surviving paths to the front of the block after every segment
   int32_t cull;                // 1: bounds[] is valid for the primary segment
+  uint32_t multi_off;          // dword offset of the spp > 1 accumulators in dynamic LDS (set by launch_pathtrace)
   TriBounds bounds[kCullMaxTris];
 };
 
