@@ -71,7 +71,7 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
     # 20 % slower (in-process A/B: the first 400 frames of a 270-row strip take 0.212 ms each, every later batch
     # 0.173 ms), which a 36 ms timed region at 8 ranks would otherwise measure instead of the kernels
     t_wake = time.perf_counter()
-    while time.perf_counter() - t_wake < PREWARM_SECONDS:
+    while time.perf_counter() - t_wake < args.prewarm_seconds:
         for _ in range(8):
             app.drawScene()
         ctx.sync()
@@ -207,9 +207,16 @@ def main():
     ap.add_argument("--emulate-strip", default=None, metavar="R/N",
                     help="diagnostic: this single process runs rank R's strip of an N-rank job (redundant halo, no "
                          "communication is needed while the camera rests) and prints its per-frame time")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a single GPU: every rank uses device 0 and torch.distributed runs "
+                         "on gloo (RCCL refuses two ranks on one device); exercises strips, halo exchange and the "
+                         "timing protocol, not the interconnect")
     ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=1,
                     help="2: the timed run itself uses app.PipelinedBackend (no per-kernel timing, roofline null); "
                          "the default run reports it under also.two_frames_in_flight")
+    ap.add_argument("--prewarm-seconds", type=float, default=PREWARM_SECONDS,
+                    help="untimed device wake-up before the W warm-up steps (0 makes the rendered frame numbers, and "
+                         "with them the ray counts, a function of --steps/--warmup only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -226,6 +233,8 @@ def main():
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_dist:
@@ -234,7 +243,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
     if args.emulate_strip:
