@@ -133,7 +133,7 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kSentinel = 0xFFFFFFFEu;
 
 __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d, HitRec& h, uint32_t* stack,
-                                               int tid) {
+                                               int tid, int nt = kThreads) {
   // A ray with a NaN component cannot hit anything (every comparison of tri_test fails, D7) — but min/max drop
   // NaNs, so every box would "pass" and that one lane would walk all of the scene: on the 1.15M-triangle lattice
   // single frames took 38-47 ms instead of 6.3 because of a handful of such paths.
@@ -166,7 +166,7 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
       const bool hl = sl & (cl != kBvhEmpty), hr = sr & (cr != kBvhEmpty);
       if (hl && hr) {
         const bool left_first = tl <= tr;
-        stack[sp * kThreads + tid] = left_first ? cr : cl;
+        stack[sp * nt + tid] = left_first ? cr : cl;
         sp++;
         cur = left_first ? cl : cr;
       } else if (hl) {
@@ -175,7 +175,7 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
         cur = cr;
       } else if (sp > 0) {
         sp--;
-        cur = stack[sp * kThreads + tid];
+        cur = stack[sp * nt + tid];
       } else {
         cur = kSentinel;
       }
@@ -188,7 +188,7 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
       }
       if (sp > 0) {
         sp--;
-        cur = stack[sp * kThreads + tid];
+        cur = stack[sp * nt + tid];
       } else {
         cur = kSentinel;
       }
@@ -197,9 +197,10 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
 }
 
 template <bool BVH>
-__device__ __forceinline__ void closest_hit(const SceneView& sc, f3 o, f3 d, HitRec& h, uint32_t* stack, int tid) {
+__device__ __forceinline__ void closest_hit(const SceneView& sc, f3 o, f3 d, HitRec& h, uint32_t* stack, int tid,
+                                            int nt = kThreads) {
   if (BVH)
-    closest_hit_bvh(sc, o, d, h, stack, tid);
+    closest_hit_bvh(sc, o, d, h, stack, tid, nt);
   else
     closest_hit_brute(sc, o, d, h);
 }
@@ -398,16 +399,25 @@ __device__ __forceinline__ f3 sky_color(f3 d) {  // raytrace.comp.glsl:95-107
 // regeneration scheme — finished lanes pick up new pixels — was also built and measured: it mixes
 // primary and secondary rays in every wave, loses the coherent, culled primary segment and ran
 // 1.5x slower at 4 segments; it is not kept.)
+// K2 tile: 64 x kPtRows pixels per workgroup.  More paths compacted together shrink the share of the half-empty
+// last wave of every later segment, but every compaction is a workgroup barrier on the slowest wave.  Swept at
+// 4K (Cornell 4 segments / 1.15M triangles 8 segments, k_pathtrace): 2 rows 862 us / 4.18 ms, 3 rows 569 / 4.04,
+// 4 rows 517 / 3.99, 8 rows 540 / 4.23, 16 rows 728 / 5.80.
+#ifndef RTPT_PT_ROWS
+#define RTPT_PT_ROWS 4
+#endif
+constexpr int kPtRows = RTPT_PT_ROWS;
+constexpr int kPtThreads = kBlockX * kPtRows;
 struct PathState {  // SoA in LDS, one slot per thread
-  uint32_t pix[kThreads];   // local pixel index (ty*64 + tx)
-  uint32_t rng[kThreads];
-  float ox[kThreads], oy[kThreads], oz[kThreads];
-  float dx[kThreads], dy[kThreads], dz[kThreads];
-  float ar[kThreads], ag[kThreads], ab[kThreads];
+  uint32_t pix[kPtThreads];   // local pixel index (ty*64 + tx)
+  uint32_t rng[kPtThreads];
+  float ox[kPtThreads], oy[kPtThreads], oz[kPtThreads];
+  float dx[kPtThreads], dy[kPtThreads], dz[kPtThreads];
+  float ar[kPtThreads], ag[kPtThreads], ab[kPtThreads];
 };
 
 template <bool BVH, bool COMPACT>
-__global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
+__global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
   // dynamic LDS, two tenants that are never live together: the BVH node stack (stack_depth x 256 entries, only
   // inside closest_hit) and the compaction exchange buffer (only between the barriers of the compaction step).
   // Sharing it takes the BVH kernel from 41 to 30 KB per block: 5 instead of 3 resident blocks per CU for a
@@ -417,16 +427,16 @@ __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
   // per-pixel sample accumulators and RNG state between samples: behind the shared region, allocated (by
   // launch_pathtrace) only when spp > 1 — the reference runs 1 spp (raytrace.comp.glsl:306)
   float* const sum_r = reinterpret_cast<float*>(stack + a.multi_off);
-  float* const sum_g = sum_r + kThreads;
-  float* const sum_b = sum_g + kThreads;
-  uint32_t* const rng_pix = reinterpret_cast<uint32_t*>(sum_b + kThreads);
-  __shared__ uint32_t wave_cnt[kBlockY];
+  float* const sum_g = sum_r + kPtThreads;
+  float* const sum_b = sum_g + kPtThreads;
+  uint32_t* const rng_pix = reinterpret_cast<uint32_t*>(sum_b + kPtThreads);
+  __shared__ uint32_t wave_cnt[kPtRows];
   __shared__ unsigned int block_rays;
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   const uint32_t lane = threadIdx.x;
   if (tid == 0) block_rays = 0;
-  const int tile_x0 = blockIdx.x * kBlockX, tile_y0 = a.g.y0 + blockIdx.y * kBlockY;
+  const int tile_x0 = blockIdx.x * kBlockX, tile_y0 = a.g.y0 + blockIdx.y * kPtRows;
   const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
   const f3 light_c = ld3(a.light_c);
   unsigned int rays = 0;
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
         if (!BVH && a.cull && seg == 0)
           closest_hit_brute_set(a.scene, cand, o, d, h);
         else
-          closest_hit<BVH>(a.scene, o, d, h, stack, tid);  // :208-222
+          closest_hit<BVH>(a.scene, o, d, h, stack, tid, kPtThreads);  // :208-222
         const int x = tile_x0 + static_cast<int>(pix & 63u), y = tile_y0 + static_cast<int>(pix >> 6);
         if (y >= a.count_y0 && y < a.count_y1) rays++;
         const size_t gi = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(kThreads) void k_pathtrace(PathtraceArgs a) {
       __syncthreads();
       uint32_t base = 0, total = 0;
 #pragma unroll
-      for (int w = 0; w < kBlockY; w++) {
+      for (int w = 0; w < kPtRows; w++) {
         const uint32_t c = wave_cnt[w];
         if (w < wave) base += c;
         total += c;
@@ -627,22 +637,23 @@ void launch_gradient(const GradientArgs& a, hipStream_t s) {
 }
 void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;
-  dim3 block(kBlockX, kBlockY);
-  const size_t stack_bytes = a.scene.use_bvh ? static_cast<size_t>(a.scene.stack_depth) * kThreads * 4 : 0;
+  dim3 block(kBlockX, kPtRows);
+  const dim3 grid((a.g.W + kBlockX - 1) / kBlockX, (a.g.y1 - a.g.y0 + kPtRows - 1) / kPtRows, 1);
+  const size_t stack_bytes = a.scene.use_bvh ? static_cast<size_t>(a.scene.stack_depth) * kPtThreads * 4 : 0;
   size_t dyn = stack_bytes > sizeof(PathState) ? stack_bytes : sizeof(PathState);  // shared by both tenants
   PathtraceArgs b = a;
   b.multi_off = static_cast<uint32_t>(dyn / 4);
-  if (a.spp > 1) dyn += 4 * kThreads * 4;  // sum_r, sum_g, sum_b, rng_pix
+  if (a.spp > 1) dyn += 4 * kPtThreads * 4;  // sum_r, sum_g, sum_b, rng_pix
   if (a.compact) {
     if (a.scene.use_bvh)
-      hipLaunchKernelGGL((k_pathtrace<true, true>), grid_for(a.g), block, dyn, s, b);
+      hipLaunchKernelGGL((k_pathtrace<true, true>), grid, block, dyn, s, b);
     else
-      hipLaunchKernelGGL((k_pathtrace<false, true>), grid_for(a.g), block, dyn, s, b);
+      hipLaunchKernelGGL((k_pathtrace<false, true>), grid, block, dyn, s, b);
   } else {
     if (a.scene.use_bvh)
-      hipLaunchKernelGGL((k_pathtrace<true, false>), grid_for(a.g), block, dyn, s, b);
+      hipLaunchKernelGGL((k_pathtrace<true, false>), grid, block, dyn, s, b);
     else
-      hipLaunchKernelGGL((k_pathtrace<false, false>), grid_for(a.g), block, dyn, s, b);
+      hipLaunchKernelGGL((k_pathtrace<false, false>), grid, block, dyn, s, b);
   }
 }
 void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s) {
