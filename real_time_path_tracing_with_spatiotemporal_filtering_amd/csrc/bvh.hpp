@@ -11,7 +11,18 @@
 namespace rt {
 
 constexpr uint32_t kBvhEmpty = 0xFFFFFFFFu;
-constexpr int kBvhMaxLeaf = 4;    // triangles per leaf
+#ifndef RTPT_BVH_MAX_LEAF
+#define RTPT_BVH_MAX_LEAF 4
+#endif
+#ifndef RTPT_BVH_MIN_LEAF
+#define RTPT_BVH_MIN_LEAF 1
+#endif
+#ifndef RTPT_BVH_NODE_COST
+#define RTPT_BVH_NODE_COST 1.5f
+#endif
+constexpr int kBvhMinLeaf = RTPT_BVH_MIN_LEAF;  // groups this small are always leaves
+constexpr float kNodeCost = RTPT_BVH_NODE_COST;  // cost of a node visit in triangle tests (SAH leaf decision)
+constexpr int kBvhMaxLeaf = RTPT_BVH_MAX_LEAF;  // triangles per leaf (the leaf reference encodes count - 1 in 2 bits)
 constexpr int kBvhMaxDepth = 48;  // traversal stack capacity (entries per lane)
 
 // 64 bytes.  A child with cnt > 0 is a leaf: idx = offset of its first record in leaf order.

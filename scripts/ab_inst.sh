@@ -6,7 +6,7 @@ mkdir -p gpurun_out/ab
 i=0
 for V in "$@"; do
   i=$((i+1))
-  touch $PKG/csrc/*.hip
+  touch $PKG/csrc/*.hip $PKG/csrc/*.cpp
   make -s -C $PKG/csrc "EXTRA=$V" > gpurun_out/ab/build_$i.log 2>&1 || { echo "build '$V' failed"; tail -5 gpurun_out/ab/build_$i.log; exit 1; }
   echo "== $V"
   timeout -k 10 200 python3 bench.py --workload instanced --steps 30 --warmup 3 --no-cpu-baseline --no-secondary | python3 -c "
