@@ -285,6 +285,13 @@ void rtpt_util_perspective(float fovy, float aspect, float z_near, float z_far, 
  * polygons fan-triangulated (0,1,2),(0,2,3) in file order (D5).  Two-call pattern: pass NULL
  * arrays to obtain counts. */
 int rtpt_util_load_obj(const char* path, float* xyz, uint32_t* n_verts, uint32_t* idx, uint32_t* n_tris);
+/* Host-only self check of the acceleration-structure builder that stands in for the driver's BLAS/TLAS build
+ * (buildAccelerationStructure, main.cpp:687-742): builds the BVH over `n_tris` world-space triangles (9 floats
+ * each), packs the device nodes and verifies the invariants the traversal relies on.  Needs no GPU.
+ *   stats[0] nodes, [1] leaves, [2] max depth, [3] largest leaf,
+ *   [4] triangles not referenced exactly once, [5] boxes that do not contain their subtree,
+ *   [6] device (16-bit grid) boxes that do not contain the binary32 box, [7] dangling child references */
+int rtpt_util_bvh_check(const float* tris, uint32_t n_tris, uint64_t stats[8]);
 
 #ifdef __cplusplus
 }

@@ -81,7 +81,7 @@ SYMBOLS = [
     "rtpt_plane_ptr", "rtpt_plane_bytes", "rtpt_set_external_history", "rtpt_stream_wait", "rtpt_scene_upload", "rtpt_gbuffer", "rtpt_temporal_gradient",
     "rtpt_raytrace", "rtpt_temporal_filter", "rtpt_end_frame", "rtpt_sync", "rtpt_readback", "rtpt_set_plane",
     "rtpt_reset_counters", "rtpt_set_count_rows", "rtpt_enable_debug", "rtpt_timing_enable", "rtpt_timing_collect", "rtpt_kernel_name",
-    "rtpt_selftest_math", "rtpt_selftest_trace", "rtpt_util_look_at", "rtpt_util_perspective", "rtpt_util_load_obj",
+    "rtpt_selftest_math", "rtpt_selftest_trace", "rtpt_util_look_at", "rtpt_util_perspective", "rtpt_util_load_obj", "rtpt_util_bvh_check",
 ]
 
 _lib = None
@@ -130,6 +130,7 @@ def load() -> C.CDLL:
         "rtpt_selftest_math": [vp, C.c_int, vp, vp, sz],
         "rtpt_selftest_trace": [vp, vp, sz, vp, vp],
         "rtpt_util_load_obj": [C.c_char_p, vp, C.POINTER(u32), vp, C.POINTER(u32)],
+        "rtpt_util_bvh_check": [vp, u32, C.POINTER(C.c_uint64 * 8)],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -336,3 +337,12 @@ class Context:
         ts = np.zeros(len(rays), np.float32)
         _check(self._lib.rtpt_selftest_trace(self._h, _ptr(rays), len(rays), _ptr(ids), _ptr(ts)))
         return ids, ts
+
+
+def bvh_check(tris: np.ndarray) -> dict:
+    """host-only self check of the BVH builder + device node packing (needs no GPU): see rtpt_util_bvh_check"""
+    tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
+    st = (C.c_uint64 * 8)()
+    _check(load().rtpt_util_bvh_check(_ptr(tris), len(tris), C.byref(st)))
+    keys = ("nodes", "leaves", "max_depth", "largest_leaf", "bad_triangle_refs", "loose_boxes", "loose_device_boxes", "bad_child_refs")
+    return dict(zip(keys, (int(v) for v in st)))

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cfloat>
 #include <cstring>
 #include <new>
 #include <string>
@@ -1031,6 +1032,100 @@ void rtpt_util_perspective(float fovy, float aspect, float zn, float zf, float m
   m[10] = zf / (zn - zf);
   m[11] = -1.0f;
   m[14] = -(zf * zn) / (zf - zn);
+}
+
+int rtpt_util_bvh_check(const float* tris, uint32_t n, uint64_t stats[8]) {
+  if (!tris || !stats || n == 0) return fail(RTPT_E_INVALID, "NULL argument / empty scene");
+  rt::Bvh bvh;
+  rt::build_bvh(tris, n, bvh);
+  std::vector<rt::BvhNodeQ> q;
+  const rt::BvhGrid g = rt::pack_quantised_nodes(bvh, q);
+  for (int i = 0; i < 8; i++) stats[i] = 0;
+  stats[0] = bvh.nodes.size();
+  stats[2] = static_cast<uint64_t>(bvh.max_depth);
+  std::vector<uint32_t> seen(n, 0);
+  if (bvh.leaf_order.size() != n) stats[4] += 1;
+  for (uint32_t id : bvh.leaf_order) {
+    if (id >= n) {
+      stats[4]++;
+      continue;
+    }
+    seen[id]++;
+  }
+  for (uint32_t i = 0; i < n; i++)
+    if (seen[i] != 1) stats[4]++;
+  struct Item { uint32_t node; };
+  // bounds of a subtree = union of the triangles below it: computed bottom-up by recursion with an explicit stack
+  struct Bounds { float mn[3], mx[3]; };
+  auto tri_bounds = [&](uint32_t first, uint32_t cnt) {
+    Bounds b{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+    for (uint32_t j = 0; j < cnt; j++) {
+      const uint32_t id = bvh.leaf_order[first + j];
+      for (int v = 0; v < 3; v++)
+        for (int a = 0; a < 3; a++) {
+          const float x = tris[9 * static_cast<size_t>(id) + 3 * v + a];
+          b.mn[a] = std::min(b.mn[a], x);
+          b.mx[a] = std::max(b.mx[a], x);
+        }
+    }
+    return b;
+  };
+  std::vector<Bounds> sub(bvh.nodes.size());
+  std::vector<uint8_t> done(bvh.nodes.size(), 0);
+  std::vector<uint32_t> st{0};
+  while (!st.empty()) {
+    const uint32_t ni = st.back();
+    const rt::BvhNode& nd = bvh.nodes[ni];
+    bool ready = true;
+    for (int side = 0; side < 2; side++) {
+      const uint32_t idx = side ? nd.ridx : nd.lidx, cnt = side ? nd.rcnt : nd.lcnt;
+      if (idx == rt::kBvhEmpty || cnt) continue;
+      if (idx >= bvh.nodes.size()) {
+        stats[7]++;
+        continue;
+      }
+      if (!done[idx]) {
+        st.push_back(idx);
+        ready = false;
+      }
+    }
+    if (!ready) continue;
+    st.pop_back();
+    Bounds me{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+    for (int side = 0; side < 2; side++) {
+      const uint32_t idx = side ? nd.ridx : nd.lidx, cnt = side ? nd.rcnt : nd.lcnt;
+      const float* bmn = side ? nd.rmin : nd.lmin;
+      const float* bmx = side ? nd.rmax : nd.lmax;
+      if (idx == rt::kBvhEmpty) continue;
+      Bounds cb;
+      if (cnt) {
+        stats[1]++;
+        stats[3] = std::max<uint64_t>(stats[3], cnt);
+        if (cnt > static_cast<uint32_t>(rt::kBvhMaxLeaf) || static_cast<uint64_t>(idx) + cnt > n) {
+          stats[7]++;
+          continue;
+        }
+        cb = tri_bounds(idx, cnt);
+      } else {
+        if (idx >= bvh.nodes.size()) continue;
+        cb = sub[idx];
+      }
+      for (int a = 0; a < 3; a++) {
+        if (!(bmn[a] <= cb.mn[a] && bmx[a] >= cb.mx[a])) stats[5]++;
+        // the device box: origin + q * cell, evaluated as the traversal's arithmetic implies (binary32)
+        const float qlo = g.origin[a] + static_cast<float>(q[ni].box[(side ? 6 : 0) + a]) * g.cell[a];
+        const float qhi = g.origin[a] + static_cast<float>(q[ni].box[(side ? 9 : 3) + a]) * g.cell[a];
+        if (!(qlo <= bmn[a] && qhi >= bmx[a])) stats[6]++;
+        me.mn[a] = std::min(me.mn[a], cb.mn[a]);
+        me.mx[a] = std::max(me.mx[a], cb.mx[a]);
+      }
+      const uint32_t want = cnt ? (0x80000000u | (idx << 2) | (cnt - 1u)) : idx;
+      if ((side ? q[ni].rref : q[ni].lref) != want) stats[7]++;
+    }
+    sub[ni] = me;
+    done[ni] = 1;
+  }
+  return RTPT_OK;
 }
 
 int rtpt_util_load_obj(const char* path, float* xyz, uint32_t* n_verts, uint32_t* idx, uint32_t* n_tris) {

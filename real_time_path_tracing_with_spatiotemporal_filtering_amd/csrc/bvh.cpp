@@ -48,7 +48,10 @@ struct Child {
   uint32_t cnt;
 };
 
-constexpr int kBins = 16;
+#ifndef RTPT_BVH_BINS
+#define RTPT_BVH_BINS 16
+#endif
+constexpr int kBins = RTPT_BVH_BINS;
 
 struct Builder {
   std::vector<Prim> prims;
@@ -272,16 +275,21 @@ BvhGrid pack_quantised_nodes(const Bvh& bvh, std::vector<BvhNodeQ>& out) {
     g.origin[a] = static_cast<float>(lo[a] - static_cast<double>(g.cell[a]));
     cell[a] = g.cell[a];
   }
+  // the decoded face origin + q * cell is formed in binary32 (the traversal's fma has the same operands up to
+  // the common factor 1/d): step until THAT value is on the outer side.  What is left between the two roundings
+  // is a few ulp of the coordinate, two orders of magnitude below the padding of the boxes.
+  auto decode = [&](double q, int a) { return g.origin[a] + static_cast<float>(q) * g.cell[a]; };
   auto qdown = [&](float x, int a) -> uint16_t {
     double q = std::floor((static_cast<double>(x) - static_cast<double>(g.origin[a])) / cell[a]);
-    // the decoded value origin + q*cell is formed in binary32 on the device: step down while it is not below x
-    while (q > 0 && static_cast<double>(g.origin[a]) + q * cell[a] > static_cast<double>(x)) q -= 1;
-    return static_cast<uint16_t>(std::min(65535.0, std::max(0.0, q)));
+    q = std::min(65535.0, std::max(0.0, q));
+    while (q > 0 && decode(q, a) > x) q -= 1;
+    return static_cast<uint16_t>(q);
   };
   auto qup = [&](float x, int a) -> uint16_t {
     double q = std::ceil((static_cast<double>(x) - static_cast<double>(g.origin[a])) / cell[a]);
-    while (q < 65535 && static_cast<double>(g.origin[a]) + q * cell[a] < static_cast<double>(x)) q += 1;
-    return static_cast<uint16_t>(std::min(65535.0, std::max(0.0, q)));
+    q = std::min(65535.0, std::max(0.0, q));
+    while (q < 65535 && decode(q, a) < x) q += 1;
+    return static_cast<uint16_t>(q);
   };
   auto ref = [](uint32_t idx, uint32_t cnt) -> uint32_t {
     if (idx == kBvhEmpty) return kBvhEmpty;
