@@ -318,6 +318,10 @@ def main():
             "value": round(r2 / e2 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
             "atrous_GBps": kr2.get("k_atrous", {}).get("algorithmic_GBps"),
             "atrous_frac": round(kr2.get("k_atrous", {}).get("algorithmic_GBps", 0) / HBM_PEAK_GBS, 4)}
+        e4, r4, _, _, _ = run_gpu(WORKLOADS["1080p"], args, 0, 1, args.steps, args.warmup, torch, None, collect_kernels=False,
+                                  in_flight=2)
+        result["also"]["cornell-1080p-1spp-4seg-5atrous"]["two_frames_in_flight"] = {
+            "value": round(r4 / e4 / 1e6, 2), "ms_per_step": round(e4 / args.steps * 1e3, 4)}
     if world == 1 and rank == 0 and not args.no_cpu_baseline and not wl.get("instanced"):
         result["cpu_baseline"] = cpu_baseline(wl)
     if dist is not None:
