@@ -161,3 +161,77 @@ def test_reprojection_and_blend_against_float64_restatement(oracle, cornell):
     clear = (vis < 1) | (np.isfinite(scr).all(-1) & (frac > 1e-3))
     assert clear.mean() > 0.95 and np.array_equal(got[clear], want[clear])
     assert (got[vis > 0] != np.stack([xs, ys], -1)[vis > 0]).any(-1).mean() > 0.5, "the camera moved: pixels must reproject elsewhere"
+
+
+# ---------------------------------------------------------------------------------------- K2
+def test_first_segment_against_float64_restatement(oracle, cornell):
+    """raytrace.comp.glsl with the loop bound 1: seed hash -> PCG -> Box-Muller jitter -> camera ray -> light test ->
+    closest hit -> albedo / sky.  Integers (the RNG) are reproduced exactly, the float part in float64; the colour of a
+    one-segment path is one of a few discrete values (or the sky gradient), so the images must agree pixel for pixel
+    except where the jittered ray grazes a silhouette or the light's rim."""
+    w, h, frame = 120, 90, 7
+    cfg = oracle.config_default(w, h)
+    cfg.max_segments = 1
+    pc = oracle.PushConstants()
+    pc.frameNumber, pc.sample_batch = frame, 0
+    cam = np.array([-0.001, 1.0, 6.0])
+    light = np.array([1.0, 1.0, -0.4])
+    pc.cameraPos[:] = cam
+    pc.lightPos[:] = light
+    pc.currentCameraColor[:] = (0.5, 0.5, 0.5)
+    img, rays, hit = oracle.raytrace(cfg, pc, cornell[2], 0, h)
+    assert rays == w * h
+
+    M = 0xFFFFFFFF
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.uint64)
+    state = ((xs * 3266489917 + ys * 668265263) & M) ^ ((frame * 374761393) & M) ^ 0     # :297
+
+    def step(s):                                                                           # :71-78
+        s = (s * 747796405 + 1) & M
+        word = ((((s >> ((s >> 28) + 4)) ^ s) & M) * 277803737) & M
+        word = ((word >> 22) ^ word) & M
+        return s, np.float32(word.astype(np.float64) / 4294967295.0).astype(np.float64)    # float(word) / 4294967295.0f
+
+    state, u1 = step(state)
+    state, u2 = step(state)
+    u1 = np.maximum(1e-38, u1)
+    r = np.sqrt(-2.0 * np.log(u1))
+    theta = 2 * 3.14159265 * u2
+    cx = xs + 0.5 + 0.375 * r * np.cos(theta)                                              # :314
+    cy = ys + 0.5 + 0.375 * r * np.sin(theta)
+    slope = np.tan(0.20)                                                                   # common.h FOV
+    d = np.stack([slope * (2 * cx - w) / h, slope * -(2 * cy - h) / h, -np.ones_like(cx)], -1)
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    # checkRayLightIntersection, :168-198 (tested before the triangle hit, :226)
+    oc = cam - light
+    b = 2 * (d @ oc)
+    disc = b * b - 4 * (oc @ oc - 0.2 * 0.2)
+    sq = np.sqrt(np.maximum(disc, 0))
+    lit = (disc >= 0) & (((-b - sq) / 2 > 0) | ((-b + sq) / 2 > 0))
+    # closest hit, textbook Moller-Trumbore
+    tris = cornell[2].astype(np.float64).reshape(-1, 3, 3)
+    v0, e1, e2 = tris[:, 0], tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]
+    D = d.reshape(-1, 1, 3)
+    p = np.cross(D, e2[None])
+    det = (e1[None] * p).sum(-1)
+    tv = (cam - v0)[None]
+    u = (tv * p).sum(-1) / det
+    q = np.cross(tv, e1[None])
+    v = (D * q).sum(-1) / det
+    t = (e2[None] * q).sum(-1) / det
+    ok = (np.abs(det) > 0) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 0)
+    tt = np.where(ok, t, np.inf)
+    best = tt.argmin(1).reshape(h, w)
+    miss = ~np.isfinite(tt.min(1)).reshape(h, w)
+    nrm = np.cross(e1, e2)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    alb = np.where((nrm[:, 0] > 0.99)[:, None], [1.0, 0, 0], np.where((-nrm[:, 0] > 0.99)[:, None], [0, 1.0, 0], [0.7, 0.7, 0.7]))  # :155-163
+    sky = np.where((d[..., 1] > 0)[..., None], 1.0 * (1 - d[..., 1:2]) + np.array([0.25, 0.5, 1.0]) * d[..., 1:2], 0.03)     # :95-107
+    want = np.where(lit[..., None], 0.5 * 30 / 5.0, np.where(miss[..., None], sky, alb[best]))
+    got = img[..., :3].astype(np.float64)
+    same = np.abs(got - want).max(-1) < 1e-5
+    assert same.mean() > 0.995, same.mean()
+    assert lit.sum() > 20 and miss.sum() > 100 and (~miss & ~lit).sum() > 1000, "light, sky and surfaces must all be in view"
+    agree_id = (hit == np.where(miss, 0, best + 1))
+    assert agree_id.mean() > 0.995
+    assert not img[..., 3].any()                                                            # :343 alpha 0
