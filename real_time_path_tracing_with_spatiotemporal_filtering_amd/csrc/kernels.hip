@@ -131,6 +131,9 @@ __device__ __forceinline__ bool slab(float mnx, float mny, float mnz, float mxx,
 // order and cull; the triangle test is binary32 on the exact records.
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kSentinel = 0xFFFFFFFEu;
+#ifndef RTPT_BVH_SPECULATE
+#define RTPT_BVH_SPECULATE 0
+#endif
 
 __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d, HitRec& h, uint32_t* stack,
                                                int tid, int nt = kThreads) {
@@ -150,50 +153,77 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
   const f3 oi{(sc.bvh_origin[0] - o.x) * rd.x, (sc.bvh_origin[1] - o.y) * rd.y, (sc.bvh_origin[2] - o.z) * rd.z};
   int sp = 0;
   uint32_t cur = 0;  // root pair
-  while (cur != kSentinel) {
-    while (!(cur & kLeafBit)) {  // interior (kSentinel and kBvhEmpty have bit 31 set)
-      const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + cur);
-      const uint4 a = np[0], b = np[1];
-      const uint32_t cl = b.z, cr = b.w;
-      const float tb = h.t;
-      float tl, tr;
-      auto lo16 = [](uint32_t w) { return static_cast<float>(w & 0xFFFFu); };
-      auto hi16 = [](uint32_t w) { return static_cast<float>(w >> 16); };
-      // both boxes are tested unconditionally (an absent child holds a zero box) so that the node is two
-      // independent 16-byte loads, not a load, a branch on the reference and another load
-      const bool sl = slab(lo16(a.x), hi16(a.x), lo16(a.y), hi16(a.y), lo16(a.z), hi16(a.z), inv, oi, tb, tl);
-      const bool sr = slab(lo16(a.w), hi16(a.w), lo16(b.x), hi16(b.x), lo16(b.y), hi16(b.y), inv, oi, tb, tr);
-      const bool hl = sl & (cl != kBvhEmpty), hr = sr & (cr != kBvhEmpty);
-      if (hl && hr) {
-        const bool left_first = tl <= tr;
-        stack[sp * nt + tid] = left_first ? cr : cl;
-        sp++;
-        cur = left_first ? cl : cr;
-      } else if (hl) {
-        cur = cl;
-      } else if (hr) {
-        cur = cr;
-      } else if (sp > 0) {
-        sp--;
-        cur = stack[sp * nt + tid];
-      } else {
-        cur = kSentinel;
-      }
+  auto pop = [&]() -> uint32_t {
+    if (sp > 0) {
+      sp--;
+      return stack[sp * nt + tid];
     }
-    if (cur != kSentinel) {  // a leaf
-      const uint32_t first = (cur & ~kLeafBit) >> 2, cnt = (cur & 3u) + 1u;
-      for (uint32_t j = 0; j < cnt; j++) {
-        const float4* r = sc.isect_leaf + 3 * static_cast<size_t>(first + j);
-        tri_test<true>(o, d, r[0], r[1], r[2], sc.leaf_ids[first + j] + 1, h);
+    return kSentinel;
+  };
+  auto test_leaf = [&](uint32_t ref) {
+    const uint32_t first = (ref & ~kLeafBit) >> 2, cnt = (ref & 3u) + 1u;
+    for (uint32_t j = 0; j < cnt; j++) {
+      const float4* r = sc.isect_leaf + 3 * static_cast<size_t>(first + j);
+      tri_test<true>(o, d, r[0], r[1], r[2], sc.leaf_ids[first + j] + 1, h);
+    }
+  };
+  auto node_step = [&]() {
+    const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + cur);
+    const uint4 a = np[0], b = np[1];
+    const uint32_t cl = b.z, cr = b.w;
+    const float tb = h.t;
+    float tl, tr;
+    auto lo16 = [](uint32_t w) { return static_cast<float>(w & 0xFFFFu); };
+    auto hi16 = [](uint32_t w) { return static_cast<float>(w >> 16); };
+    // both boxes are tested unconditionally (an absent child holds a zero box) so that the node is two
+    // independent 16-byte loads, not a load, a branch on the reference and another load
+    const bool sl = slab(lo16(a.x), hi16(a.x), lo16(a.y), hi16(a.y), lo16(a.z), hi16(a.z), inv, oi, tb, tl);
+    const bool sr = slab(lo16(a.w), hi16(a.w), lo16(b.x), hi16(b.x), lo16(b.y), hi16(b.y), inv, oi, tb, tr);
+    const bool hl = sl & (cl != kBvhEmpty), hr = sr & (cr != kBvhEmpty);
+    if (hl && hr) {
+      const bool left_first = tl <= tr;
+      stack[sp * nt + tid] = left_first ? cr : cl;
+      sp++;
+      cur = left_first ? cl : cr;
+    } else if (hl) {
+      cur = cl;
+    } else if (hr) {
+      cur = cr;
+    } else {
+      cur = pop();
+    }
+  };
+#if RTPT_BVH_SPECULATE
+  // speculative while-while: a lane that reaches a leaf postpones it and keeps walking until it holds a second
+  // leaf (or runs out of nodes), so fewer lanes idle while the slowest lane of the wave finds its first leaf
+  uint32_t post = kSentinel;
+  while (true) {
+    while (true) {
+      if (cur & kLeafBit) {  // a leaf or the sentinel
+        if (cur == kSentinel || post != kSentinel) break;
+        post = cur;
+        cur = pop();
+        continue;
       }
-      if (sp > 0) {
-        sp--;
-        cur = stack[sp * nt + tid];
-      } else {
-        cur = kSentinel;
-      }
+      node_step();
+    }
+    if (post == kSentinel) break;  // then cur is the sentinel too
+    test_leaf(post);
+    post = kSentinel;
+    if (cur != kSentinel) {
+      test_leaf(cur);
+      cur = pop();
     }
   }
+#else
+  while (cur != kSentinel) {
+    while (!(cur & kLeafBit)) node_step();  // interior (kSentinel has bit 31 set)
+    if (cur != kSentinel) {  // a leaf
+      test_leaf(cur);
+      cur = pop();
+    }
+  }
+#endif
 }
 
 template <bool BVH>
