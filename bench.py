@@ -38,6 +38,7 @@ WORKLOADS = {
     "instanced": dict(width=3840, height=2160, max_segments=8, iterations=5, instanced=True),
 }
 PREWARM_SECONDS = 0.3
+HOST_SECONDS = [0.0]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # algorithmic bytes per pixel per launch (SURVEY.md 8d / BASELINE.md 3)
 BYTES_PER_PX = {"k_atrous": 40, "k_atrous_final": 72, "k_gradient": 36, "k_gbuffer": 24, "k_pathtrace": 16}
@@ -70,23 +71,33 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
     # device wake-up, untimed and before the W warm-up steps: a cold MI355X runs its first ~50 ms of kernels
     # 20 % slower (in-process A/B: the first 400 frames of a 270-row strip take 0.212 ms each, every later batch
     # 0.173 ms), which a 36 ms timed region at 8 ranks would otherwise measure instead of the kernels
-    t_wake = time.perf_counter()
-    while time.perf_counter() - t_wake < args.prewarm_seconds:
-        for _ in range(8):
-            app.drawScene()
-        ctx.sync()
+    # The same loop fills the context's pool of timing events (created on first use; on some boxes
+    # hipEventCreate is slow enough that creating them inside the timed region cost +0.2 ms per step).
+    timing_period = 8 if steps >= 32 else 1
+    if args.prewarm_seconds > 0:
+        ctx.timing_enable(timing_period if collect_kernels else 0)
+        t_wake = time.perf_counter()
+        n_wake = 0
+        while time.perf_counter() - t_wake < args.prewarm_seconds or (n_wake < steps and time.perf_counter() - t_wake < 3.0):
+            for _ in range(16):
+                app.drawScene()
+            n_wake += 16
+            for c in ctxs:
+                c.sync()
+        ctx.timing_collect()
+        ctx.timing_enable(0)
     for _ in range(warmup):
         app.drawScene()
     fence()
     for c in ctxs:
         c.reset_counters()
     # per-kernel HIP events on the launch stream, sampled: bracketing every launch costs ~6 % of the frame
-    timing_period = 8 if steps >= 32 else 1
     ctx.timing_enable(timing_period if collect_kernels else 0)
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         app.drawScene()
+    HOST_SECONDS[0] = time.perf_counter() - t0  # time the host needed to submit the K steps (diagnostic)
     fence()
     elapsed = time.perf_counter() - t0
     ctx.timing_enable(0)
@@ -261,6 +272,7 @@ def main():
     elapsed, rays, kern, plan, timed_frames = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist,
                                                       in_flight=args.frames_in_flight)
     ms_per_step = elapsed / args.steps * 1e3
+    host_ms = HOST_SECONDS[0] / args.steps * 1e3
     result = None
     if rank == 0:
         kr = kernel_report(kern, wl, plan, timed_frames)
@@ -279,6 +291,7 @@ def main():
             "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "host_submit_ms_per_step": round(host_ms, 4),
             "fps": round(1e3 / ms_per_step, 1),
             "higher_is_better": True,
             "scaling": "strong",
