@@ -421,6 +421,28 @@ def test_two_frames_in_flight(hip_lib, oracle, cornell, exact):
     app.backend.close()
 
 
+def test_two_frames_in_flight_soak(hip_lib):
+    """300 frames submitted without a single host sync, camera and light moving in most of them: the last frame
+    depends on every earlier one through the temporal blend, so one missed cross-stream dependency anywhere would
+    change it.  Serial and pipelined hosts must end on the same bits (exact filter), at two sizes."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    keys = "DDAAWWSSEEQQJJLLIIKKOOUU"
+    for (w, h) in ((200, 120), (1920, 1080)):
+        outs = []
+        for fif in (1, 2):
+            app = make_app(w, h, max_segments=4, iterations=5, flags=hip_lib.FLAG_EXACT_FILTER, frames_in_flight=fif)
+            for f in range(300):
+                app.drawScene((keys[f % len(keys)],) if f % 3 else ())
+            be = app.backend
+            outs.append(be.final_image_rows(0, h) if fif == 2 else be.readback_rows(hip_lib.PLANE_PREVIOUS, 0, h))
+            rays = be.raycount() if fif == 2 else be.ctx.raycount()
+            outs.append(rays)
+            be.close()
+        assert outs[1] == outs[3]
+        assert np.array_equal(bits(outs[0]), bits(outs[2])), (w, h)
+        assert np.isfinite(outs[0][..., :3]).mean() > 0.999
+
+
 def test_resize_keeps_scene_and_restarts_history(hip_lib, oracle, cornell):
     """rtpt_resize (framebuffer resize, main.cpp:275-278/:1310): new planes, same scene; the frames after it equal
     a freshly created context of the new size, whose first final pass has no history (frameNumber is the caller's)."""
