@@ -62,3 +62,45 @@ def test_hip_matches_golden(hip_lib):
         assert err.max() <= 1e-5, (f, err.max())   # FILTER_TOL of test_parity_gpu.py
         app.copyImageToSwapChainsCurrentImage()
         app.frameCount += 1
+
+
+# ------------------------------------------------------------------------------ BASELINE configs[0] at its real size
+CFG1 = os.path.join(ROOT, "tests", "golden", "config1_256x256_sha256.json")
+
+
+def test_oracle_reproduces_config1_digests(oracle):
+    import json
+    import make_config1_digests as m
+    want = json.load(open(CFG1))
+    assert m.generate() == want, "oracle drifted from the committed config-1 digests"
+
+
+@pytest.mark.gpu
+def test_hip_matches_config1_digests(hip_lib):
+    """configs[0] (256x256, 2 segments, N = 5, frames 0-2, light moves on frame 2) against the committed digests:
+    every plane bit for bit, the filtered image too (exact filter arithmetic)."""
+    import json
+    import make_config1_digests as m
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    want = json.load(open(CFG1))
+    app = make_app(m.W, m.H, max_segments=m.SEGMENTS, iterations=m.ITERATIONS, flags=hip_lib.FLAG_EXACT_FILTER,
+                   debug_mask=hip_lib.DEBUG_HIT_ID | hip_lib.DEBUG_PREV_PIXEL)
+    ctx = app.backend.ctx
+    for f, keys in enumerate(m.KEYS):
+        ctx.reset_counters()
+        app.updateScene(keys)
+        app.drawVisbilityBuffer()
+        app.computeTemporalGradient()
+        app.drawSceneToImage()
+        got = {"vis": ctx.readback(hip_lib.PLANE_VIS_ID), "worldpos": ctx.readback(hip_lib.PLANE_WORLDPOS),
+               "depth": ctx.readback(hip_lib.PLANE_DEPTH), "gradient": ctx.readback(hip_lib.PLANE_GRADIENT),
+               "traced": ctx.readback(hip_lib.PLANE_IMAGE), "hit_id": ctx.readback(hip_lib.PLANE_HIT_ID)}
+        rays = ctx.raycount()
+        app.applyTemporalFiltering()
+        got["image"] = ctx.readback(hip_lib.PLANE_IMAGE)
+        got["prev_pixel"] = ctx.readback(hip_lib.PLANE_PREV_PIXEL)
+        app.copyImageToSwapChainsCurrentImage()
+        app.frameCount += 1
+        for name in m.PLANES:
+            assert m.digest(got[name]) == want["frames"][f][name], (f, name)
+        assert rays == want["frames"][f]["rays"]
