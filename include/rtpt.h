@@ -107,6 +107,14 @@ typedef struct rtpt_visibility_data {
 #define RTPT_FLAG_EXT_DISOCCLUSION 0x80u   /* blend history only where the reprojected pixel of the previous
                                               frame's id plane (previousVisibilityBuffer, main.cpp:1367: copied,
                                               never read) shows the same primitive */
+#define RTPT_FLAG_EXT_VARIANCE 0x100u      /* SVGF-style variance guidance: before the first filter iteration the first
+                                              and second moments of the traced luminance are accumulated along the
+                                              reprojected pixel (history only where the previous id plane agrees;
+                                              a = max(alpha, 1/(n+1)); short histories n < 4 scale the variance by
+                                              4/n); the colour term of the tap weight becomes
+                                              exp(-|lum_p - lum_q| / (sigma_l * sqrt(var_p) + 1e-4)) and the variance
+                                              is filtered along with weights (h w)^2.  Whole-frame contexts only
+                                              (row_begin = 0, row_end = height).  RTPT_PLANE_MOMENTS / _VARIANCE. */
 
 typedef struct rtpt_config {
   uint32_t struct_size;          /* = sizeof(rtpt_config), ABI guard */
@@ -148,7 +156,9 @@ typedef enum rtpt_plane {
                                since rtpt_reset_counters (SURVEY 8d "ray") */
   RTPT_PLANE_HIT_ID = 12,   /* build-only observable (debug): u32 first-hit primitive id+1 of the
                                jittered primary ray of rtpt_raytrace, only if enabled */
-  RTPT_PLANE_COUNT = 13
+  RTPT_PLANE_MOMENTS = 13,  /* extension RTPT_FLAG_EXT_VARIANCE: (m1, m2, history length, variance) float4 */
+  RTPT_PLANE_VARIANCE = 14, /* extension: f32 variance written by the last filter iteration (or by the moments pass) */
+  RTPT_PLANE_COUNT = 15
 } rtpt_plane;
 
 typedef struct rtpt_ctx rtpt_ctx;

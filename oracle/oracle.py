@@ -32,7 +32,7 @@ class OracleConfig(C.Structure):
     ]
 
 
-EXT_ADAPTIVE_ALPHA, EXT_GAUSS5, EXT_POW2_STRIDE, EXT_DISOCCLUSION = 0x10, 0x20, 0x40, 0x80
+EXT_ADAPTIVE_ALPHA, EXT_GAUSS5, EXT_POW2_STRIDE, EXT_DISOCCLUSION, EXT_VARIANCE = 0x10, 0x20, 0x40, 0x80, 0x100
 
 
 class PushConstants(C.Structure):
@@ -211,8 +211,24 @@ def raytrace(cfg, pc: PushConstants, tris, y0=0, y1=None, want_hit_id=True):
     return img, int(rc.value), hid
 
 
+def moments(cfg, pc: PushConstants, ubo: Ubo, traced, vis, worldpos, lut_prev, prev_vis, moments_prev, y0=0, y1=None):
+    """extension EXT_VARIANCE: (moments[H,W,4] = m1, m2, n, var; variance[H,W])"""
+    W, H = cfg.width, cfg.height
+    y1 = H if y1 is None else y1
+    if prev_vis is None:
+        prev_vis = np.zeros((H, W), np.uint32)
+    if moments_prev is None:
+        moments_prev = np.zeros((H, W, 4), np.float32)
+    mo = np.zeros((H, W, 4), np.float32)
+    var = np.zeros((H, W), np.float32)
+    lib().oracle_moments(C.byref(cfg), C.byref(pc), C.byref(ubo), _p(traced), _p(vis), _p(worldpos), _p(lut_prev),
+                         _p(prev_vis), _p(moments_prev), C.c_uint32(y0), C.c_uint32(y1), _p(mo), _p(var))
+    return mo, var
+
+
 def atrous(cfg, pc: PushConstants, ubo: Ubo, img_in, depth, vis, lut_, lut_prev, worldpos, history,
-           y0=0, y1=None, want_prev_pixel=False, gradient=None, prev_vis=None):
+           y0=0, y1=None, want_prev_pixel=False, gradient=None, prev_vis=None, var_in=None):
+    """with var_in (EXT_VARIANCE) the filtered variance is appended to the result"""
     W, H = cfg.width, cfg.height
     y1 = H if y1 is None else y1
     out = np.zeros((H, W, 4), np.float32)
@@ -223,10 +239,14 @@ def atrous(cfg, pc: PushConstants, ubo: Ubo, img_in, depth, vis, lut_, lut_prev,
         prev_vis = np.zeros((H, W), np.uint32)
     if gradient is None:
         gradient = np.zeros((H, W, 4), np.float32)
-    lib().oracle_atrous_ext(C.byref(cfg), C.byref(pc), C.byref(ubo), _p(img_in), _p(depth), _p(vis), _p(lut_),
-                            _p(lut_prev), _p(worldpos), _p(history), _p(gradient), _p(prev_vis),
-                            C.c_uint32(y0), C.c_uint32(y1), _p(out), _p(pp))
-    return (out, pp) if want_prev_pixel else out
+    var_out = np.zeros((H, W), np.float32) if var_in is not None else None
+    lib().oracle_atrous_var(C.byref(cfg), C.byref(pc), C.byref(ubo), _p(img_in), _p(depth), _p(vis), _p(lut_),
+                            _p(lut_prev), _p(worldpos), _p(history), _p(gradient), _p(prev_vis), _p(var_in),
+                            C.c_uint32(y0), C.c_uint32(y1), _p(out), _p(pp), _p(var_out))
+    res = (out, pp) if want_prev_pixel else (out,)
+    if var_in is not None:
+        res = res + (var_out,)
+    return res if len(res) > 1 else res[0]
 
 
 # ------------------------------------------------------------------------------------------
@@ -328,14 +348,24 @@ class OracleApp:
         self.pc.maxWaveletIteration = self.iterations  # main.cpp:1258
         cur = traced
         pp = None
+        var = None
+        if cfg.ext_flags & EXT_VARIANCE:
+            self.moments, var = moments(cfg, self.pc, self.ubo, traced, vis, wp, self.lut_prev, self.prev_vis,
+                                        getattr(self, "moments", None))
+            self.variance0 = var
         for k in range(1, self.iterations + 1):
             self.pc.waveletIteration = k
+            res = atrous(cfg, self.pc, self.ubo, cur, depth, vis, lut_, self.lut_prev, wp, self.history,
+                         want_prev_pixel=(k == self.iterations), gradient=grad, prev_vis=self.prev_vis, var_in=var)
+            if var is not None:
+                var = res[-1]
+                res = res[:-1]
+                res = res if len(res) > 1 else res[0]
             if k == self.iterations:
-                cur, pp = atrous(cfg, self.pc, self.ubo, cur, depth, vis, lut_, self.lut_prev, wp, self.history,
-                                 want_prev_pixel=True, gradient=grad, prev_vis=self.prev_vis)
+                cur, pp = res
             else:
-                cur = atrous(cfg, self.pc, self.ubo, cur, depth, vis, lut_, self.lut_prev, wp, self.history,
-                             gradient=grad, prev_vis=self.prev_vis)
+                cur = res
+        self.variance = var
         # history hand-over main.cpp:1361-1372
         self.history = cur
         self.lut_prev = lut_

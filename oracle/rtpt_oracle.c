@@ -502,6 +502,60 @@ static inline vec3 normal_from_id(const float* lut, uint32_t id) {
   return v3_normalize(v3_cross(v3_sub(b, a), v3_sub(c, a)));
 }
 
+/* temporalFiltering.comp.glsl:213-239 + worldToPixel :178-189 */
+static void reproject(int W, int H, const float* PVp, uint32_t id, const float* worldpos4, const float* lut_prev, int x,
+                      int y, int* ppx, int* ppy) {
+  *ppx = x;
+  *ppy = y;
+  if (id < 1) return; /* :216 */
+  vec3 wp = v3(worldpos4[0], worldpos4[1], worldpos4[2]);
+  vec3 a = lut_v(lut_prev, id, 0), b = lut_v(lut_prev, id, 1), c = lut_v(lut_prev, id, 2); /* :223-233 */
+  vec3 bc = bary_coords(wp, a, b, c);
+  vec3 wpp = bary_mix(bc, a, b, c); /* :236 */
+  float clx = mat4_row_point(PVp, 0, wpp), cly = mat4_row_point(PVp, 1, wpp), clw = mat4_row_point(PVp, 3, wpp);
+  float ndx = clx / clw, ndy = cly / clw;                          /* :183 */
+  float sx = dm_fma(ndx, 0.5f, 0.5f) * (float)W;                   /* :186 */
+  float sy = dm_fma(ndy, 0.5f, 0.5f) * (float)H;
+  *ppx = dm_f2i(sx); /* :238 ivec2() truncation */
+  *ppy = dm_f2i(sy);
+}
+
+static inline float luminance(vec3 c) { return dm_fma(0.0722f, c.z, dm_fma(0.7152f, c.y, 0.2126f * c.x)); }
+
+void oracle_moments(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
+                    const float* traced, const uint32_t* vis, const float* worldpos, const float* lut_prev,
+                    const uint32_t* prev_vis, const float* moments_prev, uint32_t y0, uint32_t y1,
+                    float* moments_out, float* var_out) {
+  const int W = (int)cfg->width, H = (int)cfg->height;
+  float PVp[16];
+  mat4_mul(ubo->projPrev, ubo->viewPrev, PVp);
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
+  for (int y = (int)y0; y < (int)y1; y++)
+    for (int x = 0; x < W; x++) {
+      uint64_t ip = (uint64_t)y * W + x;
+      uint32_t id = vis[ip];
+      float lum = luminance(v3(traced[4 * ip], traced[4 * ip + 1], traced[4 * ip + 2]));
+      int ppx, ppy;
+      reproject(W, H, PVp, id, worldpos + 4 * ip, lut_prev, x, y, &ppx, &ppy);
+      int valid = pc->frameNumber > 0 && ppx >= 0 && ppx < W && ppy >= 0 && ppy < H;
+      uint64_t iq = valid ? (uint64_t)ppy * W + ppx : 0;
+      if (valid) valid = prev_vis[iq] == id;
+      float m1 = lum, m2 = lum * lum, n = 1.0f;
+      if (valid) {
+        const float* mp = moments_prev + 4 * iq;
+        float a = dm_max(cfg->alpha, 1.0f / (mp[2] + 1.0f)), oma = 1.0f - a;
+        m1 = dm_fma(lum, a, mp[0] * oma);
+        m2 = dm_fma(lum * lum, a, mp[1] * oma);
+        n = dm_min(mp[2] + 1.0f, 255.0f);
+      }
+      float var = dm_max(0.0f, dm_fma(-m1, m1, m2));
+      if (n < 4.0f) var = var * (4.0f / n);
+      float* mo = moments_out + 4 * ip;
+      mo[0] = m1; mo[1] = m2; mo[2] = n; mo[3] = var;
+      var_out[ip] = var;
+    }
+}
+
 /* gaussianKernel2D, temporalFiltering.comp.glsl:93-99 (sum 273) */
 static const float k_gauss5[5][5] = {{1, 4, 7, 4, 1}, {4, 16, 26, 16, 4}, {7, 26, 41, 26, 7}, {4, 16, 26, 16, 4}, {1, 4, 7, 4, 1}};
 
@@ -517,7 +571,17 @@ void oracle_atrous_ext(const oracle_config* cfg, const oracle_push_constants* pc
                        const float* lut_prev, const float* worldpos, const float* history,
                        const float* gradient, const uint32_t* prev_vis,
                        uint32_t y0, uint32_t y1, float* out, int32_t* prev_pixel) {
+  oracle_atrous_var(cfg, pc, ubo, in, depth, vis, lut, lut_prev, worldpos, history, gradient, prev_vis, NULL, y0, y1, out,
+                    prev_pixel, NULL);
+}
+
+void oracle_atrous_var(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
+                       const float* in, const float* depth, const uint32_t* vis, const float* lut,
+                       const float* lut_prev, const float* worldpos, const float* history,
+                       const float* gradient, const uint32_t* prev_vis, const float* var_in,
+                       uint32_t y0, uint32_t y1, float* out, int32_t* prev_pixel, float* var_out) {
   const uint32_t ext = cfg->ext_flags;
+  const int use_var = (ext & ORACLE_EXT_VARIANCE) && var_in;
   const int R = (ext & ORACLE_EXT_GAUSS5) ? 2 : 1;
   const int W = (int)cfg->width, H = (int)cfg->height;
   const int kk = pc->waveletIteration, max_it = pc->maxWaveletIteration; /* :208-209 */
@@ -538,7 +602,9 @@ void oracle_atrous_ext(const oracle_config* cfg, const oracle_push_constants* pc
       float dp = depth[ip];                                    /* :123 */
       vec3 np = normal_from_id(lut, vis[ip]);                  /* :125-127 */
       vec3 num = v3(0.f, 0.f, 0.f);
-      float den = 0.f;
+      float den = 0.f, vsum = 0.f;
+      const float lum_p = luminance(cp);
+      const float lum_scale = use_var ? dm_fma(cfg->sigma_l, dm_sqrt(dm_max(var_in[ip], 0.0f)), 1e-4f) : 1.0f;
       for (int i = -R; i <= R; i++)     /* :132 (-1..1; -2..2 with the 5x5 table) */
         for (int j = -R; j <= R; j++) { /* :133 */
           int qx = x + i * k, qy = y + j * k; /* :135 */
@@ -550,13 +616,16 @@ void oracle_atrous_ext(const oracle_config* cfg, const oracle_push_constants* pc
           vec3 nq = normal_from_id(lut, vis[iq]);
           float wn = dm_powi(dm_max(0.0f, v3_dot(np, nq)), cfg->sigma_n);    /* :62 */
           float wd = dm_exp(-fabsf(dp - dq) / cfg->sigma_z);                 /* :67-68 */
-          float wl = dm_exp(-v3_length(v3_sub(cp, cq)) / cfg->sigma_l);      /* :73 */
+          float wl = use_var ? dm_exp(-fabsf(lum_p - luminance(cq)) / lum_scale)
+                             : dm_exp(-v3_length(v3_sub(cp, cq)) / cfg->sigma_l); /* :73 */
           float w = (wn * wd) * wl;                                          /* :77 */
           float hw = ((ext & ORACLE_EXT_GAUSS5) ? k_gauss5[i + 2][j + 2] * (1.0f / 273.0f) : h) * w;
           num = v3(dm_fma(hw, cq.x, num.x), dm_fma(hw, cq.y, num.y), dm_fma(hw, cq.z, num.z)); /* :146 */
           den = den + hw;                                                     /* :147 */
+          if (use_var) vsum = dm_fma(hw * hw, var_in[iq], vsum);
         }
       vec3 filtered = v3(num.x / den, num.y / den, num.z / den); /* :150 */
+      if (use_var && var_out) var_out[ip] = vsum / (den * den);
       float* o = out + 4 * ip;
       if (!final_pass) {
         o[0] = filtered.x; o[1] = filtered.y; o[2] = filtered.z; o[3] = 0.0f; /* :152 */
@@ -564,19 +633,8 @@ void oracle_atrous_ext(const oracle_config* cfg, const oracle_push_constants* pc
       }
       /* :213-239 reprojection (evaluated by the reference on every iteration, consumed only here) */
       uint32_t id = vis[ip];
-      int ppx = x, ppy = y;
-      if (!(id < 1)) {
-        vec3 wp = v3(worldpos[4 * ip], worldpos[4 * ip + 1], worldpos[4 * ip + 2]);
-        vec3 a = lut_v(lut_prev, id, 0), b = lut_v(lut_prev, id, 1), c = lut_v(lut_prev, id, 2); /* :223-233 */
-        vec3 bc = bary_coords(wp, a, b, c);
-        vec3 wpp = bary_mix(bc, a, b, c); /* :236 */
-        float clx = mat4_row_point(PVp, 0, wpp), cly = mat4_row_point(PVp, 1, wpp), clw = mat4_row_point(PVp, 3, wpp);
-        float ndx = clx / clw, ndy = cly / clw;                          /* :183 */
-        float sx = dm_fma(ndx, 0.5f, 0.5f) * (float)W;                   /* :186 */
-        float sy = dm_fma(ndy, 0.5f, 0.5f) * (float)H;
-        ppx = dm_f2i(sx); /* :238 ivec2() truncation */
-        ppy = dm_f2i(sy);
-      }
+      int ppx, ppy;
+      reproject(W, H, PVp, id, worldpos + 4 * ip, lut_prev, x, y, &ppx, &ppy);
       if (prev_pixel) { prev_pixel[2 * ip] = ppx; prev_pixel[2 * ip + 1] = ppy; }
       vec3 blend;
       int use_history = pc->frameNumber > 0; /* :251 */

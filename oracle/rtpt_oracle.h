@@ -37,6 +37,9 @@ typedef struct oracle_config {
 #define ORACLE_EXT_ADAPTIVE_ALPHA 0x10u /* temporalFiltering.comp.glsl:247-248 (commented out): alpha = (1-g)*alpha + g */
 #define ORACLE_EXT_GAUSS5 0x20u         /* gaussianKernel2D, temporalFiltering.comp.glsl:93-99 (declared, unused): 5x5 taps */
 #define ORACLE_EXT_POW2_STRIDE 0x40u    /* tap stride 2^(k-1) instead of k (:135) */
+#define ORACLE_EXT_VARIANCE 0x100u      /* SVGF-style luminance moments: temporally accumulated first and second moments
+                                           of the traced luminance give a per-pixel variance that scales the colour
+                                           edge-stopping term and is filtered along (see oracle_moments) */
 #define ORACLE_EXT_DISOCCLUSION 0x80u   /* previousVisibilityBuffer (main.cpp:375,:1367: copied every frame, never read):
                                            history is used only where the reprojected pixel showed the same primitive */
 
@@ -125,6 +128,25 @@ void oracle_atrous_ext(const oracle_config* cfg, const oracle_push_constants* pc
                        const float* lut_prev, const float* worldpos, const float* history,
                        const float* gradient, const uint32_t* prev_vis,
                        uint32_t y0, uint32_t y1, float* out, int32_t* prev_pixel);
+
+/* Extension ORACLE_EXT_VARIANCE, not reference behaviour.  Before the first filter iteration: per pixel
+ *   lum = 0.2126 r + 0.7152 g + 0.0722 b of the traced colour; q = the reprojected pixel (same arithmetic as the final
+ *   pass); valid = frame > 0, q inside the image and prev_vis[q] == id;
+ *   a = valid ? max(alpha, 1/(n_prev[q]+1)) : 1;  m1 = mix(m1_prev[q], lum, a);  m2 = mix(m2_prev[q], lum^2, a);
+ *   n = valid ? min(n_prev[q]+1, 255) : 1;  var = max(0, m2 - m1^2) * (n < 4 ? 4/n : 1).
+ * moments planes are 4 floats per pixel (m1, m2, n, var); var_out 1 float per pixel. */
+void oracle_moments(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
+                    const float* traced, const uint32_t* vis, const float* worldpos, const float* lut_prev,
+                    const uint32_t* prev_vis, const float* moments_prev, uint32_t y0, uint32_t y1,
+                    float* moments_out, float* var_out);
+/* oracle_atrous_ext with the variance planes: with ORACLE_EXT_VARIANCE the colour term of the weight becomes
+ *   exp(-|lum_p - lum_q| / (sigma_l * sqrt(var_in[p]) + 1e-4))
+ * and var_out[p] = sum((h w)^2 var_in[q]) / (sum(h w))^2 is filtered along.  var_in / var_out may be NULL otherwise. */
+void oracle_atrous_var(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
+                       const float* in, const float* depth, const uint32_t* vis, const float* lut,
+                       const float* lut_prev, const float* worldpos, const float* history,
+                       const float* gradient, const uint32_t* prev_vis, const float* var_in,
+                       uint32_t y0, uint32_t y1, float* out, int32_t* prev_pixel, float* var_out);
 
 #ifdef __cplusplus
 }

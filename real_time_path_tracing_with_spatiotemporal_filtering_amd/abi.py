@@ -20,12 +20,14 @@ RTPT_OK, RTPT_E_INVALID, RTPT_E_NOMEM, RTPT_E_DEVICE, RTPT_E_NO_SCENE, RTPT_E_NO
 FLAG_EXACT_FILTER, FLAG_FORCE_BVH, FLAG_DIRECT_FILTER, FLAG_NO_PATH_COMPACTION = 0x1, 0x2, 0x4, 0x8
 # extension modes (not reference behaviour, see include/rtpt.h)
 FLAG_EXT_ADAPTIVE_ALPHA, FLAG_EXT_GAUSS5, FLAG_EXT_POW2_STRIDE, FLAG_EXT_DISOCCLUSION = 0x10, 0x20, 0x40, 0x80
-FLAG_EXT_MASK = 0xF0
+FLAG_EXT_VARIANCE = 0x100
+FLAG_EXT_MASK = 0x1F0
 DEBUG_HIT_ID, DEBUG_PREV_PIXEL = 0x1, 0x2
 
 # rtpt_plane
 (PLANE_IMAGE, PLANE_FILTERED, PLANE_PREVIOUS, PLANE_WORLDPOS, PLANE_GRADIENT, PLANE_DEPTH, PLANE_VIS_ID,
- PLANE_PREV_VIS_ID, PLANE_LUT, PLANE_LUT_PREV, PLANE_PREV_PIXEL, PLANE_RAYCOUNT, PLANE_HIT_ID) = range(13)
+ PLANE_PREV_VIS_ID, PLANE_LUT, PLANE_LUT_PREV, PLANE_PREV_PIXEL, PLANE_RAYCOUNT, PLANE_HIT_ID, PLANE_MOMENTS,
+ PLANE_VARIANCE) = range(15)
 # rtpt_kernel_id
 K_GBUFFER, K_LUT, K_GRADIENT, K_PATHTRACE, K_ATROUS, K_ATROUS_FINAL, K_COUNT = range(7)
 KERNEL_NAMES = ["k_gbuffer", "k_lut", "k_gradient", "k_pathtrace", "k_atrous", "k_atrous_final"]
@@ -187,7 +189,7 @@ _PLANE_DTYPE = {
     PLANE_IMAGE: (np.float32, 4), PLANE_FILTERED: (np.float32, 4), PLANE_PREVIOUS: (np.float32, 4),
     PLANE_WORLDPOS: (np.float32, 4), PLANE_GRADIENT: (np.float32, 4), PLANE_DEPTH: (np.float32, 1),
     PLANE_VIS_ID: (np.uint32, 1), PLANE_PREV_VIS_ID: (np.uint32, 1), PLANE_PREV_PIXEL: (np.int32, 2),
-    PLANE_HIT_ID: (np.uint32, 1),
+    PLANE_HIT_ID: (np.uint32, 1), PLANE_MOMENTS: (np.float32, 4), PLANE_VARIANCE: (np.float32, 1),
 }
 
 

@@ -415,15 +415,16 @@ def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode=
              frames_in_flight=1, **app_kw):
     """createBuffers + loadMesh + buildAccelerationStructure for one rank.  `mesh` = (xyz, idx) replaces
     the OBJ (synthetic scenes of scenes.py)."""
-    plan = StripPlan(height, world, rank, iterations, mode, flags & 0xF0)
+    plan = StripPlan(height, world, rank, iterations, mode, flags & abi.FLAG_EXT_MASK)
     if torch_planes is None:
         torch_planes = world > 1  # halo exchange and the history all-gather move rows of torch-owned planes
     def one():
         return HipBackend(width, height, plan, max_segments=max_segments, flags=flags, torch_planes=torch_planes,
                           debug_mask=debug_mask)
     if frames_in_flight == 2:
-        if flags & abi.FLAG_EXT_DISOCCLUSION:
-            raise ValueError("two frames in flight cannot serve RTPT_FLAG_EXT_DISOCCLUSION (previous id plane)")
+        if flags & (abi.FLAG_EXT_DISOCCLUSION | abi.FLAG_EXT_VARIANCE):
+            raise ValueError("two frames in flight cannot serve RTPT_FLAG_EXT_DISOCCLUSION / _VARIANCE "
+                             "(previous id plane and moment history live in one context)")
         be = PipelinedBackend([one(), one()])
     elif frames_in_flight == 1:
         be = one()

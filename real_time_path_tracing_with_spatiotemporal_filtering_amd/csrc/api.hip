@@ -62,6 +62,9 @@ struct rtpt_ctx {
   Buf lut[2];
   int lut_cur = 0;
   Buf worldpos, gradient, depth, prev_pixel, hit_id, raycount, normal_tab, pair_tab;
+  Buf moments[2], variance[2];  // RTPT_FLAG_EXT_VARIANCE
+  int moments_cur = 0;          // moments[moments_cur] is written this frame, the other one is the history
+  int variance_last = 0;        // variance[] buffer holding the newest values
 
   // scene
   uint32_t n_tris = 0;
@@ -132,6 +135,8 @@ Buf* plane_buf(rtpt_ctx* c, rtpt_plane which) {
     case RTPT_PLANE_PREV_PIXEL: return &c->prev_pixel;
     case RTPT_PLANE_RAYCOUNT: return &c->raycount;
     case RTPT_PLANE_HIT_ID: return &c->hit_id;
+    case RTPT_PLANE_MOMENTS: return &c->moments[c->moments_cur];
+    case RTPT_PLANE_VARIANCE: return &c->variance[c->variance_last];
     default: return nullptr;
   }
 }
@@ -147,7 +152,9 @@ size_t plane_size(const rtpt_ctx* c, rtpt_plane which) {
     case RTPT_PLANE_DEPTH:
     case RTPT_PLANE_VIS_ID:
     case RTPT_PLANE_PREV_VIS_ID:
-    case RTPT_PLANE_HIT_ID: return px * 4;
+    case RTPT_PLANE_HIT_ID:
+    case RTPT_PLANE_VARIANCE: return px * 4;
+    case RTPT_PLANE_MOMENTS: return px * 16;
     case RTPT_PLANE_PREV_PIXEL: return px * 8;
     case RTPT_PLANE_LUT:
     case RTPT_PLANE_LUT_PREV: return (static_cast<size_t>(c->n_tris) + 1) * sizeof(rtpt_visibility_data);
@@ -314,6 +321,16 @@ static int alloc_planes(rtpt_ctx* c) {
   if (rc == RTPT_OK) rc = alloc_buf(c->gradient, px * 16);
   if (rc == RTPT_OK) rc = alloc_buf(c->depth, px * 4);
   if (rc == RTPT_OK && !c->raycount.ptr) rc = alloc_buf(c->raycount, 8);
+  if (c->cfg.flags & RTPT_FLAG_EXT_VARIANCE) {
+    for (int i = 0; i < 2 && rc == RTPT_OK; i++) rc = alloc_buf(c->moments[i], px * 16);
+    for (int i = 0; i < 2 && rc == RTPT_OK; i++) rc = alloc_buf(c->variance[i], px * 4);
+    for (int i = 0; i < 2 && rc == RTPT_OK; i++) {
+      (void)hipMemsetAsync(c->moments[i].ptr, 0, px * 16, c->stream);
+      (void)hipMemsetAsync(c->variance[i].ptr, 0, px * 4, c->stream);
+    }
+    c->moments_cur = 0;
+    c->variance_last = 0;
+  }
   if (rc == RTPT_OK && (c->debug_mask & RTPT_DEBUG_HIT_ID)) rc = alloc_buf(c->hit_id, px * 4);
   if (rc == RTPT_OK && (c->debug_mask & RTPT_DEBUG_PREV_PIXEL)) rc = alloc_buf(c->prev_pixel, px * 8);
   if (rc != RTPT_OK) return rc;
@@ -349,6 +366,8 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   if (cfg->struct_size != sizeof(rtpt_config)) return fail(RTPT_E_INVALID, "rtpt_config.struct_size mismatch (ABI)");
   if (cfg->width == 0 || cfg->height == 0 || cfg->row_begin >= cfg->row_end || cfg->row_end > cfg->height)
     return fail(RTPT_E_INVALID, "bad frame / row range");
+  if ((cfg->flags & RTPT_FLAG_EXT_VARIANCE) && (cfg->row_begin != 0 || cfg->row_end != cfg->height))
+    return fail(RTPT_E_INVALID, "RTPT_FLAG_EXT_VARIANCE needs a whole-frame context");
   if (cfg->max_segments == 0 || cfg->samples_per_pixel == 0 || cfg->sigma_n < 1)
     return fail(RTPT_E_INVALID, "max_segments, samples_per_pixel and sigma_n must be >= 1");
   int ndev = 0;
@@ -397,6 +416,8 @@ int rtpt_destroy(rtpt_ctx* c) {
   if (c->handoff_event) (void)hipEventDestroy(c->handoff_event);
   for (auto& b : c->color) free_buf(b);
   for (auto& b : c->vis) free_buf(b);
+  for (auto& b : c->moments) free_buf(b);
+  for (auto& b : c->variance) free_buf(b);
   for (auto& b : c->lut) free_buf(b);
   for (Buf* b : {&c->worldpos, &c->gradient, &c->depth, &c->prev_pixel, &c->hit_id, &c->raycount, &c->normal_tab, &c->pair_tab, &c->tris,
                  &c->leaf_order, &c->isect_id, &c->isect_leaf, &c->shade, &c->nodes})
@@ -807,6 +828,30 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
       a.hist_y1 = c->ext_hist_y1;
     }
   }
+  if (ext & rt::kExtVariance) {
+    if (!ubo) return fail(RTPT_E_INVALID, "RTPT_FLAG_EXT_VARIANCE needs the UBO (viewPrev/projPrev) on every iteration");
+    if (k == 1) {  // temporal accumulation of the luminance moments of the traced image (this iteration's input)
+      rt::MomentsArgs m;
+      std::memset(&m, 0, sizeof m);
+      m.g = geom(c, c->cfg.row_begin, c->cfg.row_end);
+      m.frame = pc->frameNumber;
+      m.alpha = c->cfg.alpha;
+      m.traced = a.in;
+      m.vis = a.vis;
+      m.worldpos = static_cast<const float4*>(c->worldpos.ptr);
+      m.lut_prev = static_cast<const float4*>(c->lut[c->lut_cur ^ 1].ptr);
+      rt::exact::mat_mul(ubo->projPrev, ubo->viewPrev, m.PVprev);
+      m.prev_vis = static_cast<const uint32_t*>(c->vis[c->vis_cur ^ 1].ptr);
+      m.moments_prev = static_cast<const float4*>(c->moments[c->moments_cur ^ 1].ptr);
+      m.moments_out = static_cast<float4*>(c->moments[c->moments_cur].ptr);
+      m.var_out = static_cast<float*>(c->variance[0].ptr);
+      rt::launch_moments(m, c->stream);
+      c->variance_last = 0;
+    }
+    a.var_in = static_cast<const float*>(c->variance[c->variance_last].ptr);
+    a.var_out = static_cast<float*>(c->variance[c->variance_last ^ 1].ptr);
+    c->variance_last ^= 1;
+  }
   {
     Timer tm(c, final_pass ? RTPT_K_ATROUS_FINAL : RTPT_K_ATROUS);
     rt::launch_atrous(a, final_pass, c->stream);
@@ -843,6 +888,7 @@ int rtpt_end_frame(rtpt_ctx* c) {
   c->hist_y1 = c->final_y1;
   // main.cpp:1367 visibilityBuffer -> previousVisibilityBuffer; main.cpp:1372 LUT -> LUTprev
   c->vis_cur ^= 1;
+  c->moments_cur ^= 1;
   c->lut_cur ^= 1;
   c->lut_prev_valid = c->n_tris != 0;
   c->final_swapped = false;

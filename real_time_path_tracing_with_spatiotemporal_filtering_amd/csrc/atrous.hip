@@ -173,6 +173,54 @@ __global__ __launch_bounds__(kThreads) void k_atrous(AtrousArgs a) {
 // one generic direct-load kernel (same tap arithmetic as k_atrous) rather than a tuned one.
 __constant__ float kGauss5[5][5] = {{1, 4, 7, 4, 1}, {4, 16, 26, 16, 4}, {7, 26, 41, 26, 7}, {4, 16, 26, 16, 4}, {1, 4, 7, 4, 1}};
 
+// reprojection of a pixel into the previous frame (temporalFiltering.comp.glsl:213-239, worldToPixel :178-189), exact
+// arithmetic: the truncated pixel coordinate is an integer observable
+__device__ __forceinline__ void reproject_pixel(int W, int H, const float* PVprev, uint32_t idp, f3 wp, const float4* lut_prev,
+                                                int x, int y, int& ppx, int& ppy) {
+  ppx = x;
+  ppy = y;
+  if (idp < 1) return;
+  const f3 va = xyz(lut_prev[3 * idp]), vb = xyz(lut_prev[3 * idp + 1]), vc = xyz(lut_prev[3 * idp + 2]);
+  const f3 bc = bary_coords(wp, va, vb, vc);
+  const f3 wpp = bary_mix(bc, va, vb, vc);
+  const float clx = exact::mat_row_point(PVprev, 0, wpp), cly = exact::mat_row_point(PVprev, 1, wpp),
+              clw = exact::mat_row_point(PVprev, 3, wpp);
+  const float ndx = clx / clw, ndy = cly / clw;
+  ppx = exact::f2i(fmaf_(ndx, 0.5f, 0.5f) * static_cast<float>(W));
+  ppy = exact::f2i(fmaf_(ndy, 0.5f, 0.5f) * static_cast<float>(H));
+}
+
+__device__ __forceinline__ float luminance(f3 c) { return fmaf_(0.0722f, c.z, fmaf_(0.7152f, c.y, 0.2126f * c.x)); }
+
+// RTPT_FLAG_EXT_VARIANCE (extension, see include/rtpt.h): first and second luminance moments accumulated along the
+// reprojected pixel, history length, and the variance the filter iterations are guided by.  Whole-frame contexts only.
+__global__ __launch_bounds__(kThreads) void k_moments(MomentsArgs a) {
+  const int x = blockIdx.x * kBlockX + threadIdx.x;
+  const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
+  if (x >= a.g.W || y >= a.g.y1) return;
+  const int W = a.g.W, H = a.g.H;
+  const size_t ip = static_cast<size_t>(y - a.g.row_base) * W + x;
+  const uint32_t id = a.vis[ip];
+  const float lum = luminance(xyz(a.traced[ip]));
+  int ppx, ppy;
+  reproject_pixel(W, H, a.PVprev, id, xyz(a.worldpos[ip]), a.lut_prev, x, y, ppx, ppy);
+  bool valid = a.frame > 0 && ppx >= 0 && ppx < W && ppy >= 0 && ppy < H;
+  const size_t iq = valid ? static_cast<size_t>(ppy - a.g.row_base) * W + ppx : 0;
+  if (valid) valid = a.prev_vis[iq] == id;
+  float m1 = lum, m2 = lum * lum, n = 1.0f;
+  if (valid) {
+    const float4 mp = a.moments_prev[iq];
+    const float al = glsl_max(a.alpha, 1.0f / (mp.z + 1.0f)), oma = 1.0f - al;
+    m1 = fmaf_(lum, al, mp.x * oma);
+    m2 = fmaf_(lum * lum, al, mp.y * oma);
+    n = glsl_min(mp.z + 1.0f, 255.0f);
+  }
+  float var = glsl_max(0.0f, fmaf_(-m1, m1, m2));
+  if (n < 4.0f) var = var * (4.0f / n);
+  a.moments_out[ip] = make_float4(m1, m2, n, var);
+  a.var_out[ip] = var;
+}
+
 template <bool FINAL, bool EXACT>
 __global__ __launch_bounds__(kThreads) void k_atrous_ext(AtrousArgs a) {
   int bx, by;
@@ -192,7 +240,13 @@ __global__ __launch_bounds__(kThreads) void k_atrous_ext(AtrousArgs a) {
   const float4 np4 = a.normal_tab[idp];
   const f3 np = xyz(np4);
   f3 num{0.f, 0.f, 0.f};
-  float den = 0.f;
+  float den = 0.f, vsum = 0.f;
+  // variance guidance (RTPT_FLAG_EXT_VARIANCE): the colour term compares luminances, scaled by the pixel's own
+  // standard deviation
+  const bool use_var = (a.ext & kExtVariance) && a.var_in;
+  const float lum_p = luminance(cp);
+  const float lum_scale = use_var ? fmaf_(a.sigma_l, exact::sqrt_(glsl_max(a.var_in[rowp + x], 0.0f)), 1e-4f) : 1.0f;
+  const float cl_var = -1.44269504088896341f * fast::rcp_(lum_scale);
   for (int i = -R; i <= R; i++) {    // :132
     for (int j = -R; j <= R; j++) {  // :133
       int qx = x + i * k, qy = y + j * k;  // :135
@@ -209,35 +263,29 @@ __global__ __launch_bounds__(kThreads) void k_atrous_ext(AtrousArgs a) {
       float w;
       if (EXACT) {
         const float wd = exact::exp_(-__builtin_fabsf(dp - dq) / a.sigma_z);  // :67-68
-        const float wl = exact::exp_(-exact::length(dc) / a.sigma_l);         // :73
+        const float wl = use_var ? exact::exp_(-__builtin_fabsf(lum_p - luminance(cq)) / lum_scale)
+                                 : exact::exp_(-exact::length(dc) / a.sigma_l);  // :73
         w = (wn * wd) * wl;                                                   // :77
       } else {
-        const float e = fmaf_(__builtin_fabsf(dp - dq), a.cz, fast::sqrt_(exact::dot(dc, dc)) * a.cl);
+        const float dl = use_var ? __builtin_fabsf(lum_p - luminance(cq)) * cl_var : fast::sqrt_(exact::dot(dc, dc)) * a.cl;
+        const float e = fmaf_(__builtin_fabsf(dp - dq), a.cz, dl);
         w = wn * __builtin_amdgcn_exp2f(e);
       }
       const float h = gauss ? kGauss5[i + 2][j + 2] * (1.0f / 273.0f) : 1.0f / 9.0f;  // :145
       const float hw = h * w;
       num = f3{fmaf_(hw, cq.x, num.x), fmaf_(hw, cq.y, num.y), fmaf_(hw, cq.z, num.z)};  // :146
       den = den + hw;                                                                    // :147
+      if (use_var) vsum = fmaf_(hw * hw, a.var_in[rowq + qx], vsum);
     }
   }
   const f3 filtered = f3{num.x / den, num.y / den, num.z / den};  // :150
+  if (use_var && a.var_out) a.var_out[rowp + x] = vsum / (den * den);
   if (!FINAL) {
     a.out[rowp + x] = make_float4(filtered.x, filtered.y, filtered.z, dp);
     return;
   }
-  int ppx = x, ppy = y;
-  if (!(idp < 1)) {
-    const f3 wp = xyz(a.worldpos[rowp + x]);
-    const f3 va = xyz(a.lut_prev[3 * idp]), vb = xyz(a.lut_prev[3 * idp + 1]), vc = xyz(a.lut_prev[3 * idp + 2]);
-    const f3 bc = bary_coords(wp, va, vb, vc);
-    const f3 wpp = bary_mix(bc, va, vb, vc);
-    const float clx = exact::mat_row_point(a.PVprev, 0, wpp), cly = exact::mat_row_point(a.PVprev, 1, wpp),
-                clw = exact::mat_row_point(a.PVprev, 3, wpp);
-    const float ndx = clx / clw, ndy = cly / clw;
-    ppx = exact::f2i(fmaf_(ndx, 0.5f, 0.5f) * static_cast<float>(W));
-    ppy = exact::f2i(fmaf_(ndy, 0.5f, 0.5f) * static_cast<float>(H));
-  }
+  int ppx, ppy;
+  reproject_pixel(W, H, a.PVprev, idp, xyz(a.worldpos[rowp + x]), a.lut_prev, x, y, ppx, ppy);
   if (a.prev_pixel) a.prev_pixel[rowp + x] = make_int2(ppx, ppy);
   bool use_history = a.frame > 0;  // :251
   const bool inside = ppx >= 0 && ppx < W && ppy >= 0 && ppy < H;
@@ -530,6 +578,11 @@ __global__ __launch_bounds__(kThreads) void k_stamp_depth(FrameGeom g, float4* c
 }
 
 }  // namespace
+
+void launch_moments(const MomentsArgs& a, hipStream_t s) {
+  if (a.g.y1 <= a.g.y0) return;
+  hipLaunchKernelGGL(k_moments, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
+}
 
 void launch_stamp_depth(const FrameGeom& g, float4* color, const float* depth, hipStream_t s) {
   if (g.y1 <= g.y0) return;

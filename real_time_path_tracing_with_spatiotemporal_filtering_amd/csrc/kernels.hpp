@@ -129,10 +129,30 @@ struct AtrousArgs {
   const float4* gradient;         // K1 output (adaptive alpha)
   const uint32_t* prev_vis;       // previous frame's id plane, rows [pvis_y0,pvis_y1) valid, stored from g.row_base
   int32_t pvis_y0, pvis_y1;
+  const float* var_in;            // RTPT_FLAG_EXT_VARIANCE: per-pixel luminance variance read by this iteration
+  float* var_out;                 //                         ... and the filtered variance it writes
 };
 
+// RTPT_FLAG_EXT_VARIANCE: temporal accumulation of the luminance moments before the first filter iteration
+struct MomentsArgs {
+  FrameGeom g;
+  uint32_t frame;
+  float alpha;
+  const float4* traced;
+  const uint32_t* vis;
+  const float4* worldpos;
+  const float4* lut_prev;
+  float PVprev[16];
+  const uint32_t* prev_vis;
+  const float4* moments_prev;
+  float4* moments_out;  // (m1, m2, n, var)
+  float* var_out;
+};
+void launch_moments(const MomentsArgs& a, hipStream_t s);
+
 constexpr uint32_t kExtAdaptiveAlpha = 0x10u, kExtGauss5 = 0x20u, kExtPow2Stride = 0x40u, kExtDisocclusion = 0x80u;
-constexpr uint32_t kExtMask = 0xF0u;
+constexpr uint32_t kExtVariance = 0x100u;
+constexpr uint32_t kExtMask = 0x1F0u;
 
 struct ScenePrepArgs {
   uint32_t n_tris;

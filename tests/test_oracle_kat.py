@@ -240,3 +240,44 @@ def test_ext_adaptive_alpha_and_disocclusion(oracle):
     outd = oracle.atrous(cfg, pc, ubo, img, depth, vis0, lut, lut, wp, hist, prev_vis=pv)
     assert outd[:, :w // 2].tobytes() == base[:, :w // 2].tobytes()
     assert outd[:, w // 2:].tobytes() == filtered[:, w // 2:].tobytes()
+
+
+def test_ext_variance_moments_definitions(oracle):
+    """EXT_VARIANCE: closed-form checks of oracle_moments and of the variance-guided weight"""
+    cfg, img, depth, vis, lut = _ext_inputs(oracle)
+    cfg.ext_flags = oracle.EXT_VARIANCE
+    w, h = cfg.width, cfg.height
+    pc, ubo = oracle.PushConstants(), oracle.Ubo()
+    vis0 = np.zeros((h, w), np.uint32)            # background: the reprojection is the identity (:216)
+    wp = np.zeros_like(img)
+    lum = (0.2126 * img[..., 0] + 0.7152 * img[..., 1] + 0.0722 * img[..., 2]).astype(np.float64)
+    # frame 0: no history
+    pc.frameNumber = 0
+    mo, var = oracle.moments(cfg, pc, ubo, img, vis0, wp, lut, None, None)
+    assert np.allclose(mo[..., 0], lum, rtol=1e-6) and np.allclose(mo[..., 1], lum * lum, rtol=1e-6)
+    assert (mo[..., 2] == 1).all() and np.array_equal(mo[..., 3], var) and var.max() < 1e-6
+    # frame 1 with the same ids: a = max(0.3, 1/2) = 0.5, n = 2, var = (m2 - m1^2) * 4/2
+    pc.frameNumber = 1
+    img2 = np.random.default_rng(5).random(img.shape, dtype=np.float32)
+    lum2 = (0.2126 * img2[..., 0] + 0.7152 * img2[..., 1] + 0.0722 * img2[..., 2]).astype(np.float64)
+    mo2, var2 = oracle.moments(cfg, pc, ubo, img2, vis0, wp, lut, vis0, mo)
+    m1 = 0.5 * lum + 0.5 * lum2
+    m2 = 0.5 * lum * lum + 0.5 * lum2 * lum2
+    assert (mo2[..., 2] == 2).all()
+    assert np.allclose(mo2[..., 0], m1, rtol=1e-5) and np.allclose(var2, np.maximum(0, m2 - m1 * m1) * 2.0, rtol=1e-3, atol=2e-6)
+    # a changed id at the reprojected pixel resets the history
+    pv = vis0.copy()
+    pv[:, : w // 2] = 9
+    mo3, var3 = oracle.moments(cfg, pc, ubo, img2, vis0, wp, lut, pv, mo)
+    assert (mo3[:, : w // 2, 2] == 1).all() and (mo3[:, w // 2:, 2] == 2).all()
+    # the filter: zero variance => the colour term only passes equal luminances; huge variance => it passes everything
+    pc.waveletIteration, pc.maxWaveletIteration = 1, 3
+    flat_var = np.zeros((h, w), np.float32)
+    out0, v0 = oracle.atrous(cfg, pc, ubo, img2, depth, vis0, lut, lut, wp, img2, var_in=flat_var)
+    same = np.isclose(out0[..., :3], img2[..., :3], rtol=1e-3, atol=1e-3).all(-1)
+    assert same.mean() > 0.95, "sigma_l * 0 + 1e-4: neighbours are rejected unless their luminance is within ~1e-4"
+    big = np.full((h, w), 1e12, np.float32)
+    out1, v1 = oracle.atrous(cfg, pc, ubo, img2, depth, vis0, lut, lut, wp, img2, var_in=big)
+    box = sum(np.roll(np.roll(img2[..., :3], i, 0), j, 1) for i in (-1, 0, 1) for j in (-1, 0, 1)) / 9
+    assert np.allclose(out1[2:-2, 2:-2, :3], box[2:-2, 2:-2], rtol=1e-4)
+    assert np.allclose(v1[2:-2, 2:-2], 1e12 / 9, rtol=1e-4), "equal weights: var' = sum(h^2 var) / (sum h)^2 = var / 9"
