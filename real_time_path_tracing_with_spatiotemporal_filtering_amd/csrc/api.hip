@@ -63,6 +63,9 @@ struct rtpt_ctx {
   int lut_cur = 0;
   Buf worldpos, gradient, depth, prev_pixel, hit_id, raycount, normal_tab, pair_tab;
   Buf moments[2], variance[2];  // RTPT_FLAG_EXT_VARIANCE
+  Buf normals;                  // per-pixel normal plane for the LDS-staged filter of scenes without an id-pair table
+  int normals_y0 = 0, normals_y1 = 0;  // rows for which it matches VIS_ID
+  uint64_t normals_frame = ~0ull;      // frame (frames_ended) those rows belong to
   int moments_cur = 0;          // moments[moments_cur] is written this frame, the other one is the history
   int variance_last = 0;        // variance[] buffer holding the newest values
 
@@ -321,6 +324,8 @@ static int alloc_planes(rtpt_ctx* c) {
   if (rc == RTPT_OK) rc = alloc_buf(c->gradient, px * 16);
   if (rc == RTPT_OK) rc = alloc_buf(c->depth, px * 4);
   if (rc == RTPT_OK && !c->raycount.ptr) rc = alloc_buf(c->raycount, 8);
+  free_buf(c->normals);  // sized per frame: re-created by the next rtpt_gbuffer
+  c->normals_y0 = c->normals_y1 = 0;
   if (c->cfg.flags & RTPT_FLAG_EXT_VARIANCE) {
     for (int i = 0; i < 2 && rc == RTPT_OK; i++) rc = alloc_buf(c->moments[i], px * 16);
     for (int i = 0; i < 2 && rc == RTPT_OK; i++) rc = alloc_buf(c->variance[i], px * 4);
@@ -416,6 +421,7 @@ int rtpt_destroy(rtpt_ctx* c) {
   if (c->handoff_event) (void)hipEventDestroy(c->handoff_event);
   for (auto& b : c->color) free_buf(b);
   for (auto& b : c->vis) free_buf(b);
+  free_buf(c->normals);
   for (auto& b : c->moments) free_buf(b);
   for (auto& b : c->variance) free_buf(b);
   for (auto& b : c->lut) free_buf(b);
@@ -601,6 +607,7 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   c->lut_prev_valid = false;
   c->lut_holds_scene[0] = c->lut_holds_scene[1] = false;
   c->tables_valid = false;
+  c->normals_y0 = c->normals_y1 = 0;  // the per-pixel normal plane belongs to the previous scene
   return RTPT_OK;
 }
 
@@ -665,6 +672,24 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
   a.vis = static_cast<uint32_t*>(c->vis[c->vis_cur].ptr);
   a.worldpos = static_cast<float4*>(c->worldpos.ptr);
   a.depth = static_cast<float*>(c->depth.ptr);
+  a.normals = nullptr;
+  a.normal_tab = static_cast<const float4*>(c->normal_tab.ptr);
+  if (!c->pair_tab.ptr) {  // more than 63 triangles: the filter stages per-pixel normals instead of ids
+    if (!c->normals.ptr) {
+      int rc2 = alloc_buf(c->normals, c->pixels() * 16);
+      if (rc2) return rc2;
+      c->normals_y0 = c->normals_y1 = 0;
+    }
+    a.normals = static_cast<float4*>(c->normals.ptr);
+    // rows written so far this frame (strips call the pass once per range; a new frame starts a new range)
+    if (c->normals_y1 == static_cast<int>(y0) && c->normals_frame == c->frames_ended)
+      c->normals_y1 = static_cast<int>(y1);
+    else {
+      c->normals_y0 = static_cast<int>(y0);
+      c->normals_y1 = static_cast<int>(y1);
+    }
+    c->normals_frame = c->frames_ended;
+  }
   {
     Timer tm(c, RTPT_K_GBUFFER);
     rt::launch_gbuffer(a, c->stream);
@@ -799,6 +824,11 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
   a.out = static_cast<float4*>(c->color[c->color_of_role[out_role]].ptr);
   a.vis = static_cast<const uint32_t*>(c->vis[c->vis_cur].ptr);
   a.normal_tab = static_cast<const float4*>(c->normal_tab.ptr);
+  {
+    const int64_t lo = std::max<int64_t>(0, static_cast<int64_t>(y0) - reach), hi = std::min<int64_t>(c->cfg.height, static_cast<int64_t>(y1) + reach);
+    const bool covered = c->normals.ptr && c->normals_frame == c->frames_ended && c->normals_y0 <= lo && c->normals_y1 >= hi;
+    a.normals = covered ? static_cast<const float4*>(c->normals.ptr) : nullptr;
+  }
   if (!c->alpha_depth[c->color_of_role[in_role]]) {
     // the input plane was injected (rtpt_set_plane / rtpt_bind_plane): give it its depth channel
     rt::launch_stamp_depth(geom(c, c->cfg.row_begin, c->cfg.row_end), static_cast<float4*>(c->color[c->color_of_role[in_role]].ptr),
@@ -944,6 +974,7 @@ int rtpt_set_plane(rtpt_ctx* c, rtpt_plane which, const void* src, size_t bytes)
     c->lut_holds_scene[c->lut_cur ^ 1] = false;  // injected content: rebuild when it becomes current
   }
   if (which == RTPT_PLANE_LUT) c->lut_holds_scene[c->lut_cur] = false;
+  if (which == RTPT_PLANE_VIS_ID) c->normals_y0 = c->normals_y1 = 0;  // the normal plane no longer matches the ids
   return RTPT_OK;
 }
 

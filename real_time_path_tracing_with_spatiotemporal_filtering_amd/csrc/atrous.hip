@@ -364,12 +364,17 @@ constexpr int kShWaves = RTPT_COMB_WAVES;    // waves (consecutive chunks) per b
 constexpr int kShHalves = RTPT_COMB_HALVES;  // 64-px segments per wave row: the 2k-column halo is paid once per 64*kShHalves px
 constexpr int kShThreads = 64 * kShWaves;
 
-template <int CWp, bool FINAL, bool EXACT>
+// NRM = true is the variant for scenes whose id-pair table does not fit LDS (more than 63 triangles, i.e. every
+// scene but the Cornell box): instead of the 4-byte id, each staged cell carries the pixel's normal — a second
+// 16-byte plane written by k_gbuffer (normal_tab[id]: n.xyz and the self weight) — and the normal weight is computed
+// per tap from the two staged normals with the same arithmetic as the direct kernel.  32 instead of 20 staged bytes
+// per pixel, but 3 vector-memory instructions per staged row instead of the direct kernel's 27 per pixel.
+template <int CWp, bool FINAL, bool EXACT, bool NRM = false>
 __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int W = a.g.W, H = a.g.H, k = a.k;
   constexpr int rows = kShWaves * kCombM + 2, cells = rows * CWp;  // block-shared rows
-  const int NP = static_cast<int>(a.n_tris) + 1;
+  const int NP = NRM ? 0 : static_cast<int>(a.n_tris) + 1;
   const int lane = static_cast<int>(threadIdx.x);
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   float* pairw = reinterpret_cast<float*>(lds_raw);  // [NP][NP]
@@ -377,6 +382,7 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
   unsigned char* mine = lds_raw + pair_bytes;  // one region per block
   const float4* col = reinterpret_cast<const float4*>(mine);                // (r, g, b, depth)
   const uint32_t* ids = reinterpret_cast<const uint32_t*>(mine + 16 * cells);
+  const float4* nrm = reinterpret_cast<const float4*>(mine + 16 * cells);   // NRM: (n.xyz, self weight) instead of ids
   const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)mine));
   const uint32_t lds_col = lds0, lds_ids = lds0 + 16u * static_cast<uint32_t>(cells);
 
@@ -399,6 +405,7 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
   const uint32_t lb_hi = x_lo + static_cast<uint32_t>((static_cast<uint64_t>(x_hi - x_lo) * (jx + 1)) / per_xcd);
   const int row_lo = a.g.row_base, row_hi = a.g.row_base + a.rows_stored - 1;
   const bool tail_lane = lane < 2 * k;  // columns 64 .. 64+2k-1
+  const bool sigma_is_128 = a.sigma_n == 128;
   const float h = 1.0f / 9.0f;  // :145
   // (residue, column, chunk group) of lb_lo, then advanced incrementally (scalar adds, no divisions)
   int r = static_cast<int>(lb_lo / per_res);
@@ -461,15 +468,22 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
     const size_t grow = static_cast<size_t>(gy - a.g.row_base) * W;  // wave-uniform
     const float4* rin = a.in + grow;
     const uint32_t* rvis = a.vis + grow;
+    const float4* rnrm = NRM ? a.normals + grow : nullptr;
     const uint32_t cj = static_cast<uint32_t>(j * CWp);
 #pragma unroll
     for (int hf = 0; hf < kShHalves; hf++) {
       dma_b128(rin, o16[hf], lds_col + (cj + 64u * hf) * 16u);
-      dma_b32(rvis, o4[hf], lds_ids + (cj + 64u * hf) * 4u);
+      if (NRM)
+        dma_b128(rnrm, o16[hf], lds_ids + (cj + 64u * hf) * 16u);
+      else
+        dma_b32(rvis, o4[hf], lds_ids + (cj + 64u * hf) * 4u);
     }
     if (tail_lane) {
       dma_b128(rin, o16[kShHalves], lds_col + (cj + 64u * kShHalves) * 16u);
-      dma_b32(rvis, o4[kShHalves], lds_ids + (cj + 64u * kShHalves) * 4u);
+      if (NRM)
+        dma_b128(rnrm, o16[kShHalves], lds_ids + (cj + 64u * kShHalves) * 16u);
+      else
+        dma_b32(rvis, o4[kShHalves], lds_ids + (cj + 64u * kShHalves) * 4u);
     }
   }
   // own DMA landed, then the barrier publishes every wave's rows to the block
@@ -486,9 +500,12 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
     const float4 cp4 = col[cc];
     const f3 cp = xyz(cp4);
     const float dp = cp4.w;
-    const uint32_t idp = ids[cc];
+    const size_t ip = static_cast<size_t>(y - a.g.row_base) * W + x;
+    const float4 np4 = NRM ? nrm[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const f3 np = xyz(np4);
+    const uint32_t idp = NRM ? (FINAL ? a.vis[ip] : 0u) : ids[cc];  // NRM: the id is only needed for the reprojection
     const float* prow = pairw + idp * NP;
-    const float wself = prow[idp];
+    const float wself = NRM ? np4.w : prow[idp];
     f3 num{0.f, 0.f, 0.f};
     float den = 0.f;
 #pragma unroll
@@ -505,7 +522,19 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
           const float4 cq4 = col[qi];
           cq = xyz(cq4);
           const float dq = cq4.w;
-          const float wn = prow[ids[qi]];  // :62 via the id-pair table
+          float wn;
+          if (NRM) {
+            // :62.  The reference's exponent is 128: seven squarings, straight-line (exact::powi's loop runs on the
+            // CU's single scalar unit and made this variant SALU-bound: 166 us; same products, same order)
+            const float x = glsl_max(0.0f, exact::dot(np, xyz(nrm[qi])));
+            if (sigma_is_128) {
+              const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32;
+              wn = x64 * x64;
+            } else {
+              wn = exact::powi(x, a.sigma_n);
+            }
+          } else
+            wn = prow[ids[qi]];  // :62 via the id-pair table
           const f3 dc = cp - cq;
           if (EXACT) {
             const float wd = exact::exp_(-__builtin_fabsf(dp - dq) / a.sigma_z);  // :67-68
@@ -534,7 +563,6 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
     } else {
       filtered = num * fast::rcp_(den);
     }
-    const size_t ip = static_cast<size_t>(y - a.g.row_base) * W + x;
     if (!FINAL) {
       a.out[ip] = make_float4(filtered.x, filtered.y, filtered.z, dp);  // :152 (+ depth in alpha)
       continue;
@@ -614,7 +642,9 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
     }
     return;
   }
-  if (!a.direct && a.pair_tab && np <= kPairMax && a.k >= 1 && a.k <= 16) {
+  const bool pair_mode = a.pair_tab && np <= kPairMax;
+  const bool nrm_mode = !pair_mode && a.normals != nullptr;
+  if (!a.direct && (pair_mode || nrm_mode) && a.k >= 1 && a.k <= 16) {
     const int seg_w = kBlockX * kShHalves;
     a.tiles_x = (a.g.W + seg_w - 1) / seg_w;
     const int nrows = a.g.y1 - a.g.y0;
@@ -632,7 +662,8 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
     const int need = seg_w + 2 * a.k;
     const int base_w = seg_w;
     const int cw = need <= base_w + 8 ? base_w + 8 : (need <= base_w + 16 ? base_w + 16 : base_w + 32);
-    const size_t lds = static_cast<size_t>((np * np * 4 + 15) & ~15) + static_cast<size_t>(kShWaves * kCombM + 2) * cw * 20;
+    const size_t lds = nrm_mode ? static_cast<size_t>(kShWaves * kCombM + 2) * cw * 32
+                                : static_cast<size_t>((np * np * 4 + 15) & ~15) + static_cast<size_t>(kShWaves * kCombM + 2) * cw * 20;
     // persistent grid: as many blocks per CU as 160 KiB of LDS and 32 waves admit
     uint32_t per_cu = static_cast<uint32_t>((160u * 1024u) / lds);
     if (per_cu > 32u / kShWaves) per_cu = 32u / kShWaves;
@@ -640,34 +671,43 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
     uint32_t per_xcd = static_cast<uint32_t>((n_cu + 7) / 8) * per_cu;
     if (per_xcd > (nlb + 7) / 8) per_xcd = (nlb + 7) / 8;
     dim3 grid(per_xcd * 8u), sblock(kBlockX, kShWaves);
-#define RTPT_LAUNCH_COMB(CW)                                                                          \
+#define RTPT_LAUNCH_COMB(CW, NRM)                                                                          \
   do {                                                                                                \
     static bool attr = false; /* one per instantiated stride */                                       \
     if (!attr) {                                                                                      \
       attr = true;                                                                                    \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, true, true, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, true, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, true, false, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, false, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     }                                                                                                 \
     if (a.exact) {                                                                                    \
       if (final_pass)                                                                                 \
-        hipLaunchKernelGGL((k_atrous_comb_sh<CW, true, true>), grid, sblock, lds, s, a);              \
+        hipLaunchKernelGGL((k_atrous_comb_sh<CW, true, true, NRM>), grid, sblock, lds, s, a);              \
       else                                                                                            \
-        hipLaunchKernelGGL((k_atrous_comb_sh<CW, false, true>), grid, sblock, lds, s, a);             \
+        hipLaunchKernelGGL((k_atrous_comb_sh<CW, false, true, NRM>), grid, sblock, lds, s, a);             \
     } else {                                                                                          \
       if (final_pass)                                                                                 \
-        hipLaunchKernelGGL((k_atrous_comb_sh<CW, true, false>), grid, sblock, lds, s, a);             \
+        hipLaunchKernelGGL((k_atrous_comb_sh<CW, true, false, NRM>), grid, sblock, lds, s, a);             \
       else                                                                                            \
-        hipLaunchKernelGGL((k_atrous_comb_sh<CW, false, false>), grid, sblock, lds, s, a);            \
+        hipLaunchKernelGGL((k_atrous_comb_sh<CW, false, false, NRM>), grid, sblock, lds, s, a);            \
     }                                                                                                 \
   } while (0)
-    if (cw == base_w + 8)
-      RTPT_LAUNCH_COMB(kBlockX * kShHalves + 8);
-    else if (cw == base_w + 16)
-      RTPT_LAUNCH_COMB(kBlockX * kShHalves + 16);
-    else
-      RTPT_LAUNCH_COMB(kBlockX * kShHalves + 32);
+    if (nrm_mode) {
+      if (cw == base_w + 8)
+        RTPT_LAUNCH_COMB(kBlockX * kShHalves + 8, true);
+      else if (cw == base_w + 16)
+        RTPT_LAUNCH_COMB(kBlockX * kShHalves + 16, true);
+      else
+        RTPT_LAUNCH_COMB(kBlockX * kShHalves + 32, true);
+    } else {
+      if (cw == base_w + 8)
+        RTPT_LAUNCH_COMB(kBlockX * kShHalves + 8, false);
+      else if (cw == base_w + 16)
+        RTPT_LAUNCH_COMB(kBlockX * kShHalves + 16, false);
+      else
+        RTPT_LAUNCH_COMB(kBlockX * kShHalves + 32, false);
+    }
 #undef RTPT_LAUNCH_COMB
     return;
   }

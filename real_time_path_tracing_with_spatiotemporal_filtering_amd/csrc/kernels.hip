@@ -331,6 +331,7 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
     closest_hit<BVH>(a.scene, o, d, h, stack, tid);
   const size_t i = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
   a.vis[i] = h.id1;  // visibility.frag.glsl:23
+  if (a.normals) a.normals[i] = a.normal_tab[h.id1];
   if (h.id1) {
     float b1 = h.u / h.ad, b2 = h.v / h.ad;
     float b0 = 1.0f - b1 - b2;

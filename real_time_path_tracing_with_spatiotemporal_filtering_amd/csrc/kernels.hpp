@@ -50,6 +50,8 @@ struct GbufferArgs {
   uint32_t* vis;
   float4* worldpos;
   float* depth;
+  float4* normals;            // nullable: per-pixel normal_tab[id] for the LDS-staged filter of large scenes
+  const float4* normal_tab;   // per-id (n.xyz, self weight), built by k_lut
   int32_t cull;                      // 1: bounds[] is valid
   TriBounds bounds[kCullMaxTris];
 };
@@ -104,6 +106,7 @@ struct AtrousArgs {
   int32_t rows_stored;   // rows held by the planes (row_base .. row_base+rows_stored-1)
   int32_t cwp;           // comb kernel: staged row length in cells (set by launch_atrous)
   const float* pair_tab; // (n_tris+1)^2 id-pair normal weights, NULL when the scene is too large
+  const float4* normals; // per-pixel (n.xyz, self weight) plane written by k_gbuffer for such scenes, NULL otherwise
   uint32_t n_tris;       // normal_tab has n_tris + 1 entries
   int32_t sigma_n;
   float cz, cl;          // fast path: -log2(e)/sigma_z, -log2(e)/sigma_l (set by launch_atrous)
