@@ -23,6 +23,17 @@
 namespace rt {
 namespace {
 
+// x^n for the normal weight (temporalFiltering.comp.glsl:62).  The reference's exponent is 128: seven squarings,
+// written straight-line — exact::powi's square-and-multiply LOOP yields the same products in the same order but
+// runs its control flow on the CU's single scalar unit, which made per-tap use of it SALU-bound.
+__device__ __forceinline__ float pow_sigma(float x, int n) {
+  if (n == 128) {
+    const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32;
+    return x64 * x64;
+  }
+  return exact::powi(x, n);
+}
+
 // XCD-aware tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an
 // XCD and its private 4 MiB L2).  The stencil re-reads every input row at y-k, y and y+k, so the three
 // uses must meet in ONE L2 while the rows in between are streamed through it.  Tiles are therefore
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void k_atrous(AtrousArgs a) {
           wn = np4.w;  // same primitive: the per-id self weight (same bits as recomputing it)
         } else {
           const f3 nq = xyz(a.normal_tab[idq]);
-          wn = exact::powi(glsl_max(0.0f, exact::dot(np, nq)), a.sigma_n);  // :62
+          wn = pow_sigma(glsl_max(0.0f, exact::dot(np, nq)), a.sigma_n);  // :62
         }
         const f3 dc = cp - cq;
         if (EXACT) {
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(kThreads) void k_atrous_ext(AtrousArgs a) {
       const float dq = cq4.w;
       const uint32_t idq = a.vis[rowq + qx];
       const f3 nq = xyz(a.normal_tab[idq]);
-      const float wn = exact::powi(glsl_max(0.0f, exact::dot(np, nq)), a.sigma_n);  // :62
+      const float wn = pow_sigma(glsl_max(0.0f, exact::dot(np, nq)), a.sigma_n);  // :62
       const f3 dc = cp - cq;
       float w;
       if (EXACT) {
@@ -405,7 +416,6 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
   const uint32_t lb_hi = x_lo + static_cast<uint32_t>((static_cast<uint64_t>(x_hi - x_lo) * (jx + 1)) / per_xcd);
   const int row_lo = a.g.row_base, row_hi = a.g.row_base + a.rows_stored - 1;
   const bool tail_lane = lane < 2 * k;  // columns 64 .. 64+2k-1
-  const bool sigma_is_128 = a.sigma_n == 128;
   const float h = 1.0f / 9.0f;  // :145
   // (residue, column, chunk group) of lb_lo, then advanced incrementally (scalar adds, no divisions)
   int r = static_cast<int>(lb_lo / per_res);
@@ -524,15 +534,8 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
           const float dq = cq4.w;
           float wn;
           if (NRM) {
-            // :62.  The reference's exponent is 128: seven squarings, straight-line (exact::powi's loop runs on the
-            // CU's single scalar unit and made this variant SALU-bound: 166 us; same products, same order)
-            const float x = glsl_max(0.0f, exact::dot(np, xyz(nrm[qi])));
-            if (sigma_is_128) {
-              const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32;
-              wn = x64 * x64;
-            } else {
-              wn = exact::powi(x, a.sigma_n);
-            }
+            // :62 (pow_sigma: with exact::powi's loop this variant was SALU-bound at 166 us)
+            wn = pow_sigma(glsl_max(0.0f, exact::dot(np, xyz(nrm[qi]))), a.sigma_n);
           } else
             wn = prow[ids[qi]];  // :62 via the id-pair table
           const f3 dc = cp - cq;
