@@ -325,6 +325,43 @@ def test_reference_default_config_32_segments(hip_lib, oracle, cornell):
     assert ok, rel
 
 
+def test_reference_default_config_full_size(hip_lib, oracle, cornell):
+    """the reference's own constants at its own size: 1000x800 (main.cpp:52-53), 32 segments, N = 9, three frames
+    with a camera move — the final image bit for bit (exact filter)"""
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    app, ref = make_pair(hip_lib, oracle, cornell, w=1000, h=800, seg=32, n=9, flags=hip_lib.FLAG_EXACT_FILTER)
+    try:
+        total = 0
+        for f in range(3):
+            app.drawScene(("D",) if f == 2 else ())
+            fo = ref.draw_scene(move_camera=(0.1, 0, 0) if f == 2 else None)
+            total += fo.rays
+        got = app.backend.readback_rows(hip_lib.PLANE_PREVIOUS, 0, 800)
+        assert np.array_equal(bits(got), bits(fo.image))
+        assert app.backend.ctx.raycount() == total
+    finally:
+        oracle.set_threads(min(8, os.cpu_count() or 1))
+        app.backend.close()
+
+
+def test_8k_frame_properties(hip_lib):
+    """7680x4320 (2 GB of planes): sizes beyond BASELINE's through properties — finite output, the ray count of a
+    deterministic frame sequence, and serial == two-frames-in-flight bit for bit"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    outs = []
+    for fif in (1, 2):
+        app = make_app(7680, 4320, max_segments=4, iterations=5, flags=hip_lib.FLAG_EXACT_FILTER, frames_in_flight=fif)
+        for f in range(3):
+            app.drawScene(("J",) if f == 1 else ())
+        be = app.backend
+        img = be.final_image_rows(0, 4320) if fif == 2 else be.readback_rows(hip_lib.PLANE_PREVIOUS, 0, 4320)
+        outs.append((img, be.raycount() if fif == 2 else be.ctx.raycount()))
+        be.close()
+    assert outs[0][1] == outs[1][1] and outs[0][1] > 3 * 7680 * 4320
+    assert np.isfinite(outs[0][0][..., :3]).all() and not outs[0][0][..., 3].any()
+    assert np.array_equal(bits(outs[0][0]), bits(outs[1][0]))
+
+
 def test_spp_4(hip_lib, oracle, cornell):
     from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
     xyz, idx, tris = cornell
