@@ -368,6 +368,9 @@ constexpr int kPairMax = 64;    // ids (T+1) for which the pair table is kept in
 #ifndef RTPT_COMB_ORDER
 #define RTPT_COMB_ORDER 1  // 1: row-major work list dealt item by item (shipping); 0: each block walks down a column
 #endif
+#ifndef RTPT_COMB_PRIO
+#define RTPT_COMB_PRIO 1  // waves run at priority 3 while they issue an item's DMAs: 4K 67.0 -> 65.5 us (in-process A/B)
+#endif
 #ifndef RTPT_COMB_HALVES
 #define RTPT_COMB_HALVES 1
 #endif
@@ -468,6 +471,9 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
   // every wave is done reading the previous group's rows before anybody overwrites them
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#if RTPT_COMB_PRIO
+  __builtin_amdgcn_s_setprio(3);  // issue this item's DMAs ahead of the other waves' arithmetic
+#endif
   // wave w stages rows w*M+1 .. w*M+M; wave 0 also row 0, the last wave also row 4M+1
   const int j_lo = wave * kCombM + (wave == 0 ? 0 : 1);
   const int j_hi = wave * kCombM + kCombM + (wave == kShWaves - 1 ? 1 : 0);
@@ -496,6 +502,9 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
         dma_b32(rvis, o4[kShHalves], lds_ids + (cj + 64u * kShHalves) * 4u);
     }
   }
+#if RTPT_COMB_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   // own DMA landed, then the barrier publishes every wave's rows to the block
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
