@@ -371,6 +371,13 @@ constexpr int kPairMax = 64;    // ids (T+1) for which the pair table is kept in
 #ifndef RTPT_COMB_PRIO
 #define RTPT_COMB_PRIO 1  // waves run at priority 3 while they issue an item's DMAs: 4K 67.0 -> 65.5 us (in-process A/B)
 #endif
+#ifndef RTPT_COMB_NT_STORE
+#define RTPT_COMB_NT_STORE 1  // non-temporal stores for the k < N passes (the pass does not re-read its output): 65 -> 62.5 us
+                              // in a frame; a pass repeated on the SAME buffers drops to 54 us (77 %) because its input then stays
+                              // in the 256 MB memory-side cache — in a frame the input was just written by the previous pass.
+                              // Tried without gain: nt on the final pass's store, nt on the staging loads (66-69 us),
+                              // alternating the walk direction per pass so a pass starts on the rows written last
+#endif
 #ifndef RTPT_COMB_HALVES
 #define RTPT_COMB_HALVES 1
 #endif
@@ -576,7 +583,15 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
       filtered = num * fast::rcp_(den);
     }
     if (!FINAL) {
+#if RTPT_COMB_NT_STORE
+      {
+        typedef float v4f_ __attribute__((ext_vector_type(4)));
+        v4f_ o4 = {filtered.x, filtered.y, filtered.z, dp};
+        __builtin_nontemporal_store(o4, reinterpret_cast<v4f_*>(a.out + ip));  // :152; not re-read by this pass
+      }
+#else
       a.out[ip] = make_float4(filtered.x, filtered.y, filtered.z, dp);  // :152 (+ depth in alpha)
+#endif
       continue;
     }
     // :213-239 reprojection — exact arithmetic: the truncated pixel coordinate is an integer observable
@@ -602,7 +617,15 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
       blend = f3{fmaf_(filtered.x, a.alpha, hc.x * oma), fmaf_(filtered.y, a.alpha, hc.y * oma),
                  fmaf_(filtered.z, a.alpha, hc.z * oma)};  // :254
     }
+#if RTPT_COMB_NT_STORE > 1
+    {
+      typedef float v4f_ __attribute__((ext_vector_type(4)));
+      v4f_ o4 = {blend.x, blend.y, blend.z, 0.0f};
+      __builtin_nontemporal_store(o4, reinterpret_cast<v4f_*>(a.out + ip));  // :263 (D1: distinct buffer)
+    }
+#else
     a.out[ip] = make_float4(blend.x, blend.y, blend.z, 0.0f);  // :263 (D1: distinct buffer)
+#endif
   }
   }  // work list
 }
