@@ -131,6 +131,9 @@ __device__ __forceinline__ bool slab(float mnx, float mny, float mnz, float mxx,
 // order and cull; the triangle test is binary32 on the exact records.
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kSentinel = 0xFFFFFFFEu;
+#ifndef RTPT_GRAD_NT_STORE
+#define RTPT_GRAD_NT_STORE 1
+#endif
 #ifndef RTPT_BVH_SPECULATE
 #define RTPT_BVH_SPECULATE 0
 #endif
@@ -408,7 +411,17 @@ __global__ __launch_bounds__(kThreads) void k_gradient(GradientArgs a) {
     float delta = glsl_max(exact::length(cur), exact::length(prv));
     lam = glsl_min(1.0f, exact::length(tg) / delta);
   }
+#if RTPT_GRAD_NT_STORE
+  {
+    // nothing on the reference's path reads the gradient again (its consumer is commented out,
+    // temporalFiltering.comp.glsl:247-248): keep the 133 MB out of the caches the filter passes need
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    v4f_ g4 = {lam, lam, lam, 0.0f};
+    __builtin_nontemporal_store(g4, reinterpret_cast<v4f_*>(a.grad + i));
+  }
+#else
   a.grad[i] = make_float4(lam, lam, lam, 0.0f);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
