@@ -96,6 +96,10 @@ typedef struct rtpt_visibility_data {
 #define RTPT_FLAG_NO_PATH_COMPACTION 0x8u /* path tracer: keep one pixel per lane for the whole path instead of
                                             compacting the surviving paths of a tile after every segment */
 
+#define RTPT_FLAG_SINGLE_LAUNCH_PATHS 0x200u /* path tracer: run all segments of a path in the tile kernel instead of
+                                              handing the paths that survive 4 / 8 / 16 segments to follow-up launches
+                                              through a queue (A/B switch; the image is the same) */
+
 /* Extension modes — NOT reference behaviour, default off.  They switch on the pieces of the textbook
  * A-SVGF that the reference declares but leaves unused; any of them routes K3 to a
  * generic direct-load kernel.  They cannot be parity-checked against the reference; tests/ check them

@@ -21,6 +21,7 @@ FLAG_EXACT_FILTER, FLAG_FORCE_BVH, FLAG_DIRECT_FILTER, FLAG_NO_PATH_COMPACTION =
 # extension modes (not reference behaviour, see include/rtpt.h)
 FLAG_EXT_ADAPTIVE_ALPHA, FLAG_EXT_GAUSS5, FLAG_EXT_POW2_STRIDE, FLAG_EXT_DISOCCLUSION = 0x10, 0x20, 0x40, 0x80
 FLAG_EXT_VARIANCE = 0x100
+FLAG_SINGLE_LAUNCH_PATHS = 0x200
 FLAG_EXT_MASK = 0x1F0
 DEBUG_HIT_ID, DEBUG_PREV_PIXEL = 0x1, 0x2
 

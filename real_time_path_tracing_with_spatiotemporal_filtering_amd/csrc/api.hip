@@ -63,6 +63,7 @@ struct rtpt_ctx {
   int lut_cur = 0;
   Buf worldpos, gradient, depth, prev_pixel, hit_id, raycount, normal_tab, pair_tab;
   Buf moments[2], variance[2];  // RTPT_FLAG_EXT_VARIANCE
+  Buf path_queue[2], path_queue_count;  // long paths: survivors handed from one k_pathtrace launch to the next
   Buf normals;                  // per-pixel normal plane for the LDS-staged filter of scenes without an id-pair table
   int normals_y0 = 0, normals_y1 = 0;  // rows for which it matches VIS_ID
   uint64_t normals_frame = ~0ull;      // frame (frames_ended) those rows belong to
@@ -324,6 +325,7 @@ static int alloc_planes(rtpt_ctx* c) {
   if (rc == RTPT_OK) rc = alloc_buf(c->gradient, px * 16);
   if (rc == RTPT_OK) rc = alloc_buf(c->depth, px * 4);
   if (rc == RTPT_OK && !c->raycount.ptr) rc = alloc_buf(c->raycount, 8);
+  for (auto& b : c->path_queue) free_buf(b);  // sized per frame: re-created by the next rtpt_raytrace
   free_buf(c->normals);  // sized per frame: re-created by the next rtpt_gbuffer
   c->normals_y0 = c->normals_y1 = 0;
   if (c->cfg.flags & RTPT_FLAG_EXT_VARIANCE) {
@@ -422,6 +424,8 @@ int rtpt_destroy(rtpt_ctx* c) {
   for (auto& b : c->color) free_buf(b);
   for (auto& b : c->vis) free_buf(b);
   free_buf(c->normals);
+  free_buf(c->path_queue_count);
+  for (auto& b : c->path_queue) free_buf(b);
   for (auto& b : c->moments) free_buf(b);
   for (auto& b : c->variance) free_buf(b);
   for (auto& b : c->lut) free_buf(b);
@@ -758,6 +762,20 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   a.count_y0 = c->count_y0;
   a.count_y1 = c->count_y1;
   a.compact = (c->cfg.flags & RTPT_FLAG_NO_PATH_COMPACTION) ? 0 : 1;
+  a.queue[0] = a.queue[1] = nullptr;
+  a.queue_count = nullptr;
+  a.queue_capacity = 0;
+  if (a.compact && a.spp == 1 && a.max_segments > rt::pt_first_window(c->use_bvh) && !(c->cfg.flags & RTPT_FLAG_SINGLE_LAUNCH_PATHS)) {
+    // one 48-byte record per pixel at most; the second buffer only when a third segment window exists
+    const size_t cap = c->pixels();
+    if (!c->path_queue_count.ptr && (rc = alloc_buf(c->path_queue_count, 2 * sizeof(uint32_t)))) return rc;
+    if (!c->path_queue[0].ptr && (rc = alloc_buf(c->path_queue[0], cap * 48))) return rc;
+    if (a.max_segments > 2u * rt::pt_first_window(c->use_bvh) && !c->path_queue[1].ptr && (rc = alloc_buf(c->path_queue[1], cap * 48))) return rc;
+    a.queue[0] = c->path_queue[0].ptr;
+    a.queue[1] = c->path_queue[1].ptr;
+    a.queue_count = static_cast<uint32_t*>(c->path_queue_count.ptr);
+    a.queue_capacity = static_cast<uint32_t>(cap);
+  }
   a.cull = 0;
   if (!c->use_bvh && c->width_fits_i16()) {
     // K2 camera (raytrace.comp.glsl:314-320): at cameraPos, looking down -z, d = (slope*ux, slope*uy, -1) with

@@ -450,6 +450,55 @@ __device__ __forceinline__ f3 sky_color(f3 d) {  // raytrace.comp.glsl:95-107
   return f3{0.03f, 0.03f, 0.03f};
 }
 
+// One path segment after its closest-hit query (raytrace.comp.glsl:226-267): the unoccluded light test, the sky, or a
+// diffuse bounce.  Returns true when the path ended (its colour is then `acc`).
+__device__ __forceinline__ bool shade_segment(const PathtraceArgs& a, const HitRec& h, uint32_t seg, f3 light_c, f3& o, f3& d,
+                                              f3& acc, uint32_t& rng) {
+  if (ray_hits_light(o, d, light_c, a.light_r2)) {  // :226
+    acc = acc * (seg == 0 ? ld3(a.light_col_first) : ld3(a.light_col));  // :229,:233
+    return true;
+  }
+  if (h.id1 == 0) {
+    acc = acc * sky_color(d);  // :266
+    return true;
+  }
+  const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
+  float4 s0 = s[0], s1 = s[1], s2 = s[2];
+  float b1 = h.u / h.ad, b2 = h.v / h.ad;
+  float b0 = 1.0f - b1 - b2;                                       // :134
+  f3 pos = bary_point(xyz(s0), xyz(s1), xyz(s2), b0, b1, b2);      // :137
+  f3 n{s0.w, s1.w, s2.w};                                          // :150 (precomputed per triangle)
+  f3 alb = (n.x > 0.99f) ? f3{1.f, 0.f, 0.f} : ((-n.x > 0.99f) ? f3{0.f, 1.f, 0.f} : f3{0.7f, 0.7f, 0.7f});  // :155-163
+  acc = acc * alb;                                                 // :244
+  if (!(exact::dot(n, d) < 0.0f)) n = -n;                          // :247 faceforward
+  o = f3{fmaf_(a.ray_offset, n.x, pos.x), fmaf_(a.ray_offset, n.y, pos.y), fmaf_(a.ray_offset, n.z, pos.z)};  // :250
+  float st_, ct;
+  exact::sincos2pi(exact::rng_next(rng), st_, ct);                 // :256
+  float u = fmaf_(2.0f, exact::rng_next(rng), -1.0f);              // :257
+  float r = exact::sqrt_(fmaf_(-u, u, 1.0f));                      // :258
+  d = exact::normalize(f3{fmaf_(r, ct, n.x), fmaf_(r, st_, n.y), n.z + u});  // :259-261
+  return seg + 1 >= a.max_segments;  // budget exhausted: the path returns its throughput (:270)
+}
+
+// Hand-over of the paths a launch did not finish (PathtraceArgs::seg_end < max_segments) to the next launch: one
+// atomic per wave reserves the slots, each surviving lane writes its 48-byte record.
+__device__ __forceinline__ void enqueue_paths(const PathtraceArgs& a, bool alive, uint32_t lane, uint32_t pixg, uint32_t rng, f3 o,
+                                              f3 d, f3 acc) {
+  const unsigned long long m = __ballot(alive);
+  if (!m) return;
+  uint32_t base = 0;
+  const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(m));
+  if (lane == leader) base = atomicAdd(a.q_out_count, static_cast<uint32_t>(__builtin_popcountll(m)));
+  base = __builtin_amdgcn_readlane(base, leader);
+  if (alive) {
+    const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+    float4* q = reinterpret_cast<float4*>(a.q_out) + 3 * static_cast<size_t>(slot);
+    q[0] = make_float4(__uint_as_float(pixg), __uint_as_float(rng), o.x, o.y);
+    q[1] = make_float4(o.z, d.x, d.y, d.z);
+    q[2] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+  }
+}
+
 // K2 tile kernel with optional per-segment compaction (PathtraceArgs::compact).
 //
 // A 256-thread block owns a 64x4 pixel tile and advances all of its paths one segment at a time
@@ -542,7 +591,7 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
       o = ld3(a.cam);
       acc = f3{1.f, 1.f, 1.f};  // :201
     }
-    for (uint32_t seg = 0; seg < a.max_segments; seg++) {  // :204 (block-uniform)
+    for (uint32_t seg = 0; seg < a.seg_end; seg++) {  // :204 (block-uniform); seg_end < max_segments: the rest is handed over
       if (alive) {
         HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
         if (!BVH && a.cull && seg == 0)
@@ -553,31 +602,7 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
         if (y >= a.count_y0 && y < a.count_y1) rays++;
         const size_t gi = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
         if (seg == 0 && smp == 0 && a.hit_id) a.hit_id[gi] = h.id1;
-        bool done;
-        if (ray_hits_light(o, d, light_c, a.light_r2)) {  // :226
-          acc = acc * (seg == 0 ? ld3(a.light_col_first) : ld3(a.light_col));  // :229,:233
-          done = true;
-        } else if (h.id1 == 0) {
-          acc = acc * sky_color(d);  // :266
-          done = true;
-        } else {
-          const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
-          float4 s0 = s[0], s1 = s[1], s2 = s[2];
-          float b1 = h.u / h.ad, b2 = h.v / h.ad;
-          float b0 = 1.0f - b1 - b2;                                       // :134
-          f3 pos = bary_point(xyz(s0), xyz(s1), xyz(s2), b0, b1, b2);      // :137
-          f3 n{s0.w, s1.w, s2.w};                                          // :150 (precomputed per triangle)
-          f3 alb = (n.x > 0.99f) ? f3{1.f, 0.f, 0.f} : ((-n.x > 0.99f) ? f3{0.f, 1.f, 0.f} : f3{0.7f, 0.7f, 0.7f});  // :155-163
-          acc = acc * alb;                                                 // :244
-          if (!(exact::dot(n, d) < 0.0f)) n = -n;                          // :247 faceforward
-          o = f3{fmaf_(a.ray_offset, n.x, pos.x), fmaf_(a.ray_offset, n.y, pos.y), fmaf_(a.ray_offset, n.z, pos.z)};  // :250
-          float st_, ct;
-          exact::sincos2pi(exact::rng_next(rng), st_, ct);                 // :256
-          float u = fmaf_(2.0f, exact::rng_next(rng), -1.0f);              // :257
-          float r = exact::sqrt_(fmaf_(-u, u, 1.0f));                      // :258
-          d = exact::normalize(f3{fmaf_(r, ct, n.x), fmaf_(r, st_, n.y), n.z + u});  // :259-261
-          done = (seg + 1 >= a.max_segments);  // budget exhausted: the path returns its throughput (:270)
-        }
+        const bool done = shade_segment(a, h, seg, light_c, o, d, acc, rng);
         if (done) {
           alive = false;
           if (a.spp == 1) {
@@ -591,7 +616,7 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
           }
         }
       }
-      if (seg + 1 >= a.max_segments) break;
+      if (seg + 1 >= a.seg_end) break;
       if (!COMPACT) {  // short paths: keep the lane <-> pixel mapping, a wave leaves when all its paths ended
         if (__ballot(alive) == 0ull) break;
         continue;
@@ -628,6 +653,11 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
       }
       __syncthreads();  // everybody has read its slot before the next compaction writes
     }
+    if (a.seg_end < a.max_segments) {  // only with spp == 1: the unfinished paths continue in k_pathtrace_queue
+      const uint32_t pixg = (static_cast<uint32_t>(tile_y0 + static_cast<int>(pix >> 6)) << 16) |
+                            static_cast<uint32_t>(tile_x0 + static_cast<int>(pix & 63u));
+      enqueue_paths(a, alive, lane, pixg, rng, o, d, acc);
+    }
   }
   __syncthreads();
   if (a.spp > 1) {
@@ -647,6 +677,93 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // self tests
+// Later segments of long paths.  By segment 8 a quarter of the Cornell box's paths is still alive, by segment 16 a
+// tenth: a 64x4 tile is then one partly filled wave in a workgroup that still holds its LDS and wave slots, and the
+// kernel — which needs its occupancy — runs a handful of waves per CU.  So a launch covers a window of segments
+// [seg_begin, seg_end) only and hands its survivors to the next one through a queue in global memory (48-byte records,
+// one atomic per wave), where they are dense again: this kernel takes 256 queued paths per workgroup, runs the same
+// segment body with the same per-segment compaction, and queues what is left for the window after it.  Each path
+// still executes the reference's loop with its own RNG stream, so the image does not change.
+template <bool BVH>
+__global__ __launch_bounds__(kPtThreads) void k_pathtrace_queue(PathtraceArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t stack[];
+  PathState& st = *reinterpret_cast<PathState*>(stack);
+  __shared__ uint32_t wave_cnt[kPtRows];
+  __shared__ unsigned int block_rays;
+  const int tid = threadIdx.y * kBlockX + threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const uint32_t lane = threadIdx.x;
+  if (tid == 0) block_rays = 0;
+  const f3 light_c = ld3(a.light_c);
+  const uint32_t n_in = *a.q_in_count;
+  unsigned int rays = 0;
+  for (uint32_t base = blockIdx.x * kPtThreads; base < n_in; base += gridDim.x * kPtThreads) {  // block-uniform
+    uint32_t pix = 0, rng = 0;
+    f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, -1.f}, acc{1.f, 1.f, 1.f};
+    bool alive = base + static_cast<uint32_t>(tid) < n_in;
+    if (alive) {
+      const float4* q = reinterpret_cast<const float4*>(a.q_in) + 3 * static_cast<size_t>(base + tid);
+      const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+      pix = __float_as_uint(q0.x);
+      rng = __float_as_uint(q0.y);
+      o = f3{q0.z, q0.w, q1.x};
+      d = f3{q1.y, q1.z, q1.w};
+      acc = f3{q2.x, q2.y, q2.z};
+    }
+    for (uint32_t seg = a.seg_begin; seg < a.seg_end; seg++) {
+      if (alive) {
+        HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
+        closest_hit<BVH>(a.scene, o, d, h, stack, tid, kPtThreads);  // :208-222
+        const int x = static_cast<int>(pix & 0xFFFFu), y = static_cast<int>(pix >> 16);
+        if (y >= a.count_y0 && y < a.count_y1) rays++;
+        if (shade_segment(a, h, seg, light_c, o, d, acc, rng)) {
+          alive = false;
+          const size_t gi = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
+          a.image[gi] = make_float4(acc.x, acc.y, acc.z, a.depth[gi]);  // :328,:343 (+ depth in alpha)
+        }
+      }
+      if (seg + 1 >= a.seg_end) break;
+      // compact the survivors to the front of the block (as in k_pathtrace)
+      const unsigned long long live = __ballot(alive);
+      if (lane == 0) wave_cnt[wave] = static_cast<uint32_t>(__builtin_popcountll(live));
+      __syncthreads();
+      uint32_t cbase = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < kPtRows; w++) {
+        const uint32_t c = wave_cnt[w];
+        if (w < wave) cbase += c;
+        total += c;
+      }
+      if (total == 0) break;  // block-uniform
+      if (alive) {
+        const uint32_t slot = cbase + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
+        st.pix[slot] = pix;
+        st.rng[slot] = rng;
+        st.ox[slot] = o.x; st.oy[slot] = o.y; st.oz[slot] = o.z;
+        st.dx[slot] = d.x; st.dy[slot] = d.y; st.dz[slot] = d.z;
+        st.ar[slot] = acc.x; st.ag[slot] = acc.y; st.ab[slot] = acc.z;
+      }
+      __syncthreads();
+      alive = static_cast<uint32_t>(tid) < total;
+      if (alive) {
+        pix = st.pix[tid];
+        rng = st.rng[tid];
+        o = f3{st.ox[tid], st.oy[tid], st.oz[tid]};
+        d = f3{st.dx[tid], st.dy[tid], st.dz[tid]};
+        acc = f3{st.ar[tid], st.ag[tid], st.ab[tid]};
+      }
+      __syncthreads();
+    }
+    if (a.seg_end < a.max_segments) enqueue_paths(a, alive, lane, pix, rng, o, d, acc);
+    __syncthreads();  // wave_cnt / st are reused by the next chunk
+  }
+  for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+  if ((tid & 63) == 0 && rays) atomicAdd(&block_rays, rays);
+  __syncthreads();
+  if (tid == 0 && block_rays) atomicAdd(a.raycount, static_cast<unsigned long long>(block_rays));
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ void k_selftest_math(int op, const float* in, float* out, size_t n) {
   size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -711,7 +828,18 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
   size_t dyn = stack_bytes > sizeof(PathState) ? stack_bytes : sizeof(PathState);  // shared by both tenants
   PathtraceArgs b = a;
   b.multi_off = static_cast<uint32_t>(dyn / 4);
+  const size_t dyn_queue = dyn;
   if (a.spp > 1) dyn += 4 * kPtThreads * 4;  // sum_r, sum_g, sum_b, rng_pix
+  const uint32_t phase0 = pt_first_window(a.scene.use_bvh != 0);
+  const bool split = a.spp == 1 && a.compact && a.queue[0] && a.queue_count && a.max_segments > phase0 &&
+                     (a.max_segments <= 2 * phase0 || a.queue[1]);
+  b.seg_begin = 0;
+  b.seg_end = split ? phase0 : a.max_segments;
+  b.q_in = nullptr;
+  b.q_in_count = nullptr;
+  b.q_out = split ? a.queue[0] : nullptr;
+  b.q_out_count = split ? a.queue_count : nullptr;
+  if (split) (void)hipMemsetAsync(a.queue_count, 0, 2 * sizeof(uint32_t), s);
   if (a.compact) {
     if (a.scene.use_bvh)
       hipLaunchKernelGGL((k_pathtrace<true, true>), grid, block, dyn, s, b);
@@ -722,6 +850,33 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
       hipLaunchKernelGGL((k_pathtrace<true, false>), grid, block, dyn, s, b);
     else
       hipLaunchKernelGGL((k_pathtrace<false, false>), grid, block, dyn, s, b);
+  }
+  if (!split) return;
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  const dim3 qgrid(static_cast<uint32_t>(n_cu) * 8u);
+  int cur = 0;
+  for (uint32_t begin = phase0, len = phase0; begin < a.max_segments; begin += len, len *= 2, cur ^= 1) {
+    const uint32_t end = begin + len < a.max_segments ? begin + len : a.max_segments;
+    PathtraceArgs c = b;
+    c.seg_begin = begin;
+    c.seg_end = end;
+    c.q_in = a.queue[cur];
+    c.q_in_count = a.queue_count + cur;
+    const bool more = end < a.max_segments;
+    c.q_out = more ? a.queue[cur ^ 1] : nullptr;
+    c.q_out_count = more ? a.queue_count + (cur ^ 1) : nullptr;
+    if (more) (void)hipMemsetAsync(a.queue_count + (cur ^ 1), 0, sizeof(uint32_t), s);
+    if (a.scene.use_bvh)
+      hipLaunchKernelGGL((k_pathtrace_queue<true>), qgrid, block, dyn_queue, s, c);
+    else
+      hipLaunchKernelGGL((k_pathtrace_queue<false>), qgrid, block, dyn_queue, s, c);
+    if (end >= a.max_segments) break;
   }
 }
 void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s) {

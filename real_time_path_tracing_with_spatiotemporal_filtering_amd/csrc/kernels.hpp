@@ -95,6 +95,17 @@ struct PathtraceArgs {
   int32_t compact;             // 1: compact surviving paths to the front of the block after every segment
   int32_t cull;                // 1: bounds[] is valid for the primary segment
   uint32_t multi_off;          // dword offset of the spp > 1 accumulators in dynamic LDS (set by launch_pathtrace)
+  // long paths (spp == 1, max_segments > 4): a launch covers the segment window [seg_begin, seg_end) and hands the
+  // unfinished paths to the next one through a queue of 48-byte records (set by launch_pathtrace)
+  uint32_t seg_begin, seg_end;
+  void* q_out;                 // records written by this launch
+  uint32_t* q_out_count;
+  const void* q_in;            // records read by k_pathtrace_queue
+  const uint32_t* q_in_count;
+  // queue storage owned by the context: two buffers of `queue_capacity` records and two counters, or NULL
+  void* queue[2];
+  uint32_t* queue_count;       // [2]
+  uint32_t queue_capacity;
   TriBounds bounds[kCullMaxTris];
 };
 
@@ -152,6 +163,16 @@ struct MomentsArgs {
   float* var_out;
 };
 void launch_moments(const MomentsArgs& a, hipStream_t s);
+
+// Long paths: segments handled by the tile kernel before the survivors are queued; every later window is twice as
+// long.  Swept at 4K on the Cornell box (k_pathtrace, 8 / 16 / 32 segments; single launch 969 / 1627 / 2843 us):
+// 4: 983 / 1406 / 1647, 6: 872 / 1236 / 1483, 8: 933 / 1291 / 1543.  BVH scenes use twice the window: the queue
+// order is the order of arrival, not of the image, and the lost ray coherence costs the traversal more than the
+// denser waves win (1.15M triangles, 8 segments: 3.65 -> 3.80 ms with a window of 4).
+#ifndef RTPT_PT_PHASE0
+#define RTPT_PT_PHASE0 6
+#endif
+inline uint32_t pt_first_window(bool use_bvh) { return use_bvh ? 2u * RTPT_PT_PHASE0 : RTPT_PT_PHASE0; }
 
 constexpr uint32_t kExtAdaptiveAlpha = 0x10u, kExtGauss5 = 0x20u, kExtPow2Stride = 0x40u, kExtDisocclusion = 0x80u;
 constexpr uint32_t kExtVariance = 0x100u;

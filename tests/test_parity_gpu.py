@@ -362,6 +362,31 @@ def test_8k_frame_properties(hip_lib):
     assert np.array_equal(bits(outs[0][0]), bits(outs[1][0]))
 
 
+@pytest.mark.parametrize("seg", [7, 13, 32])
+@pytest.mark.parametrize("bvh", [0, 2])
+def test_queued_long_paths_equal_single_launch(hip_lib, seg, bvh):
+    """paths that outlive the first segment window continue in follow-up launches fed by a queue; the traced image,
+    the ray count and the filtered frames must not notice (RTPT_FLAG_SINGLE_LAUNCH_PATHS is the A/B switch)"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    outs = []
+    for single in (hip_lib.FLAG_SINGLE_LAUNCH_PATHS, 0):
+        app = make_app(333, 190, max_segments=seg, iterations=3, flags=single | bvh | hip_lib.FLAG_EXACT_FILTER)
+        ctx = app.backend.ctx
+        for f in range(3):
+            app.updateScene(("J",) if f == 1 else ())
+            app.drawVisbilityBuffer()
+            app.computeTemporalGradient()
+            app.drawSceneToImage()
+            traced = ctx.readback(hip_lib.PLANE_IMAGE)
+            app.applyTemporalFiltering()
+            app.copyImageToSwapChainsCurrentImage()
+            app.frameCount += 1
+        outs.append((traced, ctx.readback(hip_lib.PLANE_PREVIOUS), ctx.raycount()))
+        app.backend.close()
+    assert outs[0][2] == outs[1][2]
+    assert np.array_equal(bits(outs[0][0]), bits(outs[1][0])) and np.array_equal(bits(outs[0][1]), bits(outs[1][1]))
+
+
 def test_spp_4(hip_lib, oracle, cornell):
     from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
     xyz, idx, tris = cornell
