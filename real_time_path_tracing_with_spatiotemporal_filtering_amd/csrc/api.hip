@@ -764,17 +764,20 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   a.compact = (c->cfg.flags & RTPT_FLAG_NO_PATH_COMPACTION) ? 0 : 1;
   a.queue[0] = a.queue[1] = nullptr;
   a.queue_count = nullptr;
-  a.queue_capacity = 0;
+  a.queue_region = 0;
   if (a.compact && a.spp == 1 && a.max_segments > rt::pt_first_window(c->use_bvh) && !(c->cfg.flags & RTPT_FLAG_SINGLE_LAUNCH_PATHS)) {
-    // one 48-byte record per pixel at most; the second buffer only when a third segment window exists
-    const size_t cap = c->pixels();
-    if (!c->path_queue_count.ptr && (rc = alloc_buf(c->path_queue_count, 2 * sizeof(uint32_t)))) return rc;
+    // a region holds the survivors of ceil(workgroups / kPathQueues) workgroups of 256 paths (kernels.hip); the
+    // second buffer is only needed when a third segment window exists
+    const size_t blocks = ((static_cast<size_t>(c->cfg.width) + 63) / 64) * ((c->rows() + 3) / 4);
+    const size_t region = ((blocks + rt::kPathQueues - 1) / rt::kPathQueues) * 256;
+    const size_t cap = region * rt::kPathQueues;
+    if (!c->path_queue_count.ptr && (rc = alloc_buf(c->path_queue_count, 2 * rt::kPathQueues * sizeof(uint32_t)))) return rc;
     if (!c->path_queue[0].ptr && (rc = alloc_buf(c->path_queue[0], cap * 48))) return rc;
     if (a.max_segments > 2u * rt::pt_first_window(c->use_bvh) && !c->path_queue[1].ptr && (rc = alloc_buf(c->path_queue[1], cap * 48))) return rc;
     a.queue[0] = c->path_queue[0].ptr;
     a.queue[1] = c->path_queue[1].ptr;
     a.queue_count = static_cast<uint32_t*>(c->path_queue_count.ptr);
-    a.queue_capacity = static_cast<uint32_t>(cap);
+    a.queue_region = static_cast<uint32_t>(region);
   }
   a.cull = 0;
   if (!c->use_bvh && c->width_fits_i16()) {

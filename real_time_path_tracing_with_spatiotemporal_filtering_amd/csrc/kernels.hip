@@ -450,6 +450,15 @@ __device__ __forceinline__ f3 sky_color(f3 d) {  // raytrace.comp.glsl:95-107
   return f3{0.03f, 0.03f, 0.03f};
 }
 
+// K2 tile: 64 x kPtRows pixels per workgroup.  More paths compacted together shrink the share of the half-empty
+// last wave of every later segment, but every compaction is a workgroup barrier on the slowest wave.  Swept at
+// 4K (Cornell 4 segments / 1.15M triangles 8 segments, k_pathtrace): 2 rows 862 us / 4.18 ms, 3 rows 569 / 4.04,
+// 4 rows 517 / 3.99, 8 rows 540 / 4.23, 16 rows 728 / 5.80.
+#ifndef RTPT_PT_ROWS
+#define RTPT_PT_ROWS 4
+#endif
+constexpr int kPtRows = RTPT_PT_ROWS;
+constexpr int kPtThreads = kBlockX * kPtRows;
 // One path segment after its closest-hit query (raytrace.comp.glsl:226-267): the unoccluded light test, the sky, or a
 // diffuse bounce.  Returns true when the path ended (its colour is then `acc`).
 __device__ __forceinline__ bool shade_segment(const PathtraceArgs& a, const HitRec& h, uint32_t seg, f3 light_c, f3& o, f3& d,
@@ -480,23 +489,35 @@ __device__ __forceinline__ bool shade_segment(const PathtraceArgs& a, const HitR
   return seg + 1 >= a.max_segments;  // budget exhausted: the path returns its throughput (:270)
 }
 
-// Hand-over of the paths a launch did not finish (PathtraceArgs::seg_end < max_segments) to the next launch: one
-// atomic per wave reserves the slots, each surviving lane writes its 48-byte record.
-__device__ __forceinline__ void enqueue_paths(const PathtraceArgs& a, bool alive, uint32_t lane, uint32_t pixg, uint32_t rng, f3 o,
-                                              f3 d, f3 acc) {
+// Hand-over of the paths a launch did not finish (PathtraceArgs::seg_end < max_segments) to the next launch: a
+// workgroup appends ALL of its survivors with one atomic (the per-wave counts are summed through LDS).  One atomic
+// per wave on the same counter serialised badly (tile kernel 516 -> 814 us with a window of 2).  The queue can be
+// split into kPathQueues regions with a counter each (a region then holds the survivors of at most
+// ceil(blocks / kPathQueues) workgroups: PathtraceArgs::queue_region records); once the atomics are per workgroup
+// one region is the fastest, so that is what ships.
+__device__ __forceinline__ void enqueue_paths(const PathtraceArgs& a, uint32_t region, uint32_t* wave_cnt, uint32_t* bcast,
+                                              bool alive, int wave, uint32_t lane, uint32_t pixg, uint32_t rng, f3 o, f3 d, f3 acc) {
   const unsigned long long m = __ballot(alive);
-  if (!m) return;
-  uint32_t base = 0;
-  const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(m));
-  if (lane == leader) base = atomicAdd(a.q_out_count, static_cast<uint32_t>(__builtin_popcountll(m)));
-  base = __builtin_amdgcn_readlane(base, leader);
+  if (lane == 0) wave_cnt[wave] = static_cast<uint32_t>(__builtin_popcountll(m));
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kPtRows; w++) {
+    const uint32_t c = wave_cnt[w];
+    if (w < wave) before += c;
+    total += c;
+  }
+  if (wave == 0 && lane == 0) *bcast = total ? atomicAdd(a.q_out_count + region, total) : 0u;
+  __syncthreads();
   if (alive) {
-    const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+    const uint32_t slot = region * a.queue_region + *bcast + before +
+                          __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
     float4* q = reinterpret_cast<float4*>(a.q_out) + 3 * static_cast<size_t>(slot);
     q[0] = make_float4(__uint_as_float(pixg), __uint_as_float(rng), o.x, o.y);
     q[1] = make_float4(o.z, d.x, d.y, d.z);
     q[2] = make_float4(acc.x, acc.y, acc.z, 0.0f);
   }
+  __syncthreads();  // wave_cnt / bcast may be reused right away
 }
 
 // K2 tile kernel with optional per-segment compaction (PathtraceArgs::compact).
@@ -516,15 +537,6 @@ __device__ __forceinline__ void enqueue_paths(const PathtraceArgs& a, bool alive
 // regeneration scheme — finished lanes pick up new pixels — was also built and measured: it mixes
 // primary and secondary rays in every wave, loses the coherent, culled primary segment and ran
 // 1.5x slower at 4 segments; it is not kept.)
-// K2 tile: 64 x kPtRows pixels per workgroup.  More paths compacted together shrink the share of the half-empty
-// last wave of every later segment, but every compaction is a workgroup barrier on the slowest wave.  Swept at
-// 4K (Cornell 4 segments / 1.15M triangles 8 segments, k_pathtrace): 2 rows 862 us / 4.18 ms, 3 rows 569 / 4.04,
-// 4 rows 517 / 3.99, 8 rows 540 / 4.23, 16 rows 728 / 5.80.
-#ifndef RTPT_PT_ROWS
-#define RTPT_PT_ROWS 4
-#endif
-constexpr int kPtRows = RTPT_PT_ROWS;
-constexpr int kPtThreads = kBlockX * kPtRows;
 struct PathState {  // SoA in LDS, one slot per thread
   uint32_t pix[kPtThreads];   // local pixel index (ty*64 + tx)
   uint32_t rng[kPtThreads];
@@ -548,6 +560,7 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
   float* const sum_b = sum_g + kPtThreads;
   uint32_t* const rng_pix = reinterpret_cast<uint32_t*>(sum_b + kPtThreads);
   __shared__ uint32_t wave_cnt[kPtRows];
+  __shared__ uint32_t q_base;
   __shared__ unsigned int block_rays;
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
@@ -656,7 +669,8 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
     if (a.seg_end < a.max_segments) {  // only with spp == 1: the unfinished paths continue in k_pathtrace_queue
       const uint32_t pixg = (static_cast<uint32_t>(tile_y0 + static_cast<int>(pix >> 6)) << 16) |
                             static_cast<uint32_t>(tile_x0 + static_cast<int>(pix & 63u));
-      enqueue_paths(a, alive, lane, pixg, rng, o, d, acc);
+      const uint32_t blk = blockIdx.y * gridDim.x + blockIdx.x;
+      enqueue_paths(a, blk % kPathQueues, wave_cnt, &q_base, alive, wave, lane, pixg, rng, o, d, acc);
     }
   }
   __syncthreads();
@@ -689,20 +703,24 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace_queue(PathtraceArgs a)
   extern __shared__ __attribute__((aligned(16))) uint32_t stack[];
   PathState& st = *reinterpret_cast<PathState*>(stack);
   __shared__ uint32_t wave_cnt[kPtRows];
+  __shared__ uint32_t q_base;
   __shared__ unsigned int block_rays;
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   const uint32_t lane = threadIdx.x;
   if (tid == 0) block_rays = 0;
   const f3 light_c = ld3(a.light_c);
-  const uint32_t n_in = *a.q_in_count;
+  // workgroup b serves region b mod kPathQueues, every (gridDim.x / kPathQueues)-th chunk of 256 records
+  const uint32_t region = blockIdx.x % kPathQueues;
+  const uint32_t n_in = a.q_in_count[region];
+  const size_t region_base = static_cast<size_t>(region) * a.queue_region;
   unsigned int rays = 0;
-  for (uint32_t base = blockIdx.x * kPtThreads; base < n_in; base += gridDim.x * kPtThreads) {  // block-uniform
+  for (uint32_t base = (blockIdx.x / kPathQueues) * kPtThreads; base < n_in; base += (gridDim.x / kPathQueues) * kPtThreads) {  // block-uniform
     uint32_t pix = 0, rng = 0;
     f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, -1.f}, acc{1.f, 1.f, 1.f};
     bool alive = base + static_cast<uint32_t>(tid) < n_in;
     if (alive) {
-      const float4* q = reinterpret_cast<const float4*>(a.q_in) + 3 * static_cast<size_t>(base + tid);
+      const float4* q = reinterpret_cast<const float4*>(a.q_in) + 3 * (region_base + base + tid);
       const float4 q0 = q[0], q1 = q[1], q2 = q[2];
       pix = __float_as_uint(q0.x);
       rng = __float_as_uint(q0.y);
@@ -755,7 +773,7 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace_queue(PathtraceArgs a)
       }
       __syncthreads();
     }
-    if (a.seg_end < a.max_segments) enqueue_paths(a, alive, lane, pix, rng, o, d, acc);
+    if (a.seg_end < a.max_segments) enqueue_paths(a, region, wave_cnt, &q_base, alive, wave, lane, pix, rng, o, d, acc);
     __syncthreads();  // wave_cnt / st are reused by the next chunk
   }
   for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
@@ -839,7 +857,7 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
   b.q_in_count = nullptr;
   b.q_out = split ? a.queue[0] : nullptr;
   b.q_out_count = split ? a.queue_count : nullptr;
-  if (split) (void)hipMemsetAsync(a.queue_count, 0, 2 * sizeof(uint32_t), s);
+  if (split) (void)hipMemsetAsync(a.queue_count, 0, 2 * kPathQueues * sizeof(uint32_t), s);
   if (a.compact) {
     if (a.scene.use_bvh)
       hipLaunchKernelGGL((k_pathtrace<true, true>), grid, block, dyn, s, b);
@@ -867,11 +885,11 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
     c.seg_begin = begin;
     c.seg_end = end;
     c.q_in = a.queue[cur];
-    c.q_in_count = a.queue_count + cur;
+    c.q_in_count = a.queue_count + cur * kPathQueues;
     const bool more = end < a.max_segments;
     c.q_out = more ? a.queue[cur ^ 1] : nullptr;
-    c.q_out_count = more ? a.queue_count + (cur ^ 1) : nullptr;
-    if (more) (void)hipMemsetAsync(a.queue_count + (cur ^ 1), 0, sizeof(uint32_t), s);
+    c.q_out_count = more ? a.queue_count + (cur ^ 1) * kPathQueues : nullptr;
+    if (more) (void)hipMemsetAsync(a.queue_count + (cur ^ 1) * kPathQueues, 0, kPathQueues * sizeof(uint32_t), s);
     if (a.scene.use_bvh)
       hipLaunchKernelGGL((k_pathtrace_queue<true>), qgrid, block, dyn_queue, s, c);
     else

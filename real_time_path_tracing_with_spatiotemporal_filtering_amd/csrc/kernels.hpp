@@ -104,8 +104,8 @@ struct PathtraceArgs {
   const uint32_t* q_in_count;
   // queue storage owned by the context: two buffers of `queue_capacity` records and two counters, or NULL
   void* queue[2];
-  uint32_t* queue_count;       // [2]
-  uint32_t queue_capacity;
+  uint32_t* queue_count;       // [2][kPathQueues]
+  uint32_t queue_region;       // records per region (a queue buffer holds kPathQueues regions)
   TriBounds bounds[kCullMaxTris];
 };
 
@@ -166,12 +166,16 @@ void launch_moments(const MomentsArgs& a, hipStream_t s);
 
 // Long paths: segments handled by the tile kernel before the survivors are queued; every later window is twice as
 // long.  Swept at 4K on the Cornell box (k_pathtrace, 8 / 16 / 32 segments; single launch 969 / 1627 / 2843 us):
-// 4: 983 / 1406 / 1647, 6: 872 / 1236 / 1483, 8: 933 / 1291 / 1543.  BVH scenes use twice the window: the queue
-// order is the order of arrival, not of the image, and the lost ray coherence costs the traversal more than the
-// denser waves win (1.15M triangles, 8 segments: 3.65 -> 3.80 ms with a window of 4).
+// 2: 1028 / 1376 / 1622, 3: 893 / 1246 / 1489, 4: 836 / 1186 / 1421, 6: 891 / 1238 / 1494.  BVH scenes use twice the
+// window: the queue order is the order of arrival, not of the image, and the lost ray coherence costs the traversal
+// more than the denser waves win (1.15M triangles, 8 segments: 3.65 -> 3.80 ms with a window of 4).
 #ifndef RTPT_PT_PHASE0
-#define RTPT_PT_PHASE0 6
+#define RTPT_PT_PHASE0 4
 #endif
+#ifndef RTPT_PATH_QUEUES
+#define RTPT_PATH_QUEUES 1  // 1 / 8 / 16 / 64 regions: reference frame 352 / 403 / 421 / 418 us, 4K 32 segments 1421 / 1434 / 1441 / 1429
+#endif
+constexpr uint32_t kPathQueues = RTPT_PATH_QUEUES;  // regions (and counters) per queue buffer
 inline uint32_t pt_first_window(bool use_bvh) { return use_bvh ? 2u * RTPT_PT_PHASE0 : RTPT_PT_PHASE0; }
 
 constexpr uint32_t kExtAdaptiveAlpha = 0x10u, kExtGauss5 = 0x20u, kExtPow2Stride = 0x40u, kExtDisocclusion = 0x80u;
