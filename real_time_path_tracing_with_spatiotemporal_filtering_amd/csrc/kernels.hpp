@@ -176,7 +176,10 @@ void launch_moments(const MomentsArgs& a, hipStream_t s);
 #define RTPT_PATH_QUEUES 1  // 1 / 8 / 16 / 64 regions: reference frame 352 / 403 / 421 / 418 us, 4K 32 segments 1421 / 1434 / 1441 / 1429
 #endif
 constexpr uint32_t kPathQueues = RTPT_PATH_QUEUES;  // regions (and counters) per queue buffer
-inline uint32_t pt_first_window(bool use_bvh) { return use_bvh ? 2u * RTPT_PT_PHASE0 : RTPT_PT_PHASE0; }
+#ifndef RTPT_PT_BVH_MULT
+#define RTPT_PT_BVH_MULT 2
+#endif
+inline uint32_t pt_first_window(bool use_bvh) { return use_bvh ? RTPT_PT_BVH_MULT * RTPT_PT_PHASE0 : RTPT_PT_PHASE0; }
 
 constexpr uint32_t kExtAdaptiveAlpha = 0x10u, kExtGauss5 = 0x20u, kExtPow2Stride = 0x40u, kExtDisocclusion = 0x80u;
 constexpr uint32_t kExtVariance = 0x100u;
