@@ -412,23 +412,19 @@ def test_spp_4(hip_lib, oracle, cornell):
 
 
 # ------------------------------------------------------------------------------ strips on one GPU
-@pytest.mark.parametrize("mode", ["redundant", "exchange"])
-def test_strips_equal_single_frame(hip_lib, oracle, cornell, mode):
-    """two/three virtual ranks as separate contexts on one GPU == the single-context frame, bit for bit.
-    The test plays the network: in exchange mode it copies the k halo rows between contexts instead of
-    RCCL, and in frames where the camera moved it assembles the previous frame from every rank's strip
-    and registers it with rtpt_set_external_history (the all-gather of app._prepare_history)."""
+def _strips_vs_single(w, h, seg, n, R, mode, flags, keys):
+    """R virtual ranks as separate contexts on one GPU against the single-context frame, bit for bit.  The helper plays
+    the network: in exchange mode it copies the halo rows between contexts instead of RCCL, and in frames where the
+    camera moved it assembles the previous frame from every rank's strip and registers it with
+    rtpt_set_external_history (the all-gather of app._prepare_history)."""
     import torch
     from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
-    w, h, n = 96, 72, 5
-    keys = [(), (), ("E",), ("Q", "A")]   # vertical camera moves: the reprojected pixel leaves the strip
-    single = make_app(w, h, max_segments=3, iterations=n)
-    for R in (2, 3):
-        ranks = [make_app(w, h, max_segments=3, iterations=n, rank=r, world=R, mode=mode, torch_planes=False)
-                 for r in range(R)]
-        ref_app = make_app(w, h, max_segments=3, iterations=n)
-        hist_dev = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(R)]
+    ranks = [make_app(w, h, max_segments=seg, iterations=n, rank=r, world=R, mode=mode, torch_planes=False, flags=flags)
+             for r in range(R)]
+    ref_app = make_app(w, h, max_segments=seg, iterations=n, flags=flags)
+    hist_dev = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(R)]
+    try:
         for frame, key in enumerate(keys):
             ref_app.updateScene(key)
             ref_app.drawVisbilityBuffer()
@@ -456,7 +452,7 @@ def test_strips_equal_single_frame(hip_lib, oracle, cornell, mode):
                             base = a.backend.ctx.cfg.row_begin
                             buf[recv_rows[0] - base:recv_rows[1] - base] = pb[recv_rows[0] - pbase:recv_rows[1] - pbase]
                         a.backend.ctx.set_plane(plane, buf)
-                if k == n:
+                if k == n and (k & 1):
                     moved = not ranks[0]._camera_static()
                     if frame > 0 and moved:
                         prev = np.zeros((h, w, 4), np.float32)
@@ -477,11 +473,44 @@ def test_strips_equal_single_frame(hip_lib, oracle, cornell, mode):
                 got[o0:o1] = a.backend.readback_rows(abi.PLANE_IMAGE, o0, o1)
                 a.copyImageToSwapChainsCurrentImage()
                 a.frameCount += 1
-            assert np.array_equal(bits(got), bits(want)), (mode, R, frame)
+            assert np.array_equal(bits(got), bits(want)), (w, h, seg, n, R, mode, hex(flags), frame)
+    finally:
         for a in ranks:
             a.backend.close()
         ref_app.backend.close()
-    single.backend.close()
+
+
+@pytest.mark.parametrize("mode", ["redundant", "exchange"])
+def test_strips_equal_single_frame(hip_lib, oracle, cornell, mode):
+    keys = [(), (), ("E",), ("Q", "A")]   # vertical camera moves: the reprojected pixel leaves the strip
+    for R in (2, 3):
+        _strips_vs_single(96, 72, 3, 5, R, mode, 0, keys)
+
+
+def test_strips_seeded_sweep(hip_lib):
+    """sizes, rank counts, iteration counts (even ones too), both halo modes, kernel-variant flags and the extension
+    modes that widen the halo (5x5 taps, 2^(k-1) stride)"""
+    rng = np.random.default_rng(3)
+    done = 0
+    while done < 10:
+        R = int(rng.choice([2, 3, 4, 5]))
+        h = int(rng.choice([64, 97, 120, 161]))
+        w = int(rng.choice([33, 64, 130]))
+        n = int(rng.choice([1, 2, 3, 5]))
+        mode = str(rng.choice(["redundant", "exchange"]))
+        flags = int(rng.choice([0, 0x1, 0x2, 0x4, 0x20, 0x40, 0x60, 0x30]))
+        seg = int(rng.choice([2, 4, 7]))
+        keys = [tuple(rng.choice(list("WASDQEJL"), size=rng.integers(0, 3))) for _ in range(3)]
+        from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripPlan
+        try:
+            if mode == "exchange":
+                for r in range(R):
+                    for k in range(1, n + 1):
+                        StripPlan(h, R, r, n, mode, flags & 0x1F0).exchange_rows(k)
+        except ValueError:
+            continue   # strips shorter than the halo: rejected by the plan, not a case
+        _strips_vs_single(w, h, seg, n, R, mode, flags, keys)
+        done += 1
 
 
 @pytest.mark.parametrize("exact", [0, 1])
