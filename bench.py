@@ -196,8 +196,17 @@ def cpu_baseline(wl, budget_s=12.0):
         app.pc.frameNumber += 1
         d2, r2 = band_frame(rows)
         dt, rays, reps = dt + d2, rays + r2, reps + 1
+    # also the scalar figure — one thread, a short band (about 3 s)
+    O.set_threads(1)
+    rows1 = 16
+    d1, r1 = band_frame(rows1)
+    while d1 < 1.5 and rows1 < H:
+        rows1 = min(H, rows1 * 2)
+        d1, r1 = band_frame(rows1)
+    O.set_threads(cores)
     return {
         "value": round(rays / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
+        "one_thread": {"value": round(r1 / d1 / 1e6, 3), "unit": "Mray/s", "sample": f"{rows1} centre rows, {d1:.1f} s"},
         "sample": f"{reps} x {rows} centre rows of the {W}x{H} frame (+{N * (N + 1) // 2} halo rows per side when banded), "
                   f"all passes, {dt:.1f} s of oracle/rtpt_oracle.c with {cores} OpenMP threads",
         "ms_per_frame_extrapolated": round(dt / reps / rows * H * 1e3, 1),
