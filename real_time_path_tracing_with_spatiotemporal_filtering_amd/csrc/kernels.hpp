@@ -168,7 +168,9 @@ void launch_moments(const MomentsArgs& a, hipStream_t s);
 // long.  Swept at 4K on the Cornell box (k_pathtrace, 8 / 16 / 32 segments; single launch 969 / 1627 / 2843 us):
 // 2: 1028 / 1376 / 1622, 3: 893 / 1246 / 1489, 4: 836 / 1186 / 1421, 6: 891 / 1238 / 1494.  BVH scenes use twice the
 // window: the queue order is the order of arrival, not of the image, and the lost ray coherence costs the traversal
-// more than the denser waves win (1.15M triangles, 8 segments: 3.65 -> 3.80 ms with a window of 4).
+// more than the denser waves win (1.15M triangles, 8 segments: 3.65 -> 3.80 ms with a window of 4).  Windows shorter
+// than the BASELINE configs' 4 segments lose everywhere, also on the 270-row strip of an 8-rank job (k_pathtrace
+// 89 us in one launch, 108 / 115 us with windows of 3 / 2): the hand-over costs more than the drain tail it removes.
 #ifndef RTPT_PT_PHASE0
 #define RTPT_PT_PHASE0 4
 #endif
