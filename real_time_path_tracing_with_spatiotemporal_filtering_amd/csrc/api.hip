@@ -51,6 +51,7 @@ struct TimedLaunch {
 struct rtpt_ctx {
   rtpt_config cfg;
   int device = 0;
+  int n_cu = 256;  // compute units of `device` (persistent-grid sizes); per context, not per process
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
 
@@ -400,6 +401,17 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
     return fail(RTPT_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   }
   c->stream = c->own_stream;
+  {
+    // per-DEVICE launch state (contexts on different GPUs of one process are independent, rtpt.h): CU count for the
+    // persistent grids and the >64 KiB dynamic-LDS attribute of the staged filter kernels
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    e = rt::prepare_device_atrous();
+    if (e != hipSuccess) {
+      rtpt_destroy(c);
+      return fail(RTPT_E_DEVICE, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    }
+  }
   c->count_y0 = static_cast<int>(cfg->row_begin);
   c->count_y1 = static_cast<int>(cfg->row_end);
   int rc = alloc_planes(c);
@@ -762,6 +774,7 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   a.count_y0 = c->count_y0;
   a.count_y1 = c->count_y1;
   a.compact = (c->cfg.flags & RTPT_FLAG_NO_PATH_COMPACTION) ? 0 : 1;
+  a.n_cu = c->n_cu;
   a.queue[0] = a.queue[1] = nullptr;
   a.queue_count = nullptr;
   a.queue_region = 0;
@@ -838,6 +851,10 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
   a.n_tris = c->n_tris;
   a.pair_tab = static_cast<const float*>(c->pair_tab.ptr);
   a.rows_stored = static_cast<int32_t>(c->rows());
+  a.n_cu = c->n_cu;
+  // the last iteration of an even N writes `image` and nothing filters it again: alpha 0 like the reference's
+  // vec4(rgb, 0) (temporalFiltering.comp.glsl:152), so a device-side consumer of IMAGE never sees the depth
+  a.alpha_zero = (k == max_it && !final_pass) ? 1 : 0;
   a.sigma_n = c->cfg.sigma_n;
   a.sigma_z = c->cfg.sigma_z;
   a.sigma_l = c->cfg.sigma_l;
@@ -856,7 +873,7 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
                            static_cast<const float*>(c->depth.ptr), c->stream);
     c->alpha_depth[c->color_of_role[in_role]] = true;
   }
-  c->alpha_depth[c->color_of_role[out_role]] = !final_pass;
+  c->alpha_depth[c->color_of_role[out_role]] = !final_pass && !a.alpha_zero;
   if (final_pass) {
     a.frame = pc->frameNumber;
     a.alpha = c->cfg.alpha;

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kThreads) void k_atrous(AtrousArgs a) {
     filtered = num * rd;
   }
   if (!FINAL) {
-    a.out[rowp + x] = make_float4(filtered.x, filtered.y, filtered.z, dp);  // :152 (+ depth in alpha)
+    a.out[rowp + x] = make_float4(filtered.x, filtered.y, filtered.z, a.alpha_zero ? 0.0f : dp);  // :152 (+ depth in alpha)
     return;
   }
   // :213-239 reprojection — exact arithmetic: the truncated pixel coordinate is an integer observable
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void k_atrous_ext(AtrousArgs a) {
   const f3 filtered = f3{num.x / den, num.y / den, num.z / den};  // :150
   if (use_var && a.var_out) a.var_out[rowp + x] = vsum / (den * den);
   if (!FINAL) {
-    a.out[rowp + x] = make_float4(filtered.x, filtered.y, filtered.z, dp);
+    a.out[rowp + x] = make_float4(filtered.x, filtered.y, filtered.z, a.alpha_zero ? 0.0f : dp);
     return;
   }
   int ppx, ppy;
@@ -328,12 +328,18 @@ __global__ __launch_bounds__(kThreads) void k_atrous_ext(AtrousArgs a) {
 // the wave-uniform LDS byte address; lane i lands at M0 + i*size.  One wait state is required between
 // the SALU write of M0 and the LDS-DMA that reads it.
 // `base` is a wave-uniform pointer (SGPR pair), `voff` the per-lane byte offset: no 64-bit VALU math.
+// M0 is on the clobber list: the compiler must not assume a value it placed there (s_movrel indexing, sendmsg,
+// its own LDS-DMA builtin) survives the statement.  clang warns that M0 is a reserved register; naming it is
+// exactly the point, so that warning is silenced for these two functions only.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void dma_b128(const void* base, uint32_t voff, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
 }
 __device__ __forceinline__ void dma_b32(const void* base, uint32_t voff, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 
 // "Comb" kernel.
@@ -586,11 +592,11 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
 #if RTPT_COMB_NT_STORE
       {
         typedef float v4f_ __attribute__((ext_vector_type(4)));
-        v4f_ o4 = {filtered.x, filtered.y, filtered.z, dp};
+        v4f_ o4 = {filtered.x, filtered.y, filtered.z, a.alpha_zero ? 0.0f : dp};
         __builtin_nontemporal_store(o4, reinterpret_cast<v4f_*>(a.out + ip));  // :152; not re-read by this pass
       }
 #else
-      a.out[ip] = make_float4(filtered.x, filtered.y, filtered.z, dp);  // :152 (+ depth in alpha)
+      a.out[ip] = make_float4(filtered.x, filtered.y, filtered.z, a.alpha_zero ? 0.0f : dp);  // :152 (+ depth in alpha)
 #endif
       continue;
     }
@@ -652,6 +658,29 @@ void launch_stamp_depth(const FrameGeom& g, float4* color, const float* depth, h
   hipLaunchKernelGGL(k_stamp_depth, grid_for(g), dim3(kBlockX, kBlockY), 0, s, g, color, depth);
 }
 
+// Kernels that ask for more than 64 KiB of dynamic LDS need the attribute raised once per DEVICE (it is a
+// property of the function on the current device, not of the process): rtpt_create calls this after
+// hipSetDevice, so contexts on different GPUs of one process are independent.
+template <int CW, bool NRM>
+static hipError_t comb_attrs() {
+  constexpr int kMax = 160 * 1024;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, true, true, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, true, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, true, false, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, false, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  return e;
+}
+hipError_t prepare_device_atrous() {
+  constexpr int b = kBlockX * kShHalves;
+  hipError_t e = comb_attrs<b + 8, false>();
+  if (e == hipSuccess) e = comb_attrs<b + 16, false>();
+  if (e == hipSuccess) e = comb_attrs<b + 32, false>();
+  if (e == hipSuccess) e = comb_attrs<b + 8, true>();
+  if (e == hipSuccess) e = comb_attrs<b + 16, true>();
+  if (e == hipSuccess) e = comb_attrs<b + 32, true>();
+  return e;
+}
+
 void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
   if (a0.g.y1 <= a0.g.y0) return;
   AtrousArgs a = a0;
@@ -685,13 +714,7 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
     const int nrows = a.g.y1 - a.g.y0;
     const int chunks = (nrows + kCombM * a.k - 1) / (kCombM * a.k);
     a.tiles_y = (chunks + kShWaves - 1) / kShWaves;  // chunk groups (kShWaves consecutive chunks per block)
-    static int n_cu = 0;
-    if (!n_cu) {
-      hipDeviceProp_t prop;
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = a.n_cu > 0 ? a.n_cu : 256;  // of the context's device (rtpt_create)
     const uint32_t nlb = static_cast<uint32_t>(a.tiles_x) * static_cast<uint32_t>(a.tiles_y) * static_cast<uint32_t>(a.k);
     // staged row stride (cells): segment + 2k, rounded to the template instances
     const int need = seg_w + 2 * a.k;
@@ -708,14 +731,6 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
     dim3 grid(per_xcd * 8u), sblock(kBlockX, kShWaves);
 #define RTPT_LAUNCH_COMB(CW, NRM)                                                                          \
   do {                                                                                                \
-    static bool attr = false; /* one per instantiated stride */                                       \
-    if (!attr) {                                                                                      \
-      attr = true;                                                                                    \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, true, true, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, true, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, true, false, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, false, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    }                                                                                                 \
     if (a.exact) {                                                                                    \
       if (final_pass)                                                                                 \
         hipLaunchKernelGGL((k_atrous_comb_sh<CW, true, true, NRM>), grid, sblock, lds, s, a);              \

@@ -870,13 +870,7 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
       hipLaunchKernelGGL((k_pathtrace<false, false>), grid, block, dyn, s, b);
   }
   if (!split) return;
-  static int n_cu = 0;
-  if (!n_cu) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    n_cu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
+  const int n_cu = a.n_cu > 0 ? a.n_cu : 256;  // of the context's device (rtpt_create)
   const dim3 qgrid(static_cast<uint32_t>(n_cu) * 8u);
   int cur = 0;
   for (uint32_t begin = phase0, len = phase0; begin < a.max_segments; begin += len, len *= 2, cur ^= 1) {

@@ -94,6 +94,7 @@ struct PathtraceArgs {
   int32_t count_y0, count_y1;  // rows whose queries are counted
   int32_t compact;             // 1: compact surviving paths to the front of the block after every segment
   int32_t cull;                // 1: bounds[] is valid for the primary segment
+  int32_t n_cu;                // compute units of the context's device (persistent queue-kernel grid)
   uint32_t multi_off;          // dword offset of the spp > 1 accumulators in dynamic LDS (set by launch_pathtrace)
   // long paths (spp == 1, max_segments > 4): a launch covers the segment window [seg_begin, seg_end) and hands the
   // unfinished paths to the next one through a queue of 48-byte records (set by launch_pathtrace)
@@ -116,6 +117,8 @@ struct AtrousArgs {
   int32_t direct;        // 1: force the direct-load kernel (no LDS staging)
   int32_t rows_stored;   // rows held by the planes (row_base .. row_base+rows_stored-1)
   int32_t cwp;           // comb kernel: staged row length in cells (set by launch_atrous)
+  int32_t n_cu;          // compute units of the context's device (persistent grid size)
+  int32_t alpha_zero;    // 1: a k < N launch writes alpha 0 instead of the depth (last iteration of an even N)
   const float* pair_tab; // (n_tris+1)^2 id-pair normal weights, NULL when the scene is too large
   const float4* normals; // per-pixel (n.xyz, self weight) plane written by k_gbuffer for such scenes, NULL otherwise
   uint32_t n_tris;       // normal_tab has n_tris + 1 entries
@@ -202,6 +205,7 @@ void launch_gbuffer(const GbufferArgs& a, hipStream_t s);
 void launch_gradient(const GradientArgs& a, hipStream_t s);
 void launch_pathtrace(const PathtraceArgs& a, hipStream_t s);
 void launch_atrous(const AtrousArgs& a, bool final_pass, hipStream_t s);
+hipError_t prepare_device_atrous();  // per device, from rtpt_create: raises the dynamic-LDS limit of the staged filter kernels
 void launch_stamp_depth(const FrameGeom& g, float4* color, const float* depth, hipStream_t s);
 void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s);
 void launch_selftest_trace(const SceneView& scene, const float* rays, size_t n, float tmax, uint32_t* out_id,
