@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RTPT_ABI_VERSION 1
+#define RTPT_ABI_VERSION 2
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define RTPT_OK 0
@@ -100,6 +100,10 @@ typedef struct rtpt_visibility_data {
                                               handing the paths that survive 4 / 8 / 16 segments to follow-up launches
                                               through a queue (A/B switch; the image is the same) */
 
+#define RTPT_FLAG_NO_FILTER_FUSION 0x400u /* K3: launch every rtpt_temporal_filter call at once, one kernel per
+                                             iteration, instead of recording the frame's calls and chaining
+                                             consecutive iterations into one launch (A/B switch; same pixels) */
+
 /* Extension modes — NOT reference behaviour, default off.  They switch on the pieces of the textbook
  * A-SVGF that the reference declares but leaves unused; any of them routes K3 to a
  * generic direct-load kernel.  They cannot be parity-checked against the reference; tests/ check them
@@ -157,7 +161,9 @@ typedef enum rtpt_plane {
   RTPT_PLANE_PREV_PIXEL = 10, /* build-only observable: reprojected pixel (int32 x,y) written
                                  by the final filter pass; temporalFiltering.comp.glsl:238 */
   RTPT_PLANE_RAYCOUNT = 11, /* build-only: u64[1] closest-hit queries issued by rtpt_raytrace
-                               since rtpt_reset_counters (SURVEY 8d "ray") */
+                               since rtpt_reset_counters (SURVEY 8d "ray").  On the device it is kept as 256
+                               partial sums (one counter serialised 32 400 atomics per 4K launch); rtpt_readback
+                               adds them up, rtpt_plane_ptr returns the u64[256] array */
   RTPT_PLANE_HIT_ID = 12,   /* build-only observable (debug): u32 first-hit primitive id+1 of the
                                jittered primary ray of rtpt_raytrace, only if enabled */
   RTPT_PLANE_MOMENTS = 13,  /* extension RTPT_FLAG_EXT_VARIANCE: (m1, m2, history length, variance) float4 */
@@ -195,8 +201,12 @@ int rtpt_set_stream(rtpt_ctx* ctx, void* hip_stream);
  * app owning every VkImage bound into the descriptor sets (createAndBindDescriptorSet,
  * main.cpp:744-908).  bytes must be >= rtpt_plane_bytes.  NULL returns to context-owned memory. */
 int rtpt_bind_plane(rtpt_ctx* ctx, rtpt_plane which, void* device_ptr, size_t bytes);
-/* current device pointer playing the role `which` (roles rotate at the final filter pass and at
- * rtpt_end_frame — re-query after those calls) */
+/* current device pointer playing the role `which`.  Roles ROTATE among the three colour buffers — at the final filter
+ * pass, when iterations run chained, and at rtpt_end_frame — so re-query after those calls; a buffer bound as IMAGE
+ * does not stay IMAGE.  Alpha convention on the device: IMAGE after the last iteration of a frame and PREVIOUS after
+ * rtpt_end_frame have alpha 0 like the reference's vec4(rgb, 0); between rtpt_raytrace and the last iteration the
+ * colour planes carry the G-buffer depth in alpha ("rgbd"), and FILTERED is scratch whose alpha may hold it at any
+ * time.  rtpt_readback always returns alpha 0. */
 int rtpt_plane_ptr(rtpt_ctx* ctx, rtpt_plane which, void** device_ptr);
 int rtpt_plane_bytes(const rtpt_ctx* ctx, rtpt_plane which, size_t* bytes);
 
@@ -239,7 +249,15 @@ int rtpt_raytrace(rtpt_ctx* ctx, const rtpt_push_constants* pc, uint32_t y0, uin
  * like main.cpp:1259.  Odd k reads IMAGE and writes FILTERED, even k the reverse
  * (main.cpp:1264-1281).  On k == max (odd) the fused reprojection + blend result becomes
  * IMAGE (D1: taps read the pre-pass snapshot).  ubo supplies viewPrev/projPrev and may be
- * NULL when k < max. */
+ * NULL when k < max.
+ * The calls of a frame are RECORDED, like the reference records its dispatches into command buffers
+ * (main.cpp:1284-1303), and launched when the call with k == max arrives: consecutive iterations then run as one
+ * chained kernel whose intermediate image stays in LDS instead of travelling through `filteredImageBuffer` / `image`
+ * (same arithmetic per pixel, same bits).  Every other entry point that reads or changes a plane, a stream or the
+ * frame state first launches what is recorded, one kernel per iteration, so between iterations each plane holds what
+ * the separate dispatches leave there.  After the LAST iteration IMAGE holds the frame; FILTERED is scratch (the
+ * reference's own last store to it, temporalFiltering.comp.glsl:152, is dead).  RTPT_FLAG_NO_FILTER_FUSION turns the
+ * recording off.  An error of a recorded launch is reported by the call that triggers it. */
 int rtpt_temporal_filter(rtpt_ctx* ctx, const rtpt_push_constants* pc, const rtpt_ubo* ubo,
                          uint32_t y0, uint32_t y1);
 /* history hand-over of copyImageToSwapChainsCurrentImage (main.cpp:1364-1372):
@@ -276,7 +294,9 @@ typedef enum rtpt_kernel_id {
   RTPT_K_PATHTRACE = 3,
   RTPT_K_ATROUS = 4,
   RTPT_K_ATROUS_FINAL = 5,
-  RTPT_K_COUNT = 6
+  RTPT_K_ATROUS_CHAIN = 6,       /* several consecutive iterations k < N in one launch (intermediates in LDS) */
+  RTPT_K_ATROUS_CHAIN_FINAL = 7, /* ... ending in the final pass */
+  RTPT_K_COUNT = 8
 } rtpt_kernel_id;
 int rtpt_timing_enable(rtpt_ctx* ctx, int enable);
 int rtpt_timing_collect(rtpt_ctx* ctx, double ms_sum[RTPT_K_COUNT], uint32_t launches[RTPT_K_COUNT]);

@@ -22,6 +22,7 @@ FLAG_EXACT_FILTER, FLAG_FORCE_BVH, FLAG_DIRECT_FILTER, FLAG_NO_PATH_COMPACTION =
 FLAG_EXT_ADAPTIVE_ALPHA, FLAG_EXT_GAUSS5, FLAG_EXT_POW2_STRIDE, FLAG_EXT_DISOCCLUSION = 0x10, 0x20, 0x40, 0x80
 FLAG_EXT_VARIANCE = 0x100
 FLAG_SINGLE_LAUNCH_PATHS = 0x200
+FLAG_NO_FILTER_FUSION = 0x400
 FLAG_EXT_MASK = 0x1F0
 DEBUG_HIT_ID, DEBUG_PREV_PIXEL = 0x1, 0x2
 
@@ -30,8 +31,9 @@ DEBUG_HIT_ID, DEBUG_PREV_PIXEL = 0x1, 0x2
  PLANE_PREV_VIS_ID, PLANE_LUT, PLANE_LUT_PREV, PLANE_PREV_PIXEL, PLANE_RAYCOUNT, PLANE_HIT_ID, PLANE_MOMENTS,
  PLANE_VARIANCE) = range(15)
 # rtpt_kernel_id
-K_GBUFFER, K_LUT, K_GRADIENT, K_PATHTRACE, K_ATROUS, K_ATROUS_FINAL, K_COUNT = range(7)
-KERNEL_NAMES = ["k_gbuffer", "k_lut", "k_gradient", "k_pathtrace", "k_atrous", "k_atrous_final"]
+K_GBUFFER, K_LUT, K_GRADIENT, K_PATHTRACE, K_ATROUS, K_ATROUS_FINAL, K_ATROUS_CHAIN, K_ATROUS_CHAIN_FINAL, K_COUNT = range(9)
+KERNEL_NAMES = ["k_gbuffer", "k_lut", "k_gradient", "k_pathtrace", "k_atrous", "k_atrous_final", "k_atrous_chain",
+                "k_atrous_chain_final"]
 
 
 class RtptLibraryMissing(RuntimeError):

@@ -41,6 +41,13 @@ struct Buf {
 
 enum ColorRole { ROLE_IMAGE = 0, ROLE_FILTERED = 1, ROLE_PREVIOUS = 2 };
 
+struct FilterCall {  // one recorded rtpt_temporal_filter call
+  rtpt_push_constants pc;
+  rtpt_ubo ubo;
+  bool has_ubo;
+  uint32_t y0, y1;
+};
+
 struct TimedLaunch {
   int kernel;
   hipEvent_t start, stop;
@@ -93,6 +100,11 @@ struct rtpt_ctx {
   int ext_hist_y0 = 0, ext_hist_y1 = 0;
   int count_y0 = 0, count_y1 = 0;  // rows counted into RAYCOUNT
 
+  // K3 iterations recorded by rtpt_temporal_filter and not launched yet (see filter_flush)
+  std::vector<FilterCall> pending;
+  int chain_max = 2;        // iterations per chained launch (1 = never chain)
+  bool chain_final = false; // may a chain end in the FINAL pass
+
   // timing
   int timing_period = 0;          // 0 off, n: kernels of every n-th frame are bracketed by events
   uint64_t frames_ended = 0;
@@ -106,6 +118,14 @@ struct rtpt_ctx {
 };
 
 namespace {
+
+// K3 iterations recorded by rtpt_temporal_filter are launched before anything else looks at or changes the planes
+int filter_flush(rtpt_ctx* c, bool fuse);
+#define FLUSH_FILTER(c)                          \
+  do {                                           \
+    int rcf_ = filter_flush((c), false);         \
+    if (rcf_) return rcf_;                       \
+  } while (0)
 
 int alloc_buf(Buf& b, size_t bytes) {
   if (b.owned && b.ptr) (void)hipFree(b.ptr);
@@ -325,7 +345,7 @@ static int alloc_planes(rtpt_ctx* c) {
   if (rc == RTPT_OK) rc = alloc_buf(c->worldpos, px * 16);
   if (rc == RTPT_OK) rc = alloc_buf(c->gradient, px * 16);
   if (rc == RTPT_OK) rc = alloc_buf(c->depth, px * 4);
-  if (rc == RTPT_OK && !c->raycount.ptr) rc = alloc_buf(c->raycount, 8);
+  if (rc == RTPT_OK && !c->raycount.ptr) rc = alloc_buf(c->raycount, 8 * rt::kRayCounters);
   for (auto& b : c->path_queue) free_buf(b);  // sized per frame: re-created by the next rtpt_raytrace
   free_buf(c->normals);  // sized per frame: re-created by the next rtpt_gbuffer
   c->normals_y0 = c->normals_y1 = 0;
@@ -348,7 +368,7 @@ static int alloc_planes(rtpt_ctx* c) {
   (void)hipMemsetAsync(c->worldpos.ptr, 0, px * 16, c->stream);
   (void)hipMemsetAsync(c->gradient.ptr, 0, px * 16, c->stream);
   (void)hipMemsetAsync(c->depth.ptr, 0, px * 4, c->stream);
-  (void)hipMemsetAsync(c->raycount.ptr, 0, 8, c->stream);
+  (void)hipMemsetAsync(c->raycount.ptr, 0, 8 * rt::kRayCounters, c->stream);
   if (c->hit_id.ptr) (void)hipMemsetAsync(c->hit_id.ptr, 0, px * 4, c->stream);
   if (c->prev_pixel.ptr) (void)hipMemsetAsync(c->prev_pixel.ptr, 0, px * 8, c->stream);
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -407,6 +427,7 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
     e = rt::prepare_device_atrous();
+    if (e == hipSuccess) e = rt::prepare_device_atrous_chain();
     if (e != hipSuccess) {
       rtpt_destroy(c);
       return fail(RTPT_E_DEVICE, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
@@ -414,6 +435,9 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   }
   c->count_y0 = static_cast<int>(cfg->row_begin);
   c->count_y1 = static_cast<int>(cfg->row_end);
+  // tuning knobs for A/B runs on the box (never needed for correctness: every setting computes the same pixels)
+  if (const char* v = std::getenv("RTPT_CHAIN_MAX")) c->chain_max = std::max(1, std::min(3, std::atoi(v)));
+  if (const char* v = std::getenv("RTPT_CHAIN_FINAL")) c->chain_final = std::atoi(v) != 0;
   int rc = alloc_planes(c);
   if (rc != RTPT_OK) {
     rtpt_destroy(c);
@@ -454,6 +478,7 @@ int rtpt_resize(rtpt_ctx* c, uint32_t width, uint32_t height, uint32_t row_begin
   if (row_begin == 0 && row_end == 0) row_end = height;
   if (width == 0 || height == 0 || row_begin >= row_end || row_end > height) return fail(RTPT_E_INVALID, "bad frame / row range");
   HIP_TRY(hipSetDevice(c->device));
+  FLUSH_FILTER(c);
   HIP_TRY(hipStreamSynchronize(c->stream));
   rtpt_config old = c->cfg;
   c->cfg.width = width;
@@ -471,6 +496,7 @@ int rtpt_resize(rtpt_ctx* c, uint32_t width, uint32_t height, uint32_t row_begin
 
 int rtpt_set_stream(rtpt_ctx* c, void* hip_stream) {
   if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  FLUSH_FILTER(c);
   c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
   return RTPT_OK;
 }
@@ -484,6 +510,7 @@ int rtpt_plane_bytes(const rtpt_ctx* c, rtpt_plane which, size_t* bytes) {
 
 int rtpt_plane_ptr(rtpt_ctx* c, rtpt_plane which, void** device_ptr) {
   if (!c || !device_ptr) return fail(RTPT_E_INVALID, "NULL argument");
+  FLUSH_FILTER(c);  // roles rotate when recorded iterations run
   Buf* b = plane_buf(c, which);
   if (!b) return fail(RTPT_E_INVALID, "unknown plane");
   *device_ptr = b->ptr;
@@ -492,6 +519,7 @@ int rtpt_plane_ptr(rtpt_ctx* c, rtpt_plane which, void** device_ptr) {
 
 int rtpt_bind_plane(rtpt_ctx* c, rtpt_plane which, void* device_ptr, size_t bytes) {
   if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  FLUSH_FILTER(c);
   Buf* b = plane_buf(c, which);
   if (!b || which == RTPT_PLANE_RAYCOUNT || which == RTPT_PLANE_LUT || which == RTPT_PLANE_LUT_PREV)
     return fail(RTPT_E_INVALID, "plane cannot be bound");
@@ -524,9 +552,12 @@ int rtpt_set_external_history(rtpt_ctx* c, const void* device_ptr, uint32_t row_
 
 int rtpt_stream_wait(rtpt_ctx* c, rtpt_ctx* other) {
   if (!c || !other) return fail(RTPT_E_INVALID, "NULL argument");
+  FLUSH_FILTER(other);  // "everything submitted to `other` so far" includes its recorded iterations
+  FLUSH_FILTER(c);
   if (c == other || c->stream == other->stream) return RTPT_OK;  // one stream is already in order
   if (c->device != other->device) return fail(RTPT_E_INVALID, "rtpt_stream_wait: the contexts are on different devices");
   HIP_TRY(hipSetDevice(c->device));
+
   if (!other->handoff_event) HIP_TRY(hipEventCreateWithFlags(&other->handoff_event, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(other->handoff_event, other->stream));
   HIP_TRY(hipStreamWaitEvent(c->stream, other->handoff_event, 0));
@@ -558,6 +589,7 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   for (uint32_t i = 0; i < 3 * n_tris; i++)
     if (idx[i] >= n_verts) return fail(RTPT_E_INVALID, "index out of range");
   HIP_TRY(hipSetDevice(c->device));
+  FLUSH_FILTER(c);
   const uint32_t ni = (xf && n_instances) ? n_instances : 1;
   const uint64_t total64 = static_cast<uint64_t>(ni) * n_tris;
   if (total64 >= 0xFFFFFFF0ull) return fail(RTPT_E_INVALID, "too many triangles");
@@ -633,6 +665,7 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
   if (!c->n_tris) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");
   int rc = check_rows(c, y0, y1);
   if (rc) return rc;
+  FLUSH_FILTER(c);
   if (!is_identity(ubo->model))
     return fail(RTPT_E_INVALID, "ubo.model must be identity (the reference's is, main.cpp:1469; animated models are out of scope)");
   HIP_TRY(hipSetDevice(c->device));
@@ -720,6 +753,7 @@ int rtpt_temporal_gradient(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t 
   int rc = check_rows(c, y0, y1);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
+  FLUSH_FILTER(c);
   rt::GradientArgs a;
   a.g = geom(c, y0, y1);
   for (int i = 0; i < 3; i++) {
@@ -748,6 +782,7 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   int rc = check_rows(c, y0, y1);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
+  FLUSH_FILTER(c);
   rt::PathtraceArgs a;
   a.g = geom(c, y0, y1);
   a.scene = scene_view(c);
@@ -813,9 +848,15 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
 }
 
 // ------------------------------------------------------------------------------------------ K3
-int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
-  if (!c || !pc) return fail(RTPT_E_INVALID, "NULL argument");
-  if (!c->n_tris) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");
+// rtpt_temporal_filter keeps the reference's shape — one call per iteration of applyTemporalFiltering's loop
+// (main.cpp:1259-1305) — but the calls of a frame are RECORDED and launched when the last iteration arrives, the way the
+// reference records its dispatches into command buffers: consecutive iterations then run as one chained launch
+// (atrous_chain.hip) whose intermediate image never leaves LDS.  Any call that observes or changes what an iteration
+// reads or writes (readback, plane pointers, sync, another pass, ...) first runs the recorded iterations one by one, so
+// between iterations every plane holds exactly what the separate dispatches would have left there.
+namespace {
+
+int filter_validate(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_ubo* ubo, uint32_t& y0, uint32_t& y1) {
   int rc = check_rows(c, y0, y1);
   if (rc) return rc;
   const int k = pc->waveletIteration, max_it = pc->maxWaveletIteration;
@@ -825,21 +866,38 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
   const int stride = (ext & rt::kExtPow2Stride) ? (1 << (k - 1)) : k;
   const int64_t reach = static_cast<int64_t>(stride) * ((ext & rt::kExtGauss5) ? 2 : 1);
   // taps reach rows y +- reach (clamped to the frame, temporalFiltering.comp.glsl:135-136): they must be stored here
-  {
-    const int64_t lo = std::max<int64_t>(0, static_cast<int64_t>(y0) - reach);
-    const int64_t hi = std::min<int64_t>(c->cfg.height, static_cast<int64_t>(y1) + reach);
-    if (y1 > y0 && (lo < c->cfg.row_begin || hi > c->cfg.row_end))
-      return fail(RTPT_E_INVALID, "filter taps reaching " + std::to_string(reach) + " rows leave the stored rows (missing halo)");
-  }
+  const int64_t lo = std::max<int64_t>(0, static_cast<int64_t>(y0) - reach);
+  const int64_t hi = std::min<int64_t>(c->cfg.height, static_cast<int64_t>(y1) + reach);
+  if (y1 > y0 && (lo < c->cfg.row_begin || hi > c->cfg.row_end))
+    return fail(RTPT_E_INVALID, "filter taps reaching " + std::to_string(reach) + " rows leave the stored rows (missing halo)");
+  const bool final_pass = (k == max_it) && (k & 1);
+  if (final_pass && !ubo) return fail(RTPT_E_INVALID, "the final pass needs the UBO (viewPrev/projPrev)");
+  if ((ext & rt::kExtVariance) && !ubo)
+    return fail(RTPT_E_INVALID, "RTPT_FLAG_EXT_VARIANCE needs the UBO (viewPrev/projPrev) on every iteration");
+  return RTPT_OK;
+}
+
+// launch iteration f.pc.waveletIteration — or, with levels > 1, that iteration and the levels - 1 after it as one chain
+int filter_launch(rtpt_ctx* c, const FilterCall& f, int levels) {
+  const rtpt_push_constants* pc = &f.pc;
+  const rtpt_ubo* ubo = f.has_ubo ? &f.ubo : nullptr;
+  const uint32_t y0 = f.y0, y1 = f.y1;  // rows of the LAST iteration of the chain
+  const int k = pc->waveletIteration, max_it = pc->maxWaveletIteration;
+  const int k_last = k + levels - 1;
+  const uint32_t ext = c->cfg.flags & rt::kExtMask;
+  const int stride = (ext & rt::kExtPow2Stride) ? (1 << (k - 1)) : k;
+  const int64_t reach = static_cast<int64_t>(stride) * ((ext & rt::kExtGauss5) ? 2 : 1);
   // main.cpp:1264-1281: odd k reads `image`, writes `filteredImageBuffer`; even k the reverse.
   // An even final pass blends into a buffer nothing reads (main.cpp:55 "must be an odd number"),
   // so only an odd final pass is a FINAL launch.
-  const bool final_pass = (k == max_it) && (k & 1);
-  if (final_pass && !ubo) return fail(RTPT_E_INVALID, "the final pass needs the UBO (viewPrev/projPrev)");
+  const bool final_pass = (k_last == max_it) && (k_last & 1);
   HIP_TRY(hipSetDevice(c->device));
   int in_role = (k & 1) ? ROLE_IMAGE : ROLE_FILTERED;
   int out_role = (k & 1) ? ROLE_FILTERED : ROLE_IMAGE;
-  if (final_pass && c->final_swapped) std::swap(in_role, out_role);  // a second row range of the same final pass
+  if (levels == 1 && final_pass && c->final_swapped) std::swap(in_role, out_role);  // a second row range of the same final pass
+  // a chain reads the first iteration's input and writes the OTHER buffer, whatever the parity of its length; the roles
+  // are re-pointed below so that afterwards every role names the buffer the separate passes would have left it in
+  const int in_buf = c->color_of_role[in_role], out_buf = c->color_of_role[out_role];
   rt::AtrousArgs a;
   std::memset(&a, 0, sizeof a);
   a.g = geom(c, y0, y1);
@@ -854,12 +912,12 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
   a.n_cu = c->n_cu;
   // the last iteration of an even N writes `image` and nothing filters it again: alpha 0 like the reference's
   // vec4(rgb, 0) (temporalFiltering.comp.glsl:152), so a device-side consumer of IMAGE never sees the depth
-  a.alpha_zero = (k == max_it && !final_pass) ? 1 : 0;
+  a.alpha_zero = (k_last == max_it && !final_pass) ? 1 : 0;
   a.sigma_n = c->cfg.sigma_n;
   a.sigma_z = c->cfg.sigma_z;
   a.sigma_l = c->cfg.sigma_l;
-  a.in = static_cast<const float4*>(c->color[c->color_of_role[in_role]].ptr);
-  a.out = static_cast<float4*>(c->color[c->color_of_role[out_role]].ptr);
+  a.in = static_cast<const float4*>(c->color[in_buf].ptr);
+  a.out = static_cast<float4*>(c->color[out_buf].ptr);
   a.vis = static_cast<const uint32_t*>(c->vis[c->vis_cur].ptr);
   a.normal_tab = static_cast<const float4*>(c->normal_tab.ptr);
   {
@@ -867,13 +925,13 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
     const bool covered = c->normals.ptr && c->normals_frame == c->frames_ended && c->normals_y0 <= lo && c->normals_y1 >= hi;
     a.normals = covered ? static_cast<const float4*>(c->normals.ptr) : nullptr;
   }
-  if (!c->alpha_depth[c->color_of_role[in_role]]) {
+  if (!c->alpha_depth[in_buf]) {
     // the input plane was injected (rtpt_set_plane / rtpt_bind_plane): give it its depth channel
-    rt::launch_stamp_depth(geom(c, c->cfg.row_begin, c->cfg.row_end), static_cast<float4*>(c->color[c->color_of_role[in_role]].ptr),
+    rt::launch_stamp_depth(geom(c, c->cfg.row_begin, c->cfg.row_end), static_cast<float4*>(c->color[in_buf].ptr),
                            static_cast<const float*>(c->depth.ptr), c->stream);
-    c->alpha_depth[c->color_of_role[in_role]] = true;
+    c->alpha_depth[in_buf] = true;
   }
-  c->alpha_depth[c->color_of_role[out_role]] = !final_pass && !a.alpha_zero;
+  c->alpha_depth[out_buf] = !final_pass && !a.alpha_zero;
   if (final_pass) {
     a.frame = pc->frameNumber;
     a.alpha = c->cfg.alpha;
@@ -897,7 +955,6 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
     }
   }
   if (ext & rt::kExtVariance) {
-    if (!ubo) return fail(RTPT_E_INVALID, "RTPT_FLAG_EXT_VARIANCE needs the UBO (viewPrev/projPrev) on every iteration");
     if (k == 1) {  // temporal accumulation of the luminance moments of the traced image (this iteration's input)
       rt::MomentsArgs m;
       std::memset(&m, 0, sizeof m);
@@ -921,10 +978,30 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
     c->variance_last ^= 1;
   }
   {
-    Timer tm(c, final_pass ? RTPT_K_ATROUS_FINAL : RTPT_K_ATROUS);
-    rt::launch_atrous(a, final_pass, c->stream);
+    Timer tm(c, levels > 1 ? (final_pass ? RTPT_K_ATROUS_CHAIN_FINAL : RTPT_K_ATROUS_CHAIN) : (final_pass ? RTPT_K_ATROUS_FINAL : RTPT_K_ATROUS));
+    if (levels > 1)
+      rt::launch_atrous_chain(a, levels, final_pass, c->stream);
+    else
+      rt::launch_atrous(a, final_pass, c->stream);
   }
+  int rc;
   if ((rc = launch_check("temporal_filter"))) return rc;
+  if (levels > 1) {
+    // point the roles at the buffers the separate passes would have left them in: the result sits in out_buf
+    const int res_role = final_pass ? ROLE_IMAGE : ((k_last & 1) ? ROLE_FILTERED : ROLE_IMAGE);
+    const int oth_role = res_role == ROLE_IMAGE ? ROLE_FILTERED : ROLE_IMAGE;
+    c->color_of_role[res_role] = out_buf;
+    c->color_of_role[oth_role] = in_buf;
+    if (final_pass) {
+      c->final_swapped = true;
+      c->final_y0 = static_cast<int>(y0);
+      c->final_y1 = static_cast<int>(y1);
+    } else if (k_last == max_it) {
+      c->final_y0 = static_cast<int>(y0);
+      c->final_y1 = static_cast<int>(y1);
+    }
+    return RTPT_OK;
+  }
   if (final_pass) {
     if (!c->final_swapped) {
       // D1: the blend went to a distinct buffer, which now becomes `image`
@@ -943,9 +1020,82 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
   return RTPT_OK;
 }
 
+// run the recorded iterations.  fuse = false: one launch per iteration (an observer is about to look at the planes)
+int filter_flush(rtpt_ctx* c, bool fuse) {
+  if (c->pending.empty()) return RTPT_OK;
+  std::vector<FilterCall> calls;
+  calls.swap(c->pending);  // filter_launch may fail: the record is dropped either way
+  const size_t n = calls.size();
+  const int H = static_cast<int>(c->cfg.height);
+  size_t i = 0;
+  while (i < n) {
+    int levels = 1;
+    if (fuse && !(c->cfg.flags & (RTPT_FLAG_DIRECT_FILTER | RTPT_FLAG_NO_FILTER_FUSION)) && !(c->cfg.flags & rt::kExtMask) && c->pair_tab.ptr) {
+      const int k0 = calls[i].pc.waveletIteration, max_it = calls[i].pc.maxWaveletIteration;
+      // grow the chain while the next record is the next iteration, its rows are covered and the kernel has the LDS
+      while (i + levels < n && levels < c->chain_max) {
+        const FilterCall &cur = calls[i + levels - 1], &nxt = calls[i + levels];
+        const int kn = nxt.pc.waveletIteration;
+        if (kn != k0 + levels || nxt.pc.maxWaveletIteration != max_it) break;
+        const bool nxt_final = (kn == max_it) && (kn & 1);
+        if (nxt_final && !c->chain_final) break;
+        if (nxt_final && c->final_swapped) break;
+        const int need0 = std::max(0, static_cast<int>(nxt.y0) - kn), need1 = std::min(H, static_cast<int>(nxt.y1) + kn);
+        if (nxt.y1 <= nxt.y0 || static_cast<int>(cur.y0) > need0 || static_cast<int>(cur.y1) < need1) break;
+        if (!rt::atrous_chain_supported(k0, levels + 1, c->n_tris)) break;
+        levels++;
+        if (nxt_final) break;
+      }
+      // a chain must not end one short of a FINAL pass it could have included... nothing to do: greedy from the front
+    }
+    FilterCall f = calls[i];
+    if (levels > 1) {
+      const FilterCall& lastc = calls[i + levels - 1];
+      f.y0 = lastc.y0;
+      f.y1 = lastc.y1;
+      f.has_ubo = lastc.has_ubo;
+      f.ubo = lastc.ubo;
+      f.pc.frameNumber = lastc.pc.frameNumber;
+    }
+    int rc = filter_launch(c, f, levels);
+    if (rc) return rc;
+    i += static_cast<size_t>(levels);
+  }
+  return RTPT_OK;
+}
+
+}  // namespace
+
+int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
+  if (!c || !pc) return fail(RTPT_E_INVALID, "NULL argument");
+  if (!c->n_tris) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");
+  int rc = filter_validate(c, pc, ubo, y0, y1);
+  if (rc) return rc;
+  FilterCall f;
+  f.pc = *pc;
+  f.has_ubo = ubo != nullptr;
+  if (ubo) f.ubo = *ubo;
+  f.y0 = y0;
+  f.y1 = y1;
+  const bool record = !(c->cfg.flags & (RTPT_FLAG_NO_FILTER_FUSION | RTPT_FLAG_DIRECT_FILTER)) && !(c->cfg.flags & rt::kExtMask) &&
+                      c->pair_tab.ptr && c->chain_max > 1;
+  if (!record) {
+    FLUSH_FILTER(c);
+    return filter_launch(c, f, 1);
+  }
+  // a record that does not continue the recorded run (same iteration twice, a restart) ends it
+  if (!c->pending.empty() && (c->pending.back().pc.waveletIteration + 1 != pc->waveletIteration ||
+                              c->pending.back().pc.maxWaveletIteration != pc->maxWaveletIteration))
+    FLUSH_FILTER(c);
+  c->pending.push_back(f);
+  if (pc->waveletIteration == pc->maxWaveletIteration) return filter_flush(c, true);
+  return RTPT_OK;
+}
+
 // ------------------------------------------------------------------------------------------ K4
 int rtpt_end_frame(rtpt_ctx* c) {
   if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  FLUSH_FILTER(c);
   // main.cpp:1364 image -> previousImage: rotate roles instead of blitting.  After the reference's
   // copy both images hold the same pixels; here IMAGE now names the old history buffer (about to be
   // overwritten by the next rtpt_raytrace), so until then rtpt_readback(IMAGE) is served from
@@ -968,18 +1118,29 @@ int rtpt_end_frame(rtpt_ctx* c) {
 int rtpt_sync(rtpt_ctx* c) {
   if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
+  FLUSH_FILTER(c);
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RTPT_OK;
 }
 
 int rtpt_readback(rtpt_ctx* c, rtpt_plane which, void* dst, size_t bytes) {
   if (!c || !dst) return fail(RTPT_E_INVALID, "NULL argument");
+  FLUSH_FILTER(c);
   Buf* b = plane_buf(c, (which == RTPT_PLANE_IMAGE && c->image_alias) ? RTPT_PLANE_PREVIOUS : which);
   if (!b) return fail(RTPT_E_INVALID, "unknown plane");
   if (!b->ptr) return fail(RTPT_E_INVALID, "plane not allocated (scene not uploaded / debug plane not enabled)");
   const size_t need = plane_size(c, which);
   if (bytes < need) return fail(RTPT_E_INVALID, "destination too small");
   HIP_TRY(hipSetDevice(c->device));
+  if (which == RTPT_PLANE_RAYCOUNT) {  // kept as partial sums on the device
+    unsigned long long part[rt::kRayCounters];
+    HIP_TRY(hipMemcpyAsync(part, b->ptr, sizeof part, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long total = 0;
+    for (unsigned long long v : part) total += v;
+    std::memcpy(dst, &total, sizeof total);
+    return RTPT_OK;
+  }
   HIP_TRY(hipMemcpyAsync(dst, b->ptr, need, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (int i = 0; i < 3; i++)
@@ -993,6 +1154,7 @@ int rtpt_readback(rtpt_ctx* c, rtpt_plane which, void* dst, size_t bytes) {
 
 int rtpt_set_plane(rtpt_ctx* c, rtpt_plane which, const void* src, size_t bytes) {
   if (!c || !src) return fail(RTPT_E_INVALID, "NULL argument");
+  FLUSH_FILTER(c);
   Buf* b = plane_buf(c, which);
   if (!b) return fail(RTPT_E_INVALID, "unknown plane");
   if (!b->ptr) return fail(RTPT_E_INVALID, "plane not allocated (scene not uploaded / debug plane not enabled)");
@@ -1019,7 +1181,7 @@ int rtpt_set_plane(rtpt_ctx* c, rtpt_plane which, const void* src, size_t bytes)
 int rtpt_reset_counters(rtpt_ctx* c) {
   if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipMemsetAsync(c->raycount.ptr, 0, 8, c->stream));
+  HIP_TRY(hipMemsetAsync(c->raycount.ptr, 0, 8 * rt::kRayCounters, c->stream));
   return RTPT_OK;
 }
 
@@ -1041,6 +1203,7 @@ int rtpt_timing_enable(rtpt_ctx* c, int enable) {
 int rtpt_timing_collect(rtpt_ctx* c, double ms_sum[RTPT_K_COUNT], uint32_t launches[RTPT_K_COUNT]) {
   if (!c || !ms_sum || !launches) return fail(RTPT_E_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(c->device));
+  FLUSH_FILTER(c);
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (int i = 0; i < RTPT_K_COUNT; i++) {
     ms_sum[i] = 0.0;
@@ -1067,6 +1230,8 @@ const char* rtpt_kernel_name(rtpt_kernel_id k) {
     case RTPT_K_PATHTRACE: return "k_pathtrace";
     case RTPT_K_ATROUS: return "k_atrous";
     case RTPT_K_ATROUS_FINAL: return "k_atrous_final";
+    case RTPT_K_ATROUS_CHAIN: return "k_atrous_chain";
+    case RTPT_K_ATROUS_CHAIN_FINAL: return "k_atrous_chain_final";
     default: return "?";
   }
 }

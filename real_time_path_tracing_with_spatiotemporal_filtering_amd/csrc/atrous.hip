@@ -19,6 +19,7 @@
 // HBM traffic per pixel and a third fewer load instructions.  The final pass writes alpha 0 again;
 // the C-ABI layer hides the convention (rtpt_readback masks alpha, rtpt_set_plane re-stamps depth).
 #include "device_common.hpp"
+#include "lds_dma.hpp"
 
 namespace rt {
 namespace {
@@ -184,23 +185,6 @@ __global__ __launch_bounds__(kThreads) void k_atrous(AtrousArgs a) {
 // one generic direct-load kernel (same tap arithmetic as k_atrous) rather than a tuned one.
 __constant__ float kGauss5[5][5] = {{1, 4, 7, 4, 1}, {4, 16, 26, 16, 4}, {7, 26, 41, 26, 7}, {4, 16, 26, 16, 4}, {1, 4, 7, 4, 1}};
 
-// reprojection of a pixel into the previous frame (temporalFiltering.comp.glsl:213-239, worldToPixel :178-189), exact
-// arithmetic: the truncated pixel coordinate is an integer observable
-__device__ __forceinline__ void reproject_pixel(int W, int H, const float* PVprev, uint32_t idp, f3 wp, const float4* lut_prev,
-                                                int x, int y, int& ppx, int& ppy) {
-  ppx = x;
-  ppy = y;
-  if (idp < 1) return;
-  const f3 va = xyz(lut_prev[3 * idp]), vb = xyz(lut_prev[3 * idp + 1]), vc = xyz(lut_prev[3 * idp + 2]);
-  const f3 bc = bary_coords(wp, va, vb, vc);
-  const f3 wpp = bary_mix(bc, va, vb, vc);
-  const float clx = exact::mat_row_point(PVprev, 0, wpp), cly = exact::mat_row_point(PVprev, 1, wpp),
-              clw = exact::mat_row_point(PVprev, 3, wpp);
-  const float ndx = clx / clw, ndy = cly / clw;
-  ppx = exact::f2i(fmaf_(ndx, 0.5f, 0.5f) * static_cast<float>(W));
-  ppy = exact::f2i(fmaf_(ndy, 0.5f, 0.5f) * static_cast<float>(H));
-}
-
 __device__ __forceinline__ float luminance(f3 c) { return fmaf_(0.0722f, c.z, fmaf_(0.7152f, c.y, 0.2126f * c.x)); }
 
 // RTPT_FLAG_EXT_VARIANCE (extension, see include/rtpt.h): first and second luminance moments accumulated along the
@@ -321,25 +305,6 @@ __global__ __launch_bounds__(kThreads) void k_atrous_ext(AtrousArgs a) {
   a.out[rowp + x] = make_float4(blend.x, blend.y, blend.z, 0.0f);
 }
 
-// LDS-DMA issued from inline asm.  hipcc models `__builtin_amdgcn_global_load_lds` as an LDS store and
-// puts `s_waitcnt vmcnt(0)` in front of every later ds_read that may alias it — with a ring buffer
-// that is every read, which drains the prefetch each step.  Hidden in asm, the DMA is invisible to
-// that pass and is ordered by hand: counted vmcnt + s_barrier before the reads (below).  M0 carries
-// the wave-uniform LDS byte address; lane i lands at M0 + i*size.  One wait state is required between
-// the SALU write of M0 and the LDS-DMA that reads it.
-// `base` is a wave-uniform pointer (SGPR pair), `voff` the per-lane byte offset: no 64-bit VALU math.
-// M0 is on the clobber list: the compiler must not assume a value it placed there (s_movrel indexing, sendmsg,
-// its own LDS-DMA builtin) survives the statement.  clang warns that M0 is a reserved register; naming it is
-// exactly the point, so that warning is silenced for these two functions only.
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ void dma_b128(const void* base, uint32_t voff, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
-}
-__device__ __forceinline__ void dma_b32(const void* base, uint32_t voff, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
-}
-#pragma clang diagnostic pop
 
 
 // "Comb" kernel.

@@ -1,0 +1,363 @@
+// atrous_chain.hip — K3, several CONSECUTIVE iterations of applyTemporalFiltering's loop (main.cpp:1259-1305) in one
+// launch: iteration k reads what iteration k-1 wrote, so run back to back every pass costs a 16 B/px store and a
+// 20 B/px load that exist only to carry the intermediate image through HBM.  Here the intermediates live in LDS.
+//
+// Per-pixel arithmetic is the single-pass kernel's (temporalFiltering.comp.glsl:118-155: 3x3 taps at stride k,
+// x offset outer / y offset inner, same weights, same accumulation order), and an intermediate is the same binary32
+// value whether it rests in HBM or in LDS — so the chain is bit-identical to the separate passes, in the exact and in
+// the fast weight arithmetic (tests compare the two bit for bit at full size).
+//
+// Shape.  A workgroup owns a column strip (bw output pixels wide) of a row segment and slides down it.  Level l
+// (iteration k0 + l, stride s_l) produces G rows per step from a ring of rows of level l-1 kept in LDS; the levels run
+// as a software pipeline — in one step every level works on the rows the level before it finished in the previous
+// step — so there is ONE workgroup barrier per step and no vertical halo inside a segment.  Level l is computed
+// E_l = sum_{j>l} s_j columns beyond the strip on either side (what the later levels' taps reach), the input is staged
+// E_0 + s_0 beyond it: for the pair (3,4) that is 128 computed and 134 staged columns per 120 stored — 1.07x / 1.12x
+// instead of the 9 (or 81) global taps per pixel of the separate passes.
+//   rows of level l at step t:  y = in_start + t*G + g - lag_l,   lag_0 = s_0 + G,  lag_l = lag_{l-1} + s_l + G
+//   ring of level l's input:    2*s_l + 2*G rows (what level l still reads + what its producer writes this step)
+// The input ring is filled by LDS-DMA issued at the top of a step for the rows the NEXT step consumes, so the loads
+// are in flight under a whole step of arithmetic; only the level-0 waves issue DMA and only the last level's waves
+// store to global memory, so `s_waitcnt vmcnt(0)` at the barrier never waits for a store.
+// Frame borders follow the reference's clamp (:136): rows by clamping the tap row before the ring slot is formed
+// (scalar), columns by letting a lane that stands for a column outside the frame compute the clamped column's value
+// (one v_med3 per task), so every staged cell of every level holds exactly what the clamped fetch would return.
+#include "device_common.hpp"
+#include "lds_dma.hpp"
+
+namespace rt {
+namespace {
+
+#ifndef RTPT_CHAIN_G
+#define RTPT_CHAIN_G 2
+#endif
+constexpr int kChG = RTPT_CHAIN_G;  // rows per level per step
+constexpr int kChCols = 128;        // columns a level computes at most: two waves per row
+
+__device__ __forceinline__ int posmod(int n, int r) {
+  int m = n % r;
+  return m < 0 ? m + r : m;
+}
+
+template <int L, bool FINAL, bool EXACT>
+__global__ __launch_bounds__(128 * L * kChG) void k_atrous_chain(AtrousArgs a) {
+  constexpr int G = kChG;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int W = a.g.W, H = a.g.H;
+  const int lane = static_cast<int>(threadIdx.x);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const int NP = static_cast<int>(a.n_tris) + 1;
+
+  // ---- geometry of the chain (all wave-uniform)
+  int s[L], E[L], R[L], lag[L];
+  for (int l = 0; l < L; l++) s[l] = a.k + l;  // main.cpp:1259-1260: waveletIteration = k, tap offset i*k (:135)
+  E[L - 1] = 0;
+  for (int l = L - 2; l >= 0; l--) E[l] = E[l + 1] + s[l + 1];
+  for (int l = 0; l < L; l++) R[l] = 2 * s[l] + 2 * G;  // ring l = input of level l
+  lag[0] = s[0] + G;
+  for (int l = 1; l < L; l++) lag[l] = lag[l - 1] + s[l] + G;
+  const int bw = kChCols - 2 * E[0];
+  const int in_stride = kChCols + 2 * s[0];  // staged input columns
+  // LDS: [id-pair weights][ring 0: colour cells, ids][ring 1: colour, ids]...
+  uint32_t ring_col[L], ring_ids[L];
+  {
+    uint32_t off = static_cast<uint32_t>((NP * NP * 4 + 15) & ~15);
+    for (int l = 0; l < L; l++) {
+      const uint32_t cells = static_cast<uint32_t>(R[l] * (l == 0 ? in_stride : kChCols));
+      ring_col[l] = off;
+      ring_ids[l] = off + 16u * cells;
+      off += 20u * cells;
+    }
+  }
+  float* pairw = reinterpret_cast<float*>(lds_raw);
+  for (int i = wave * 64 + lane; i < NP * NP; i += 128 * L * G) pairw[i] = a.pair_tab[i];
+
+  // ---- this workgroup's strip and row segment.  XCD-aware: physical blocks b, b+8, ... share an L2; each XCD gets a
+  // contiguous run of the (segment-major, strip-minor) list so the column halos shared by neighbouring strips meet there.
+  const uint32_t nb = static_cast<uint32_t>(a.n_strips) * static_cast<uint32_t>(a.n_segs);
+  const uint32_t per_xcd = (nb + 7u) >> 3;
+  const uint32_t lb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (lb >= nb) return;  // block-uniform, before any barrier
+  const int seg = static_cast<int>(lb / static_cast<uint32_t>(a.n_strips));
+  const int strip = static_cast<int>(lb - static_cast<uint32_t>(seg) * static_cast<uint32_t>(a.n_strips));
+  const int x0 = strip * bw;
+  const int ya = a.g.y0 + seg * a.seg_rows;
+  const int yb = ya + a.seg_rows < a.g.y1 ? ya + a.seg_rows : a.g.y1;
+  if (ya >= yb) return;
+  // rows every level must produce for this segment (frame clamp of the taps, :136), and the input rows to stage
+  int lo[L], hi[L];
+  lo[L - 1] = ya;
+  hi[L - 1] = yb - 1;
+  for (int l = L - 2; l >= 0; l--) {
+    lo[l] = lo[l + 1] - s[l + 1] < 0 ? 0 : lo[l + 1] - s[l + 1];
+    hi[l] = hi[l + 1] + s[l + 1] > H - 1 ? H - 1 : hi[l + 1] + s[l + 1];
+  }
+  const int ilo = lo[0] - s[0] < 0 ? 0 : lo[0] - s[0];
+  const int ihi = hi[0] + s[0] > H - 1 ? H - 1 : hi[0] + s[0];
+  int in_start = ya;
+  for (int l = 0; l < L; l++) in_start -= s[l];
+  const int T = (yb - 1 - in_start + lag[L - 1]) / G + 1;  // steps until the last output row has been produced
+
+  // ---- this wave's role: level lw, row gw of the step, half hw of the row
+  const int lw = wave / (2 * G), gw = (wave >> 1) % G, hw = wave & 1;
+  int sl = s[0], El = E[0], Rs = R[0], Rd = 1, lagw = lag[0], low = lo[0], hiw = hi[0];
+  uint32_t src_col = ring_col[0], src_ids = ring_ids[0], dst_col = 0, dst_ids = 0;
+#pragma unroll
+  for (int l = 1; l < L; l++)
+    if (lw == l) {
+      sl = s[l]; El = E[l]; Rs = R[l]; lagw = lag[l]; low = lo[l]; hiw = hi[l];
+      src_col = ring_col[l]; src_ids = ring_ids[l];
+    }
+#pragma unroll
+  for (int l = 0; l + 1 < L; l++)
+    if (lw == l) {
+      Rd = R[l + 1];
+      dst_col = ring_col[l + 1];
+      dst_ids = ring_ids[l + 1];
+    }
+  const bool last = lw == L - 1;
+  const int src_stride = lw == 0 ? in_stride : kChCols;
+  const int colv = hw * 64 + lane;                   // column within this level's extent
+  const bool lane_on = colv < bw + 2 * El;
+  const int xv = x0 - El + colv;                     // frame column this lane stands for
+  const int xc = xv < 0 ? 0 : (xv > W - 1 ? W - 1 : xv);  // :136
+  const int csrc = xc - x0 + El + sl;                // its column in the source ring (origin x0 - El - sl)
+  const float4* scol = reinterpret_cast<const float4*>(lds_raw + src_col);
+  const uint32_t* sids = reinterpret_cast<const uint32_t*>(lds_raw + src_ids);
+  float4* dcol = reinterpret_cast<float4*>(lds_raw + dst_col);
+  uint32_t* dids = reinterpret_cast<uint32_t*>(lds_raw + dst_ids);
+  int slot_s = posmod(gw - lagw, Rs), slot_d = posmod(gw - lagw, Rd);
+
+  // ---- staging duty (level-0 waves): wave w < G stages columns [0,64) and the tail [128, in_stride) of row w of the
+  // step, wave G <= w < 2G columns [64,128) of row w - G
+  const bool stager = wave < 2 * G;
+  const int srow = wave < G ? wave : wave - G;
+  const int schunk = wave < G ? 0 : 1;
+  uint32_t o16 = 0, o16t = 0;
+  {
+    const int origin = x0 - E[0] - s[0];
+    int gx = origin + schunk * 64 + lane;
+    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);  // :136
+    o16 = static_cast<uint32_t>(gx) * 16u;
+    int gt = origin + 128 + lane;
+    gt = gt < 0 ? 0 : (gt > W - 1 ? W - 1 : gt);
+    o16t = static_cast<uint32_t>(gt) * 16u;
+  }
+  const bool tail_lane = lane < 2 * s[0];
+  const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)lds_raw));
+  int slot_in = srow % R[0];  // ring slot of input row in_start + t*G + srow
+
+  __syncthreads();  // pair table visible
+
+  const float h9 = 1.0f / 9.0f;  // :145
+#pragma unroll 1
+  for (int t = 0; t < T; t++) {
+    // 1. stage the input rows of this step (consumed from the next step on)
+    if (stager) {
+      const int iy = in_start + t * G + srow;
+      if (iy >= ilo && iy <= ihi) {
+        const size_t grow = static_cast<size_t>(iy - a.g.row_base) * W;
+        const float4* rin = a.in + grow;
+        const uint32_t* rvis = a.vis + grow;
+        const uint32_t cell = static_cast<uint32_t>(slot_in * in_stride + schunk * 64);
+        __builtin_amdgcn_s_setprio(3);
+        dma_b128(rin, o16, lds0 + ring_col[0] + cell * 16u);
+        dma_b32(rvis, o16 >> 2, lds0 + ring_ids[0] + cell * 4u);
+        if (schunk == 0 && tail_lane) {
+          const uint32_t cellt = static_cast<uint32_t>(slot_in * in_stride + 128);
+          dma_b128(rin, o16t, lds0 + ring_col[0] + cellt * 16u);
+          dma_b32(rvis, o16t >> 2, lds0 + ring_ids[0] + cellt * 4u);
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+      slot_in += G;
+      if (slot_in >= R[0]) slot_in -= R[0];
+    }
+    // 2. this wave's row of its level
+    const int y = in_start + t * G + gw - lagw;
+    if (y >= low && y <= hiw && lane_on) {
+      const int ym = y - sl < 0 ? 0 : y - sl, yp = y + sl > H - 1 ? H - 1 : y + sl;  // :136
+      int sm = slot_s + (ym - y), sp = slot_s + (yp - y);
+      if (sm < 0) sm += Rs;
+      if (sp >= Rs) sp -= Rs;
+      const int rows3[3] = {sm * src_stride, slot_s * src_stride, sp * src_stride};
+      const int cc = rows3[1] + csrc;
+      const float4 cp4 = scol[cc];
+      const f3 cp = xyz(cp4);
+      const float dp = cp4.w;
+      const uint32_t idp = sids[cc];
+      const float* prow = pairw + idp * NP;
+      f3 num{0.f, 0.f, 0.f};
+      float den = 0.f;
+#pragma unroll
+      for (int i = -1; i < 2; i++) {  // :132 (x offset outer: the reference's accumulation order)
+#pragma unroll
+        for (int jj = -1; jj < 2; jj++) {  // :133
+          float w;
+          f3 cq;
+          if (i == 0 && jj == 0) {
+            cq = cp;
+            w = prow[idp];  // centre tap: q == p, both exponentials are exactly 1
+          } else {
+            const int qi = rows3[jj + 1] + csrc + i * sl;
+            const float4 cq4 = scol[qi];
+            cq = xyz(cq4);
+            const float dq = cq4.w;
+            const float wn = prow[sids[qi]];  // :62 via the id-pair table
+            const f3 dc = cp - cq;
+            if (EXACT) {
+              const float wd = exact::exp_(-__builtin_fabsf(dp - dq) / a.sigma_z);  // :67-68
+              const float wl = exact::exp_(-exact::length(dc) / a.sigma_l);         // :73
+              w = (wn * wd) * wl;                                                   // :77
+            } else {
+              const float e = fmaf_(__builtin_fabsf(dp - dq), a.cz, fast::sqrt_(exact::dot(dc, dc)) * a.cl);
+              w = wn * __builtin_amdgcn_exp2f(e);
+            }
+          }
+          if (EXACT) {
+            const float hw_ = h9 * w;
+            num = f3{fmaf_(hw_, cq.x, num.x), fmaf_(hw_, cq.y, num.y), fmaf_(hw_, cq.z, num.z)};  // :146
+            den = den + hw_;                                                                       // :147
+          } else {
+            num = f3{fmaf_(w, cq.x, num.x), fmaf_(w, cq.y, num.y), fmaf_(w, cq.z, num.z)};
+            den = den + w;
+          }
+        }
+      }
+      f3 filtered;
+      if (EXACT)
+        filtered = f3{num.x / den, num.y / den, num.z / den};  // :150
+      else
+        filtered = num * fast::rcp_(den);
+      if (!last) {
+        // :152 into the next level's ring instead of filteredImageBuffer / image
+        const int di = slot_d * kChCols + colv;
+        dcol[di] = make_float4(filtered.x, filtered.y, filtered.z, dp);
+        dids[di] = idp;
+      } else if (colv < bw && xv < W) {
+        const size_t ip = static_cast<size_t>(y - a.g.row_base) * W + xv;
+        if (!FINAL) {
+          typedef float v4f_ __attribute__((ext_vector_type(4)));
+          v4f_ o4 = {filtered.x, filtered.y, filtered.z, a.alpha_zero ? 0.0f : dp};
+          __builtin_nontemporal_store(o4, reinterpret_cast<v4f_*>(a.out + ip));  // :152; nothing in this launch re-reads it
+        } else {
+          // :213-263 reprojection + temporal blend, exact arithmetic (the truncated pixel is an integer observable)
+          int ppx, ppy;
+          reproject_pixel(W, H, a.PVprev, idp, xyz(a.worldpos[ip]), a.lut_prev, xv, y, ppx, ppy);
+          if (a.prev_pixel) a.prev_pixel[ip] = make_int2(ppx, ppy);
+          f3 blend = filtered;  // :258
+          if (a.frame > 0) {    // :251
+            f3 hc{0.f, 0.f, 0.f};  // D2
+            if (ppx >= 0 && ppx < W && ppy >= a.hist_y0 && ppy < a.hist_y1)
+              hc = xyz(a.history[static_cast<size_t>(ppy - a.hist_row_base) * W + ppx]);
+            const float oma = 1.0f - a.alpha;
+            blend = f3{fmaf_(filtered.x, a.alpha, hc.x * oma), fmaf_(filtered.y, a.alpha, hc.y * oma),
+                       fmaf_(filtered.z, a.alpha, hc.z * oma)};  // :254
+          }
+          a.out[ip] = make_float4(blend.x, blend.y, blend.z, 0.0f);  // :263 (D1: distinct buffer)
+        }
+      }
+    }
+    slot_s += G;
+    if (slot_s >= Rs) slot_s -= Rs;
+    slot_d += G;
+    if (slot_d >= Rd) slot_d -= Rd;
+    // 3. staged rows landed, ring writes done; the barrier publishes both to the next step
+    if (stager)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+}  // namespace
+
+// bytes of dynamic LDS of a chain of `levels` iterations starting at stride k0 (host mirror of the kernel's layout)
+size_t atrous_chain_lds(int k0, int levels, uint32_t n_tris) {
+  const int np = static_cast<int>(n_tris) + 1;
+  size_t off = static_cast<size_t>((np * np * 4 + 15) & ~15);
+  for (int l = 0; l < levels; l++) {
+    const int s = k0 + l;
+    const size_t cells = static_cast<size_t>(2 * s + 2 * kChG) * (l == 0 ? kChCols + 2 * k0 : kChCols);
+    off += 20 * cells;
+  }
+  return off;
+}
+
+int atrous_chain_strip_width(int k0, int levels) {
+  int e0 = 0;
+  for (int l = 1; l < levels; l++) e0 += k0 + l;
+  return kChCols - 2 * e0;
+}
+
+template <int L>
+static hipError_t chain_attrs() {
+  constexpr int kMax = 160 * 1024;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  return e;
+}
+hipError_t prepare_device_atrous_chain() {
+  hipError_t e = chain_attrs<2>();
+  if (e == hipSuccess) e = chain_attrs<3>();
+  return e;
+}
+
+// true when `levels` consecutive iterations from stride k0 can run as one chain on this scene
+bool atrous_chain_supported(int k0, int levels, uint32_t n_tris) {
+  if (levels < 2 || levels > 3 || k0 < 1) return false;
+  if (n_tris + 1 > 64) return false;  // id-pair table in LDS (the per-pixel-normal variant is not chained)
+  if (atrous_chain_strip_width(k0, levels) < 64) return false;
+  return atrous_chain_lds(k0, levels, n_tris) <= 160 * 1024;
+}
+
+void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, hipStream_t s) {
+  if (a0.g.y1 <= a0.g.y0) return;
+  AtrousArgs a = a0;
+  a.cz = -1.44269504088896341f / a.sigma_z;
+  a.cl = -1.44269504088896341f / a.sigma_l;
+  const int bw = atrous_chain_strip_width(a.k, levels);
+  const size_t lds = atrous_chain_lds(a.k, levels, a.n_tris);
+  a.n_strips = (a.g.W + bw - 1) / bw;
+  // one resident generation of workgroups: as many per CU as the LDS admits, row segments sized to fill them
+  const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
+  const int waves = 2 * levels * kChG;
+  int per_cu = static_cast<int>((160u * 1024u) / lds);
+  if (per_cu > 32 / waves) per_cu = 32 / waves;
+  if (per_cu < 1) per_cu = 1;
+  const int rows = a.g.y1 - a.g.y0;
+  int n_segs = (n_cu * per_cu) / a.n_strips;
+  if (n_segs < 1) n_segs = 1;
+  int seg_rows = (rows + n_segs - 1) / n_segs;
+  const int min_rows = 16 * a.k;  // a segment re-stages 2*sum(s) rows: keep that a small share
+  if (seg_rows < min_rows) seg_rows = min_rows;
+  seg_rows = (seg_rows + kChG - 1) / kChG * kChG;
+  a.seg_rows = seg_rows;
+  a.n_segs = (rows + seg_rows - 1) / seg_rows;
+  const uint32_t nb = static_cast<uint32_t>(a.n_strips) * static_cast<uint32_t>(a.n_segs);
+  const dim3 grid(((nb + 7u) / 8u) * 8u), block(64, waves);
+#define RTPT_LAUNCH_CHAIN(LV)                                                              \
+  do {                                                                                     \
+    if (a.exact) {                                                                         \
+      if (final_pass)                                                                      \
+        hipLaunchKernelGGL((k_atrous_chain<LV, true, true>), grid, block, lds, s, a);      \
+      else                                                                                 \
+        hipLaunchKernelGGL((k_atrous_chain<LV, false, true>), grid, block, lds, s, a);     \
+    } else {                                                                               \
+      if (final_pass)                                                                      \
+        hipLaunchKernelGGL((k_atrous_chain<LV, true, false>), grid, block, lds, s, a);     \
+      else                                                                                 \
+        hipLaunchKernelGGL((k_atrous_chain<LV, false, false>), grid, block, lds, s, a);    \
+    }                                                                                      \
+  } while (0)
+  if (levels == 2)
+    RTPT_LAUNCH_CHAIN(2);
+  else
+    RTPT_LAUNCH_CHAIN(3);
+#undef RTPT_LAUNCH_CHAIN
+}
+
+}  // namespace rt

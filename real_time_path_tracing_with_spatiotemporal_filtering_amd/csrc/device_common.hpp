@@ -26,6 +26,23 @@ __device__ __forceinline__ f3 bary_mix(f3 bc, f3 a, f3 b, f3 c) {
 }
 
 
+// reprojection of a pixel into the previous frame (temporalFiltering.comp.glsl:213-239, worldToPixel :178-189), exact
+// arithmetic: the truncated pixel coordinate is an integer observable
+__device__ __forceinline__ void reproject_pixel(int W, int H, const float* PVprev, uint32_t idp, f3 wp, const float4* lut_prev,
+                                                int x, int y, int& ppx, int& ppy) {
+  ppx = x;
+  ppy = y;
+  if (idp < 1) return;
+  const f3 va = xyz(lut_prev[3 * idp]), vb = xyz(lut_prev[3 * idp + 1]), vc = xyz(lut_prev[3 * idp + 2]);
+  const f3 bc = bary_coords(wp, va, vb, vc);
+  const f3 wpp = bary_mix(bc, va, vb, vc);
+  const float clx = exact::mat_row_point(PVprev, 0, wpp), cly = exact::mat_row_point(PVprev, 1, wpp),
+              clw = exact::mat_row_point(PVprev, 3, wpp);
+  const float ndx = clx / clw, ndy = cly / clw;
+  ppx = exact::f2i(fmaf_(ndx, 0.5f, 0.5f) * static_cast<float>(W));
+  ppy = exact::f2i(fmaf_(ndy, 0.5f, 0.5f) * static_cast<float>(H));
+}
+
 inline dim3 grid_for(const FrameGeom& g) {
   return dim3((g.W + kBlockX - 1) / kBlockX, (g.y1 - g.y0 + kBlockY - 1) / kBlockY, 1);
 }

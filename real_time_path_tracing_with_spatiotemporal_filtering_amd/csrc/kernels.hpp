@@ -119,6 +119,7 @@ struct AtrousArgs {
   int32_t cwp;           // comb kernel: staged row length in cells (set by launch_atrous)
   int32_t n_cu;          // compute units of the context's device (persistent grid size)
   int32_t alpha_zero;    // 1: a k < N launch writes alpha 0 instead of the depth (last iteration of an even N)
+  int32_t n_strips, n_segs, seg_rows;  // chained iterations (atrous_chain.hip): column strips x row segments (set by launch_atrous_chain)
   const float* pair_tab; // (n_tris+1)^2 id-pair normal weights, NULL when the scene is too large
   const float4* normals; // per-pixel (n.xyz, self weight) plane written by k_gbuffer for such scenes, NULL otherwise
   uint32_t n_tris;       // normal_tab has n_tris + 1 entries
@@ -186,6 +187,8 @@ constexpr uint32_t kPathQueues = RTPT_PATH_QUEUES;  // regions (and counters) pe
 #endif
 inline uint32_t pt_first_window(bool use_bvh) { return use_bvh ? RTPT_PT_BVH_MULT * RTPT_PT_PHASE0 : RTPT_PT_PHASE0; }
 
+constexpr uint32_t kRayCounters = 256;  // RAYCOUNT is kept as this many partial sums (power of two), added up at readback
+
 constexpr uint32_t kExtAdaptiveAlpha = 0x10u, kExtGauss5 = 0x20u, kExtPow2Stride = 0x40u, kExtDisocclusion = 0x80u;
 constexpr uint32_t kExtVariance = 0x100u;
 constexpr uint32_t kExtMask = 0x1F0u;
@@ -205,6 +208,12 @@ void launch_gbuffer(const GbufferArgs& a, hipStream_t s);
 void launch_gradient(const GradientArgs& a, hipStream_t s);
 void launch_pathtrace(const PathtraceArgs& a, hipStream_t s);
 void launch_atrous(const AtrousArgs& a, bool final_pass, hipStream_t s);
+// `levels` consecutive iterations k, k+1, .. in one launch, intermediates in LDS (atrous_chain.hip): a.k = the first
+// stride, a.in / a.out = input of the first and output of the last iteration (distinct buffers), final_pass = the last
+// level is the frame's FINAL pass (reprojection + blend)
+void launch_atrous_chain(const AtrousArgs& a, int levels, bool final_pass, hipStream_t s);
+bool atrous_chain_supported(int k0, int levels, uint32_t n_tris);
+hipError_t prepare_device_atrous_chain();
 hipError_t prepare_device_atrous();  // per device, from rtpt_create: raises the dynamic-LDS limit of the staged filter kernels
 void launch_stamp_depth(const FrameGeom& g, float4* color, const float* depth, hipStream_t s);
 void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s);

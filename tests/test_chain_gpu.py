@@ -1,0 +1,118 @@
+"""K3 chained iterations (atrous_chain.hip) against the one-kernel-per-iteration path (RTPT_FLAG_NO_FILTER_FUSION): the
+chain keeps the intermediate image in LDS instead of HBM and must not change a single bit — per-pixel arithmetic and
+accumulation order are the separate passes' (temporalFiltering.comp.glsl:118-155).  Every other GPU test runs with the
+chain on (it is the default), i.e. against the oracle; this file pins chain == separate passes at sizes the oracle is
+too slow for, and the recording semantics of rtpt_temporal_filter."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(hip_lib, w, h, n, flags, keys, seg=3, **kw):
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    app = make_app(w, h, max_segments=seg, iterations=n, flags=flags, debug_mask=hip_lib.DEBUG_PREV_PIXEL, **kw)
+    outs = []
+    for k in keys:
+        app.drawScene(k)
+        outs.append((app.backend.ctx.readback(hip_lib.PLANE_PREVIOUS), app.backend.ctx.readback(hip_lib.PLANE_PREV_PIXEL)))
+    names = app.backend.ctx.timing_collect()
+    app.backend.close()
+    return outs, names
+
+
+@pytest.mark.parametrize("exact", [0, 1])
+@pytest.mark.parametrize("size", [(1, 1), (63, 5), (65, 7), (130, 33), (121, 64), (333, 170), (1000, 800)])
+def test_chain_equals_separate_passes(hip_lib, size, exact):
+    """ragged widths (strip tails, a strip of one column), frames shorter than a ring, N = 2..9 (pairs (1,2), (3,4) run
+    chained, larger strides as far as the LDS admits, odd and even N), fast and exact weights, camera + light moving"""
+    w, h = size
+    keys = [(), ("J",), ("D", "E"), ()]
+    for n in (2, 3, 4, 5, 9):
+        a, _ = _frames(hip_lib, w, h, n, exact, keys)
+        b, _ = _frames(hip_lib, w, h, n, exact | hip_lib.FLAG_NO_FILTER_FUSION, keys)
+        for f, ((ia, pa), (ib, pb)) in enumerate(zip(a, b)):
+            assert np.array_equal(bits(ia), bits(ib)), (size, n, exact, f)
+            assert np.array_equal(pa, pb)
+
+
+@pytest.mark.parametrize("exact", [0, 1])
+def test_chain_equals_separate_passes_4k(hip_lib, exact):
+    """BASELINE configs[2] at its size: 3840x2160, 4 segments, N = 5, three frames"""
+    keys = [(), ("J",), ("A",)]
+    a, _ = _frames(hip_lib, 3840, 2160, 5, exact, keys, seg=4)
+    b, _ = _frames(hip_lib, 3840, 2160, 5, exact | hip_lib.FLAG_NO_FILTER_FUSION, keys, seg=4)
+    for (ia, pa), (ib, pb) in zip(a, b):
+        assert np.array_equal(bits(ia), bits(ib))
+        assert np.array_equal(pa, pb)
+        assert np.isfinite(ia[..., :3]).all() and not ia[..., 3].any()
+
+
+def test_chain_is_what_runs_by_default(hip_lib):
+    """the timing hooks name the launches: N = 5 is two chained pairs + the final pass, not four k_atrous launches"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    app = make_app(320, 200, max_segments=2, iterations=5)
+    ctx = app.backend.ctx
+    ctx.timing_enable(1)
+    for _ in range(3):
+        app.drawScene()
+    tm = ctx.timing_collect()
+    assert tm["k_atrous_chain"][1] == 6 and tm["k_atrous"][1] == 0 and tm["k_atrous_final"][1] == 3, tm
+    app.backend.close()
+    app = make_app(320, 200, max_segments=2, iterations=5, flags=hip_lib.FLAG_NO_FILTER_FUSION)
+    ctx = app.backend.ctx
+    ctx.timing_enable(1)
+    app.drawScene()
+    tm = ctx.timing_collect()
+    assert tm["k_atrous_chain"][1] == 0 and tm["k_atrous"][1] == 4 and tm["k_atrous_final"][1] == 1, tm
+    app.backend.close()
+
+
+def test_observation_between_iterations_sees_the_separate_pass_state(hip_lib, oracle, cornell):
+    """rtpt_temporal_filter records; a readback between iterations must show exactly what the separate dispatches leave
+    (main.cpp:1264-1281: odd k writes filteredImageBuffer, even k writes image), and the frame must still finish right"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    w, h, n = 200, 96, 5
+    X = hip_lib.FLAG_EXACT_FILTER
+    app = make_app(w, h, max_segments=3, iterations=n, flags=X)
+    ref = oracle.OracleApp(w, h, cornell[2], max_segments=3, iterations=n)
+    ctx = app.backend.ctx
+    for frame in range(2):
+        app.updateScene(("J",) if frame else ())
+        app.drawVisbilityBuffer()
+        app.computeTemporalGradient()
+        app.drawSceneToImage()
+        traced = ctx.readback(hip_lib.PLANE_IMAGE)
+        depth, vis, wp, lut, lutp = (ctx.readback(p) for p in (hip_lib.PLANE_DEPTH, hip_lib.PLANE_VIS_ID, hip_lib.PLANE_WORLDPOS,
+                                                             hip_lib.PLANE_LUT, hip_lib.PLANE_LUT_PREV))
+        pc = app.pushConstants
+        pc.maxWaveletIteration = n
+        opc = oracle.PushConstants.from_buffer_copy(bytes(pc))
+        oubo = oracle.Ubo.from_buffer_copy(bytes(app.ubo))
+        cur = traced
+        for k in range(1, n + 1):
+            pc.waveletIteration = k
+            opc.waveletIteration = k
+            app.backend.temporal_filter(pc, app.ubo, 0, h)
+            if k < n:
+                cur = oracle.atrous(ref.cfg, opc, oubo, cur, depth, vis, lut, lutp, wp, None)
+            if k in (2, 3):  # look after an even and an odd iteration: 1+2 were recorded, then 3 alone
+                got = ctx.readback(hip_lib.PLANE_IMAGE if k % 2 == 0 else hip_lib.PLANE_FILTERED)
+                assert np.array_equal(bits(got[..., :3]), bits(cur[..., :3])), (frame, k)
+        final = ctx.readback(hip_lib.PLANE_IMAGE)
+        app.copyImageToSwapChainsCurrentImage()
+        app.frameCount += 1
+        fo = ref.draw_scene(move_light=(-0.1, 0, 0) if frame else None)
+        assert np.array_equal(bits(final), bits(fo.image))
+    app.backend.close()
+
+
+@pytest.mark.parametrize("mode", ["redundant"])
+def test_chain_on_strips(hip_lib, mode):
+    """redundant-halo strips record and chain too (their row ranges shrink by the next stride per iteration, which is
+    exactly what a chain needs); exchange-mode strips look at the planes between iterations and run separate passes"""
+    from test_parity_gpu import _strips_vs_single
+    _strips_vs_single(250, 301, 3, 5, 4, mode, 0, [(), ("E",), ("J",)])
+    _strips_vs_single(250, 301, 3, 4, 3, mode, hip_lib.FLAG_EXACT_FILTER, [(), ("Q",), ()])
