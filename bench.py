@@ -39,9 +39,17 @@ WORKLOADS = {
 }
 PREWARM_SECONDS = 0.3
 HOST_SECONDS = [0.0]
+HIST_BYTES = [0]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# algorithmic bytes per pixel per launch (SURVEY.md 8d / BASELINE.md 3)
-BYTES_PER_PX = {"k_atrous": 40, "k_atrous_final": 72, "k_gradient": 36, "k_gbuffer": 24, "k_pathtrace": 16}
+# ALGORITHMIC bytes per pixel per launch (SURVEY.md 8d / BASELINE.md 3): one a-trous iteration k < N = 16+4+4 read +
+# 16 write = 40, the final one 72.  k_atrous_chain runs CHAIN_LEVELS iterations in one launch, so its algorithmic bytes
+# are CHAIN_LEVELS x 40 — the work 8(d) prices — although the intermediate image never reaches HBM.
+CHAIN_LEVELS = 2
+BYTES_PER_PX = {"k_atrous": 40, "k_atrous_final": 72, "k_atrous_chain": 40 * CHAIN_LEVELS, "k_gradient": 36, "k_gbuffer": 24,
+                "k_pathtrace": 16}
+# bytes the kernel as built MUST move per pixel (rgbd cells: depth rides in alpha, so 16 + 4 read and 16 written; the
+# chain reads its input once and writes its last level once; the per-pixel-normal variant of large scenes stages 16 more)
+REQUIRED_PER_PX = {"k_atrous": 36, "k_atrous_final": 68, "k_atrous_chain": 36}
 
 
 def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=True, in_flight=1):
@@ -54,8 +62,16 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
         extra = dict(mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar,
                      lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
     app = make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"],
-                   rank=rank, world=world, mode=args.halo,
+                   rank=rank, world=world, mode=args.halo, flags=args.flags,
                    torch_planes=(dist is not None), frames_in_flight=in_flight, **extra)
+    keys_of = (lambda f: (args.camera_keys[f % len(args.camera_keys)],)) if args.camera_keys else (lambda f: ())
+    frame_no = [0]
+    hist_bytes = [0]
+
+    def draw():
+        app.drawScene(keys_of(frame_no[0]))
+        frame_no[0] += 1
+        hist_bytes[0] += getattr(app, "history_bytes_sent", 0)
     ctxs = [b.ctx for b in app.backend.be] if in_flight == 2 else [app.backend.ctx]
     ctx = ctxs[0]
     collect_kernels = collect_kernels and in_flight == 1  # overlapping frames stretch every kernel's duration
@@ -80,15 +96,16 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
         n_wake = 0
         while time.perf_counter() - t_wake < args.prewarm_seconds or (n_wake < steps and time.perf_counter() - t_wake < 3.0):
             for _ in range(16):
-                app.drawScene()
+                draw()
             n_wake += 16
             for c in ctxs:
                 c.sync()
         ctx.timing_collect()
         ctx.timing_enable(0)
     for _ in range(warmup):
-        app.drawScene()
+        draw()
     fence()
+    hist_bytes[0] = 0
     for c in ctxs:
         c.reset_counters()
     # per-kernel HIP events on the launch stream, sampled: bracketing every launch costs ~6 % of the frame
@@ -96,7 +113,8 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        app.drawScene()
+        draw()
+    HIST_BYTES[0] = hist_bytes[0]
     HOST_SECONDS[0] = time.perf_counter() - t0  # time the host needed to submit the K steps (diagnostic)
     fence()
     elapsed = time.perf_counter() - t0
@@ -130,10 +148,12 @@ def kernel_report(kern, wl, plan, steps):
             continue
         avg_us = ms / n * 1e3
         e = {"launches_per_frame": n / steps, "avg_us": round(avg_us, 3)}
-        if name == "k_atrous":
+        if name in ("k_atrous", "k_atrous_chain"):
             N = wl["iterations"]
             ks = [k for k in range(1, N + 1) if not (k == N and N & 1)]  # an odd final pass is k_atrous_final
-            px = sum(b - a for a, b in map(plan.filter_rows, ks)) * W / len(ks)
+            if name == "k_atrous_chain":
+                ks = ks[CHAIN_LEVELS - 1::CHAIN_LEVELS]  # a chain stores the rows of its LAST iteration
+            px = sum(b - a for a, b in map(plan.filter_rows, ks)) * W / max(1, len(ks))
         elif name in rows:
             a, b = rows[name]
             px = (b - a) * W
@@ -142,6 +162,8 @@ def kernel_report(kern, wl, plan, steps):
         if px and name in BYTES_PER_PX:
             e["algorithmic_bytes"] = int(BYTES_PER_PX[name] * px)
             e["algorithmic_GBps"] = round(BYTES_PER_PX[name] * px / (avg_us * 1e-6) / 1e9, 1)
+        if px and name in REQUIRED_PER_PX:
+            e["required_bytes"] = int(REQUIRED_PER_PX[name] * px)
         out[name] = e
     return out
 
@@ -237,6 +259,12 @@ def main():
     ap.add_argument("--prewarm-seconds", type=float, default=PREWARM_SECONDS,
                     help="untimed device wake-up before the W warm-up steps (0 makes the rendered frame numbers, and "
                          "with them the ray counts, a function of --steps/--warmup only)")
+    ap.add_argument("--flags", type=lambda v: int(v, 0), default=0,
+                    help="RTPT_FLAG_* bits for A/B runs (0x400 = one kernel per a-trous iteration, no chaining)")
+    ap.add_argument("--camera-keys", default="",
+                    help="keys held on successive frames, cycled (e.g. EQ: the camera moves up and down 0.1 per frame, "
+                         "main.cpp:1119-1168), so that every frame reprojects and, on strips, exchanges history bands; "
+                         "default: camera at rest, like every BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -285,12 +313,16 @@ def main():
     result = None
     if rank == 0:
         kr = kernel_report(kern, wl, plan, timed_frames)
-        at = kr.get("k_atrous", {})
-        traffic = None
+        # the filter iterations k < N: chained pairs by default, single launches with RTPT_FLAG_NO_FILTER_FUSION
+        rk = "k_atrous_chain" if "k_atrous_chain" in kr else "k_atrous"
+        at = kr.get(rk, {})
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and world == 1:
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("k_atrous")
+                tj = json.load(open(tpath))
+                traffic = tj.get(args.workload, {}).get(rk)
+                traffic_source = tj.get("_source")
             except Exception:
                 traffic = None
         achieved = at.get("algorithmic_GBps")
@@ -313,11 +345,25 @@ def main():
                        "parallelism": f"row-strips x{world}" + (f" ({args.halo} halo)" if world > 1 else ""),
                        "frames_in_flight": args.frames_in_flight},
             "rays_per_frame": round(rays / args.steps, 1),
-            "roofline": {"kernel": "k_atrous (one a-trous iteration, k < N)", "bound": "hbm",
+            "history_exchange_bytes_per_frame_rank0": round(HIST_BYTES[0] / args.steps, 1),
+            # achieved / frac follow the contract: ALGORITHMIC bytes per launch / measured launch time.  For the
+            # chained kernel that is the bytes of the iterations it REPLACES, so frac says how much faster than "those
+            # passes at HBM peak" it runs and can exceed what a kernel moving them could reach; frac_required prices
+            # the bytes this kernel itself must move, frac_traffic the fabric bytes the PMC counters saw (per launch,
+            # profiles/traffic.json: a committed measurement of the commit named in traffic_source, not of this run).
+            "roofline": {"kernel": rk + (f" ({CHAIN_LEVELS} a-trous iterations k < N per launch, intermediates in LDS)"
+                                        if rk == "k_atrous_chain" else " (one a-trous iteration, k < N)"),
+                         "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "avg_launch_us": at.get("avg_us"), "algorithmic_bytes": at.get("algorithmic_bytes"),
-                         "traffic": traffic},
+                         "required_bytes": at.get("required_bytes"),
+                         "frac_required": round(at["required_bytes"] / (at["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                         if at.get("required_bytes") and at.get("avg_us") else None,
+                         "traffic": traffic,
+                         "frac_traffic": round(traffic / (at["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                         if traffic and at.get("avg_us") else None,
+                         "traffic_source": traffic_source},
             "kernels": kr,
         }
         pt = kr.get("k_pathtrace")
@@ -338,8 +384,10 @@ def main():
         kr2 = kernel_report(k2, WORKLOADS["1080p"], p2, tf2)
         result.setdefault("also", {})["cornell-1080p-1spp-4seg-5atrous"] = {
             "value": round(r2 / e2 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
-            "atrous_GBps": kr2.get("k_atrous", {}).get("algorithmic_GBps"),
-            "atrous_frac": round(kr2.get("k_atrous", {}).get("algorithmic_GBps", 0) / HBM_PEAK_GBS, 4)}
+            "kernels": kr2,
+            "atrous_kernel": "k_atrous_chain" if "k_atrous_chain" in kr2 else "k_atrous",
+            "atrous_GBps": (kr2.get("k_atrous_chain") or kr2.get("k_atrous", {})).get("algorithmic_GBps"),
+            "atrous_frac": round((kr2.get("k_atrous_chain") or kr2.get("k_atrous", {})).get("algorithmic_GBps", 0) / HBM_PEAK_GBS, 4)}
         e4, r4, _, _, _ = run_gpu(WORKLOADS["1080p"], args, 0, 1, args.steps, args.warmup, torch, None, collect_kernels=False,
                                   in_flight=2)
         result["also"]["cornell-1080p-1spp-4seg-5atrous"]["two_frames_in_flight"] = {

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 from . import abi
-from .strips import StripPlan, exchange_halo
+from .strips import StripPlan, exchange_halo, exchange_history, reprojection_rows
 
 FOV = 0.20                 # common.h:16
 SPEED = np.float32(0.1)    # main.cpp:68
@@ -109,10 +109,12 @@ class HipBackend:
             self._hist_full = torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=dev)
         return self._hist_full
 
-    def use_external_history(self, on: bool):
+    def use_external_history(self, on: bool, rows=None):
+        """rows = (a, b): the frame rows of history_full() that hold the previous frame (default: all)"""
         if on:
             t = self.history_full()
-            self.ctx.set_external_history(t.data_ptr(), 0, self.height)
+            a, b = rows if rows is not None else (0, self.height)
+            self.ctx.set_external_history(t.data_ptr() + a * self.width * 16, a, b)
         else:
             self.ctx.set_external_history(None)
 
@@ -216,10 +218,10 @@ class PipelinedBackend:
     def history_full(self):
         return self.cur.history_full()
 
-    def use_external_history(self, on):
+    def use_external_history(self, on, rows=None):
         self._ext_by_app = bool(on)
         if on:
-            self.cur.use_external_history(True)
+            self.cur.use_external_history(True, rows)
         # off: temporal_filter installs the other backend's plane (frame > 0) — nothing to undo here
 
     def readback_rows(self, plane, y0, y1):
@@ -254,6 +256,8 @@ class PathTracingApplication:
         self.lightColor = np.array(lightColor, np.float32)             # main.cpp:72
         self.cameraMoved = False
         self.frameCount = 0
+        self.history_bytes_sent = 0   # bytes this rank sent for the last frame's history exchange
+        self.history_rows = None
         self.pushConstants = abi.PushConstants()
         self.ubo = abi.Ubo()
         self._upload_initial_ubo()
@@ -268,6 +272,17 @@ class PathTracingApplication:
     def buildAccelerationStructure(self, instance_xforms=None):
         """main.cpp:687-742 — one BLAS, identity instance unless transforms are given."""
         self.backend.scene_upload(self.objVertices, self.objIndices, instance_xforms)
+        # world-space bounds of the scene (strips bound the reprojection reach with them, strips.reprojection_rows)
+        v = np.asarray(self.objVertices, np.float64).reshape(-1, 3)
+        v = v[np.unique(np.asarray(self.objIndices).ravel())]
+        if instance_xforms is None:
+            self.sceneBounds = (v.min(0), v.max(0))
+        else:
+            m = np.asarray(instance_xforms, np.float64).reshape(-1, 3, 4)
+            c = np.array([[x, y, z] for x in (v[:, 0].min(), v[:, 0].max()) for y in (v[:, 1].min(), v[:, 1].max())
+                          for z in (v[:, 2].min(), v[:, 2].max())])
+            w = np.einsum("nij,kj->nki", m[:, :, :3], c) + m[:, None, :, 3]
+            self.sceneBounds = (w.reshape(-1, 3).min(0), w.reshape(-1, 3).max(0))
 
     def _perspective(self):
         proj = abi.perspective(np.float32(FOV) * 2, np.float32(self.render_width) / np.float32(self.render_height),
@@ -375,22 +390,24 @@ class PathTracingApplication:
 
     def _prepare_history(self):
         """With several ranks the final pass may fetch history at a reprojected pixel of another strip
-        (temporalFiltering.comp.glsl:253).  While the camera rests the reprojection is the identity and
-        the strip-local PREVIOUS plane is enough; in a frame where view/proj differ from viewPrev/projPrev
-        every rank's finished strip of the previous frame (still in PREVIOUS) is all-gathered first."""
+        (temporalFiltering.comp.glsl:253).  While the camera rests the reprojection is the identity and the
+        strip-local PREVIOUS plane is enough.  In a frame where view/proj differ from viewPrev/projPrev every rank
+        bounds the previous-frame rows its own pixels can reach (strips.reprojection_rows: camera matrices + scene
+        bounds, the same on every rank) and the ranks swap exactly those bands of their finished strips — k*W*16 B
+        messages to the neighbours the band overlaps instead of the whole previous frame to everybody."""
         be = self.backend
         if self.frameCount == 0 or self._camera_static():
             be.use_external_history(False)
+            self.history_bytes_sent = 0
             return
-        import torch.distributed as dist
-        full = be.history_full()
         H, R = self.plan.height, self.plan.world
-        o0, o1 = self.plan.own
-        full[o0:o1].copy_(be.color_rows(abi.PLANE_PREVIOUS, o0, o1))
-        for r in range(R):  # strips may differ by a row (H % R), so one broadcast per owner instead of all_gather
-            a, b = StripPlan.bounds(H, R, r)
-            dist.broadcast(full[a:b], src=r, group=self.group)
-        be.use_external_history(True)
+        needs = [reprojection_rows(self.ubo, self.render_width, H, StripPlan.bounds(H, R, r), self.sceneBounds, self.z_near)
+                 for r in range(R)]
+        full = be.history_full()
+        self.history_bytes_sent = exchange_history(self.plan, needs, lambda a, b: be.color_rows(abi.PLANE_PREVIOUS, a, b),
+                                                   full, self.group)
+        self.history_rows = needs[self.plan.rank]
+        be.use_external_history(True, needs[self.plan.rank])
 
     def drawScene(self, keys=()):
         """main.cpp:1090-1113."""

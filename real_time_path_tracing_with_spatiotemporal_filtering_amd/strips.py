@@ -140,3 +140,96 @@ def exchange_halo(plan: StripPlan, k: int, rows_view, group=None):
         ops.append(dist.P2POp(dist.irecv, rows_view(*recv_rows), peer, group))
     for req in dist.batch_isend_irecv(ops):
         req.wait()
+
+
+# ------------------------------------------------------------------------------------------
+# history under camera motion: which rows of the previous frame can a strip's final pass fetch?
+# ------------------------------------------------------------------------------------------
+def _mat(m16):
+    import numpy as np
+    return np.asarray(m16, np.float64).reshape(4, 4).T  # column-major float[16] -> row-major 4x4
+
+
+def reprojection_rows(ubo, width: int, height: int, rows, bounds, z_near: float = 0.1, pad: int = 2):
+    """Frame rows [a, b) of the PREVIOUS frame that the final pass of frame rows `rows` = (y0, y1) can fetch history
+    from (temporalFiltering.comp.glsl:213-239,:253), given the scene's world-space bounds ((min xyz), (max xyz)).
+
+    The G-buffer's world position of pixel (x, y) lies on that pixel's centre ray at a view depth z between the
+    nearest and the farthest corner of the bounds; its previous-frame pixel row is
+        ppy = ((P_prev V_prev M_prev M^-1 p).y / (...).w * 0.5 + 0.5) * H        (worldToPixel, :178-189)
+    which is a ratio of functions affine in x, in y and in z separately — monotone along each of the three axes — so
+    over the box [0, W-1] x [y0, y1-1] x [z_lo, z_hi] it takes its extremes at the 8 corners.  `pad` rows cover the
+    binary32 rounding of the device arithmetic (the kernel's value is within a small fraction of a pixel of this
+    float64 one).  A corner behind the previous camera makes the projection unbounded: the whole frame is returned.
+    Background pixels (id 0) fetch their own pixel (:215-217), so `rows` itself is always part of the result."""
+    import numpy as np
+    y0, y1 = rows
+    V, P = _mat(ubo.view), _mat(ubo.proj)
+    D = _mat(ubo.modelPrev) @ np.linalg.inv(_mat(ubo.model))
+    PVp = _mat(ubo.projPrev) @ _mat(ubo.viewPrev) @ D
+    R, t = V[:3, :3], V[:3, 3]
+    org = -R.T @ t
+    lo, hi = (np.asarray(b, np.float64) for b in bounds)
+    corners = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+    depth = -(corners @ R.T + t)[:, 2]
+    z_lo = max(float(z_near), float(depth.min()))
+    z_hi = max(z_lo, float(depth.max()))
+    a, b = min(y0, height - 1), max(y0, min(y1, height) - 1)
+    ppy = []
+    for x in (0, width - 1):
+        for y in (a, b):
+            nx = (2.0 * (x + 0.5) - width) / width
+            ny = (2.0 * (y + 0.5) - height) / height
+            d = R.T @ np.array([nx / P[0, 0], ny / P[1, 1], -1.0])
+            for z in (z_lo, z_hi):
+                clip = PVp @ np.append(org + z * d, 1.0)
+                if not clip[3] > 1e-6:
+                    return 0, height
+                ppy.append((clip[1] / clip[3] * 0.5 + 0.5) * height)
+    n0 = int(np.floor(min(ppy))) - pad
+    n1 = int(np.floor(max(ppy))) + 1 + pad
+    # background pixels fetch their own pixel: the strip's own rows always belong to the range (they are local anyway)
+    n0, n1 = min(n0, y0), max(n1, y1)
+    return max(0, min(n0, height)), max(0, min(n1, height))
+
+
+def history_exchange_plan(height: int, world: int, needs):
+    """needs[q] = (a, b): previous-frame rows rank q's final pass can fetch.  Returns, per rank r,
+    [(peer, 'send' | 'recv', (y0, y1))] — r sends the part of ITS OWN rows that peer needs, receives the part of the
+    peer's rows it needs itself.  Every rank computes the same table from the same camera matrices: no negotiation."""
+    table = [[] for _ in range(world)]
+    own = [StripPlan.bounds(height, world, r) for r in range(world)]
+    for r in range(world):
+        for q in range(world):
+            if q == r:
+                continue
+            s0, s1 = max(own[r][0], needs[q][0]), min(own[r][1], needs[q][1])
+            if s1 > s0:
+                table[r].append((q, "send", (s0, s1)))
+            g0, g1 = max(own[q][0], needs[r][0]), min(own[q][1], needs[r][1])
+            if g1 > g0:
+                table[r].append((q, "recv", (g0, g1)))
+    return table
+
+
+def exchange_history(plan: StripPlan, needs, prev_rows_view, full, group=None) -> int:
+    """Move the previous frame's rows between ranks so that `full` (a [H, W, 4] tensor on every rank) holds rows
+    needs[plan.rank] of it; `prev_rows_view(y0, y1)` views rows of this rank's finished strip.  Returns bytes sent."""
+    import torch.distributed as dist
+    r = plan.rank
+    o0, o1 = plan.own
+    a, b = max(o0, needs[r][0]), min(o1, needs[r][1])
+    if b > a:
+        full[a:b].copy_(prev_rows_view(a, b))
+    ops, sent = [], 0
+    for peer, what, (y0, y1) in history_exchange_plan(plan.height, plan.world, needs)[r]:
+        if what == "send":
+            t = prev_rows_view(y0, y1)
+            sent += t.numel() * t.element_size()
+            ops.append(dist.P2POp(dist.isend, t, peer, group))
+        else:
+            ops.append(dist.P2POp(dist.irecv, full[y0:y1], peer, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return sent

@@ -31,7 +31,7 @@ class Recorder:
     def end_frame(self):
         self.calls.append(("end_frame",))
 
-    def use_external_history(self, on):
+    def use_external_history(self, on, rows=None):
         self.calls.append(("ext_history", bool(on)))
 
 

@@ -101,6 +101,7 @@ class OracleBackend:
         self.width, self.height = width, height
         self._hist_full = None
         self._ext = False
+        self._ext_rows = None
 
     def scene_upload(self, xyz, idx, xforms=None):
         self.tris = self.O.flatten(xyz, idx, xforms)
@@ -132,7 +133,16 @@ class OracleBackend:
     def temporal_filter(self, pc, ubo, y0, y1):
         k, n = pc.waveletIteration, pc.maxWaveletIteration
         src, dst = (abi.PLANE_IMAGE, abi.PLANE_FILTERED) if k & 1 else (abi.PLANE_FILTERED, abi.PLANE_IMAGE)
-        hist = self._hist_full.numpy() if self._ext else self.color[self.role[abi.PLANE_PREVIOUS]]
+        hist = self.color[self.role[abi.PLANE_PREVIOUS]]
+        if self._ext:
+            hist = self._hist_full.numpy()
+            if self._ext_rows is not None:
+                # only the registered band is the previous frame; everything else is poison, so a fetch outside it
+                # (a band computed too small) shows up as NaNs in the output
+                a, b = self._ext_rows
+                band = np.full_like(hist, np.nan)
+                band[a:b] = hist[a:b]
+                hist = band
         out = self.O.atrous(self.cfg, self._opc(pc), self._oubo(ubo), self.color[self.role[src]], self.depth, self.vis,
                             self.lut, self.lut_prev, self.wp, hist, y0, y1, gradient=self.grad)
         self.color[self.role[dst]][y0:y1] = out[y0:y1]
@@ -152,8 +162,9 @@ class OracleBackend:
             self._hist_full = torch.zeros((self.height, self.width, 4), dtype=torch.float32)
         return self._hist_full
 
-    def use_external_history(self, on):
+    def use_external_history(self, on, rows=None):
         self._ext = bool(on)
+        self._ext_rows = rows if on else None
 
     def final_image(self):
         return self.color[self.role[abi.PLANE_PREVIOUS]]
@@ -163,6 +174,7 @@ class OracleBackend:
         import torch
         self._hist_full = torch.from_numpy(other.color[other.role[abi.PLANE_PREVIOUS]])
         self._ext = True
+        self._ext_rows = None
 
 
 W, H, SEG, N, FRAMES = 48, 40, 2, 5, 5
@@ -240,3 +252,57 @@ def test_two_frames_in_flight_equal_one(tmp_path, oracle, world, mode):
         got = np.concatenate([p[f"arr_{f}"] for p in parts], axis=0)
         assert got.tobytes() == ref[f"arr_{f}"].tobytes(), f"frame {f}"
     assert sum(int(p["rays"][0]) for p in parts) == int(ref["rays"][0])
+
+
+# ------------------------------------------------------------------------------ history bands under camera motion
+def test_history_exchange_plan_is_symmetric():
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import history_exchange_plan
+    H, R = 2160, 8
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        needs = []
+        for r in range(R):
+            o0, o1 = StripPlan.bounds(H, R, r)
+            a = max(0, o0 - int(rng.integers(0, 700)))
+            needs.append((a, min(H, max(a + 1, o1 + int(rng.integers(-100, 700))))))
+        table = history_exchange_plan(H, R, needs)
+        sends = {(r, q, rows) for r in range(R) for q, what, rows in table[r] if what == "send"}
+        recvs = {(q, r, rows) for r in range(R) for q, what, rows in table[r] if what == "recv"}
+        assert sends == recvs, "what r sends to q is exactly what q expects from r"
+        for r in range(R):   # own rows + received rows cover the need
+            got = np.zeros(H, bool)
+            o0, o1 = StripPlan.bounds(H, R, r)
+            got[o0:o1] = True
+            for q, what, (y0, y1) in table[r]:
+                if what == "recv":
+                    assert not got[y0:y1].any()
+                    got[y0:y1] = True
+            assert got[needs[r][0]:needs[r][1]].all()
+
+
+@pytest.mark.parametrize("size", [(96, 80), (160, 45)])
+def test_reprojection_rows_bound_the_oracle_prev_pixels(oracle, cornell, size):
+    """strips.reprojection_rows (float64, camera matrices + scene bounds) must contain every previous-frame row the
+    device arithmetic (here: the oracle's binary32 restatement, temporalFiltering.comp.glsl:213-239) produces for a
+    strip's pixels — whatever way the camera moved — and should not be much wider than what was actually fetched"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import reprojection_rows
+    w, h = size
+    xyz, idx, tris = cornell
+    bounds = (tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0))
+    moves = [None, (0, 0.1, 0), (0, -0.1, 0), (0.1, 0.1, 0), (0, 0, -0.1), (0, 0.3, 0.2), (0, -0.1, 0.1), (-0.2, 0.1, -0.3)]
+    ref = oracle.OracleApp(w, h, tris, max_segments=1, iterations=1)
+    slack = []
+    for mv in moves:
+        fo = ref.draw_scene(move_camera=mv)
+        ubo = abi.Ubo.from_buffer_copy(bytes(ref.ubo))
+        for R in (2, 3, 5):
+            for r in range(R):
+                o0, o1 = StripPlan.bounds(h, R, r)
+                a, b = reprojection_rows(ubo, w, h, (o0, o1), bounds)
+                assert 0 <= a <= b <= h
+                ppy = fo.prev_pixel[o0:o1, :, 1]
+                inside = (ppy >= 0) & (ppy < h)      # rows outside the frame fetch 0 (D2) on any rank count
+                assert (ppy[inside] >= a).all() and (ppy[inside] < b).all(), (mv, R, r, a, b, ppy[inside].min(), ppy[inside].max())
+                if inside.any():
+                    slack.append((b - a) - (int(ppy[inside].max()) - int(ppy[inside].min()) + 1))
+    assert np.median(slack) <= 0.25 * h, "the bound is conservative, not vacuous"
