@@ -13,7 +13,8 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "librtpt_hip.so")
+# RTPT_LIB_PATH: a differently-built library for compile-time A/B runs on the GPU box (never set in tests or bench lines)
+LIB_PATH = os.environ.get("RTPT_LIB_PATH") or os.path.join(PKG_DIR, "librtpt_hip.so")
 HEADER_PATH = os.path.join(REPO_DIR, "include", "rtpt.h")
 
 RTPT_OK, RTPT_E_INVALID, RTPT_E_NOMEM, RTPT_E_DEVICE, RTPT_E_NO_SCENE, RTPT_E_NO_GPU = 0, -1, -2, -3, -4, -5

@@ -14,11 +14,13 @@
 // E_l = sum_{j>l} s_j columns beyond the strip on either side (what the later levels' taps reach), the input is staged
 // E_0 + s_0 beyond it: for the pair (3,4) that is 128 computed and 134 staged columns per 120 stored — 1.07x / 1.12x
 // instead of the 9 (or 81) global taps per pixel of the separate passes.
-//   rows of level l at step t:  y = in_start + t*G + g - lag_l,   lag_0 = s_0 + G,  lag_l = lag_{l-1} + s_l + G
-//   ring of level l's input:    2*s_l + 2*G rows (what level l still reads + what its producer writes this step)
-// The input ring is filled by LDS-DMA issued at the top of a step for the rows the NEXT step consumes, so the loads
-// are in flight under a whole step of arithmetic; only the level-0 waves issue DMA and only the last level's waves
-// store to global memory, so `s_waitcnt vmcnt(0)` at the barrier never waits for a store.
+//   rows of level l at step t:  y = in_start + t*G + g - lag_l,   lag_0 = s_0 + P*G,  lag_l = lag_{l-1} + s_l + G
+//   ring of level l's input:    2*s_l + 2*G rows (what level l still reads + what its producer writes this step);
+//                               the staged input ring has (P-1)*G more
+// The input ring is filled by LDS-DMA issued at the top of a step for the rows consumed P steps later, so the loads
+// are in flight under P steps of arithmetic (the wait at the barrier is a counted vmcnt: only the rows issued a step
+// ago must have landed); only the level-0 waves issue DMA and only the last level's waves store to global memory, so
+// that wait never includes a store.
 // Frame borders follow the reference's clamp (:136): rows by clamping the tap row before the ring slot is formed
 // (scalar), columns by letting a lane that stands for a column outside the frame compute the clamped column's value
 // (one v_med3 per task), so every staged cell of every level holds exactly what the clamped fetch would return.
@@ -32,6 +34,11 @@ namespace {
 #define RTPT_CHAIN_G 2
 #endif
 constexpr int kChG = RTPT_CHAIN_G;  // rows per level per step
+#ifndef RTPT_CHAIN_P
+#define RTPT_CHAIN_P 2
+#endif
+constexpr int kChP = RTPT_CHAIN_P;  // steps between staging an input row and its first use: a step of arithmetic is
+                                    // ~0.8 us per workgroup, less than a loaded HBM round trip, so the DMA gets kChP of them
 constexpr int kChCols = 128;        // columns a level computes at most: two waves per row
 
 __device__ __forceinline__ int posmod(int n, int r) {
@@ -54,7 +61,8 @@ __global__ __launch_bounds__(128 * L * kChG) void k_atrous_chain(AtrousArgs a) {
   E[L - 1] = 0;
   for (int l = L - 2; l >= 0; l--) E[l] = E[l + 1] + s[l + 1];
   for (int l = 0; l < L; l++) R[l] = 2 * s[l] + 2 * G;  // ring l = input of level l
-  lag[0] = s[0] + G;
+  R[0] += (kChP - 1) * G;
+  lag[0] = s[0] + kChP * G;
   for (int l = 1; l < L; l++) lag[l] = lag[l - 1] + s[l] + G;
   const int bw = kChCols - 2 * E[0];
   const int in_stride = kChCols + 2 * s[0];  // staged input columns
@@ -152,7 +160,8 @@ __global__ __launch_bounds__(128 * L * kChG) void k_atrous_chain(AtrousArgs a) {
   const float h9 = 1.0f / 9.0f;  // :145
 #pragma unroll 1
   for (int t = 0; t < T; t++) {
-    // 1. stage the input rows of this step (consumed from the next step on)
+    // 1. stage the input rows of this step (consumed kChP steps from now)
+    bool issued = false;
     if (stager) {
       const int iy = in_start + t * G + srow;
       if (iy >= ilo && iy <= ihi) {
@@ -169,6 +178,7 @@ __global__ __launch_bounds__(128 * L * kChG) void k_atrous_chain(AtrousArgs a) {
           dma_b32(rvis, o16t >> 2, lds0 + ring_ids[0] + cellt * 4u);
         }
         __builtin_amdgcn_s_setprio(0);
+        issued = true;
       }
       slot_in += G;
       if (slot_in >= R[0]) slot_in -= R[0];
@@ -263,9 +273,16 @@ __global__ __launch_bounds__(128 * L * kChG) void k_atrous_chain(AtrousArgs a) {
     slot_d += G;
     if (slot_d >= Rd) slot_d -= Rd;
     // 3. staged rows landed, ring writes done; the barrier publishes both to the next step
-    if (stager)
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else
+    if (stager) {
+      // vector-memory operations return in issue order: allowing this step's DMAs (4 per row for the wave that also
+      // stages the tail columns, 2 otherwise) to stay in flight waits exactly for everything older
+      if (kChP < 2 || !issued)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else if (schunk == 0)
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    } else
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -279,7 +296,7 @@ size_t atrous_chain_lds(int k0, int levels, uint32_t n_tris) {
   size_t off = static_cast<size_t>((np * np * 4 + 15) & ~15);
   for (int l = 0; l < levels; l++) {
     const int s = k0 + l;
-    const size_t cells = static_cast<size_t>(2 * s + 2 * kChG) * (l == 0 ? kChCols + 2 * k0 : kChCols);
+    const size_t cells = static_cast<size_t>(2 * s + 2 * kChG + (l == 0 ? (kChP - 1) * kChG : 0)) * (l == 0 ? kChCols + 2 * k0 : kChCols);
     off += 20 * cells;
   }
   return off;

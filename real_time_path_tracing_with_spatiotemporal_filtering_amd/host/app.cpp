@@ -1,6 +1,7 @@
 // app.cpp — see app.hpp.  Every method cites the reference lines it stands for.
 #include "app.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -62,12 +63,63 @@ void PathTracingApplication::createBuffers() {
   check(rtpt_config_default(&cfg, opt_.width, opt_.height), "rtpt_config_default");
   cfg.max_segments = opt_.max_segments;
   cfg.flags = opt_.flags;
+  if (multi()) {
+    // one strip context per rank this process runs; all on one stream, which is also the stream the transport's
+    // messages are ordered on (RCCL point-to-point calls or device-to-device copies)
+    if (opt_.frames_in_flight != 1) throw std::runtime_error("strips run one frame in flight");
+    if (opt_.flags & 0x1F0u) throw std::runtime_error("the extension modes are not served on strips by this host");
+    const bool local = opt_.rank < 0;
+    if (!local && opt_.rank >= opt_.ranks) throw std::runtime_error("rank out of range");
+    int dev = opt_.device;
+    if (dev < 0 && !local) {
+      const int n = host_device_count();
+      dev = n > 0 ? opt_.rank % n : 0;
+    }
+    if (dev >= 0) host_set_device(dev);
+    cfg.device = dev;
+    stream_ = host_stream_create();
+    transport_ = local ? make_local_transport() : make_rccl_transport(opt_.ranks, opt_.rank, opt_.rccl_id_file);
+    for (int r = local ? 0 : opt_.rank; r < (local ? opt_.ranks : opt_.rank + 1); r++) {
+      RankState rs;
+      rs.plan.height = static_cast<int>(opt_.height);
+      rs.plan.world = opt_.ranks;
+      rs.plan.rank = r;
+      rs.plan.iterations = opt_.maxWaveletIteration;
+      rs.plan.exchange = opt_.exchange_halo;
+      const Rows st = rs.plan.stored(), own = rs.plan.own();
+      cfg.row_begin = static_cast<uint32_t>(st.first);
+      cfg.row_end = static_cast<uint32_t>(st.second);
+      check(rtpt_create(&cfg, &rs.ctx), "createBuffers");
+      check(rtpt_set_stream(rs.ctx, stream_), "rtpt_set_stream");
+      check(rtpt_set_count_rows(rs.ctx, static_cast<uint32_t>(own.first), static_cast<uint32_t>(own.second)), "rtpt_set_count_rows");
+      ranks_.push_back(rs);
+    }
+    ctx_ = last_ = ranks_[0].ctx;
+    return;
+  }
   if (opt_.frames_in_flight != 1 && opt_.frames_in_flight != 2) throw std::runtime_error("frames_in_flight must be 1 or 2");
   for (int i = 0; i < opt_.frames_in_flight; i++) check(rtpt_create(&cfg, &ctxs_[i]), "createBuffers");
   ctx_ = last_ = ctxs_[0];
 }
 
 void PathTracingApplication::buildAccelerationStructure() {
+  // world-space bounds of the scene: strips bound the reprojection reach with them (strips.hpp)
+  for (int a = 0; a < 3; a++) {
+    sceneMin_[a] = 1e30f;
+    sceneMax_[a] = -1e30f;
+  }
+  for (uint32_t i : objIndices)
+    for (int a = 0; a < 3; a++) {
+      sceneMin_[a] = std::min(sceneMin_[a], objVertices[3 * static_cast<size_t>(i) + a]);
+      sceneMax_[a] = std::max(sceneMax_[a], objVertices[3 * static_cast<size_t>(i) + a]);
+    }
+  if (multi()) {
+    for (auto& rs : ranks_)
+      check(rtpt_scene_upload(rs.ctx, objVertices.data(), static_cast<uint32_t>(objVertices.size() / 3), objIndices.data(),
+                              static_cast<uint32_t>(objIndices.size() / 3), nullptr, 0),
+            "buildAccelerationStructure");
+    return;
+  }
   for (int i = 0; i < opt_.frames_in_flight; i++)
     check(rtpt_scene_upload(ctxs_[i], objVertices.data(), static_cast<uint32_t>(objVertices.size() / 3), objIndices.data(),
                             static_cast<uint32_t>(objIndices.size() / 3), nullptr, 0),
@@ -118,19 +170,122 @@ void PathTracingApplication::updateScene(const std::string& keys) {
   }
 }
 
-void PathTracingApplication::drawVisbilityBuffer() { check(rtpt_gbuffer(ctx_, &ubo, 0, 0), "drawVisbilityBuffer"); }
+void PathTracingApplication::drawVisbilityBuffer() {
+  if (multi()) {
+    for (auto& rs : ranks_) {
+      const Rows r = rs.plan.gbuffer_rows();
+      check(rtpt_gbuffer(rs.ctx, &ubo, static_cast<uint32_t>(r.first), static_cast<uint32_t>(r.second)), "drawVisbilityBuffer");
+    }
+    return;
+  }
+  check(rtpt_gbuffer(ctx_, &ubo, 0, 0), "drawVisbilityBuffer");
+}
 
 void PathTracingApplication::computeTemporalGradient() {
+  if (multi()) {
+    for (auto& rs : ranks_) {
+      const Rows r = rs.plan.gradient_rows();
+      check(rtpt_temporal_gradient(rs.ctx, &pushConstants, static_cast<uint32_t>(r.first), static_cast<uint32_t>(r.second)),
+            "computeTemporalGradient");
+    }
+    return;
+  }
   check(rtpt_temporal_gradient(ctx_, &pushConstants, 0, 0), "computeTemporalGradient");
 }
 
 void PathTracingApplication::drawSceneToImage() {
   pushConstants.sample_batch = 0;  // NUM_SAMPLE_BATCHES = 1, main.cpp:1223,:1237
+  if (multi()) {
+    for (auto& rs : ranks_) {
+      const Rows r = rs.plan.raytrace_rows();
+      check(rtpt_raytrace(rs.ctx, &pushConstants, static_cast<uint32_t>(r.first), static_cast<uint32_t>(r.second)), "drawSceneToImage");
+    }
+    return;
+  }
   check(rtpt_raytrace(ctx_, &pushConstants, 0, 0), "drawSceneToImage");
+}
+
+bool PathTracingApplication::cameraStatic() const {
+  return std::memcmp(ubo.view, ubo.viewPrev, sizeof ubo.view) == 0 && std::memcmp(ubo.proj, ubo.projPrev, sizeof ubo.proj) == 0;
+}
+
+// exchange mode: before iteration k every rank sends its k boundary rows of the iteration's INPUT plane (rgbd cells, so
+// the depth travels with the colour) to each neighbour — the one real exchange step of the path
+void PathTracingApplication::exchangeHalo(int k) {
+  const rtpt_plane in_plane = (k & 1) ? RTPT_PLANE_IMAGE : RTPT_PLANE_FILTERED;
+  const size_t row_bytes = static_cast<size_t>(opt_.width) * 16;
+  transport_->begin(stream_);
+  for (auto& rs : ranks_) {
+    void* base = nullptr;
+    check(rtpt_plane_ptr(rs.ctx, in_plane, &base), "rtpt_plane_ptr");  // also launches what rtpt_temporal_filter recorded
+    const int row0 = rs.plan.stored().first;
+    auto rows_ptr = [&](int y) { return static_cast<char*>(base) + static_cast<size_t>(y - row0) * row_bytes; };
+    for (const auto& e : rs.plan.exchange_rows(k)) {
+      transport_->send(rs.plan.rank, rows_ptr(e.send.first), e.peer, static_cast<size_t>(e.send.second - e.send.first) * row_bytes);
+      transport_->recv(rs.plan.rank, rows_ptr(e.recv.first), e.peer, static_cast<size_t>(e.recv.second - e.recv.first) * row_bytes);
+    }
+  }
+  transport_->end();
+}
+
+// The final pass fetches previousFrameImage at the reprojected pixel (temporalFiltering.comp.glsl:253).  While the
+// camera rests that is the pixel itself and the strip-local PREVIOUS plane serves it.  When it moved, every rank bounds
+// the previous-frame rows its pixels can reach (reprojection_rows: the same numbers on every rank, no negotiation) and
+// the ranks swap exactly those bands of their finished strips.
+void PathTracingApplication::prepareHistory() {
+  if (frameCount == 0 || cameraStatic()) {
+    for (auto& rs : ranks_) check(rtpt_set_external_history(rs.ctx, nullptr, 0, 0), "rtpt_set_external_history");
+    return;
+  }
+  const int H = static_cast<int>(opt_.height);
+  const size_t row_bytes = static_cast<size_t>(opt_.width) * 16;
+  std::vector<Rows> needs;
+  for (int r = 0; r < opt_.ranks; r++)
+    needs.push_back(reprojection_rows(ubo, static_cast<int>(opt_.width), H, StripPlan::bounds(H, opt_.ranks, r), sceneMin_, sceneMax_, 0.1f));
+  const auto table = history_exchange_plan(H, opt_.ranks, needs);
+  transport_->begin(stream_);
+  for (auto& rs : ranks_) {
+    if (!rs.history) rs.history = host_device_alloc(static_cast<size_t>(H) * row_bytes);
+    void* prev = nullptr;
+    check(rtpt_plane_ptr(rs.ctx, RTPT_PLANE_PREVIOUS, &prev), "rtpt_plane_ptr");
+    const int row0 = rs.plan.stored().first;
+    auto prev_rows = [&](int y) { return static_cast<char*>(prev) + static_cast<size_t>(y - row0) * row_bytes; };
+    auto hist_rows = [&](int y) { return static_cast<char*>(rs.history) + static_cast<size_t>(y) * row_bytes; };
+    const Rows own = rs.plan.own(), need = needs[static_cast<size_t>(rs.plan.rank)];
+    const int a = std::max(own.first, need.first), b = std::min(own.second, need.second);
+    if (b > a) host_device_copy(hist_rows(a), prev_rows(a), static_cast<size_t>(b - a) * row_bytes, stream_);
+    for (const auto& op : table[static_cast<size_t>(rs.plan.rank)]) {
+      const size_t bytes = static_cast<size_t>(op.rows.second - op.rows.first) * row_bytes;
+      if (op.send)
+        transport_->send(rs.plan.rank, prev_rows(op.rows.first), op.peer, bytes);
+      else
+        transport_->recv(rs.plan.rank, hist_rows(op.rows.first), op.peer, bytes);
+    }
+  }
+  transport_->end();
+  for (auto& rs : ranks_) {
+    const Rows need = needs[static_cast<size_t>(rs.plan.rank)];
+    check(rtpt_set_external_history(rs.ctx, static_cast<char*>(rs.history) + static_cast<size_t>(need.first) * row_bytes,
+                                    static_cast<uint32_t>(need.first), static_cast<uint32_t>(need.second)),
+          "rtpt_set_external_history");
+  }
 }
 
 void PathTracingApplication::applyTemporalFiltering() {
   pushConstants.maxWaveletIteration = opt_.maxWaveletIteration;   // :1258
+  if (multi()) {
+    for (int k = 1; k <= opt_.maxWaveletIteration; k++) {         // :1259
+      pushConstants.waveletIteration = k;                         // :1260
+      if (opt_.exchange_halo) exchangeHalo(k);
+      if (k == opt_.maxWaveletIteration && (k & 1)) prepareHistory();
+      for (auto& rs : ranks_) {
+        const Rows r = rs.plan.filter_rows(k);
+        check(rtpt_temporal_filter(rs.ctx, &pushConstants, &ubo, static_cast<uint32_t>(r.first), static_cast<uint32_t>(r.second)),
+              "applyTemporalFiltering");
+      }
+    }
+    return;
+  }
   for (int k = 1; k <= opt_.maxWaveletIteration; k++) {           // :1259
     pushConstants.waveletIteration = k;                           // :1260
     if (opt_.frames_in_flight == 2 && k == opt_.maxWaveletIteration && (k & 1) && frameCount > 0) {
@@ -146,6 +301,10 @@ void PathTracingApplication::applyTemporalFiltering() {
 }
 
 void PathTracingApplication::copyImageToSwapChainsCurrentImage() {
+  if (multi()) {
+    for (auto& rs : ranks_) check(rtpt_end_frame(rs.ctx), "copyImageToSwapChainsCurrentImage");
+    return;
+  }
   check(rtpt_end_frame(ctx_), "copyImageToSwapChainsCurrentImage");  // history hand-over, :1364-1372
   last_ = ctx_;
   ctx_ = ctxs_[(frameCount + 1) % static_cast<uint32_t>(opt_.frames_in_flight)];
@@ -162,6 +321,20 @@ void PathTracingApplication::drawScene(const std::string& keys) {
 }
 
 void PathTracingApplication::freeRessources() {
+  for (auto& rs : ranks_) {
+    if (rs.ctx) rtpt_destroy(rs.ctx);
+    if (rs.history) host_device_free(rs.history);
+  }
+  if (!ranks_.empty()) {
+    ranks_.clear();
+    ctxs_[0] = ctxs_[1] = nullptr;
+    delete transport_;
+    transport_ = nullptr;
+    if (stream_) host_stream_destroy(stream_);
+    stream_ = nullptr;
+    ctx_ = last_ = nullptr;
+    return;
+  }
   for (auto& c : ctxs_) {
     if (c) rtpt_destroy(c);
     c = nullptr;
@@ -169,12 +342,30 @@ void PathTracingApplication::freeRessources() {
   ctx_ = last_ = nullptr;
 }
 
+uint64_t PathTracingApplication::bytesSent() const { return transport_ ? transport_->bytes_sent() : 0; }
+
 void PathTracingApplication::sync() {
+  if (multi()) {
+    for (auto& rs : ranks_) check(rtpt_sync(rs.ctx), "rtpt_sync");
+    return;
+  }
   for (int i = 0; i < opt_.frames_in_flight; i++) check(rtpt_sync(ctxs_[i]), "rtpt_sync");
 }
 
 std::vector<float> PathTracingApplication::readImage() {
   std::vector<float> img(static_cast<size_t>(opt_.width) * opt_.height * 4);
+  if (multi()) {
+    // the rows this process owns (all of them in local mode; one strip per process with RCCL, the rest stays 0)
+    const size_t row_floats = static_cast<size_t>(opt_.width) * 4;
+    for (auto& rs : ranks_) {
+      const Rows st = rs.plan.stored(), own = rs.plan.own();
+      std::vector<float> strip(static_cast<size_t>(st.second - st.first) * row_floats);
+      check(rtpt_readback(rs.ctx, RTPT_PLANE_PREVIOUS, strip.data(), strip.size() * sizeof(float)), "rtpt_readback");
+      std::memcpy(img.data() + static_cast<size_t>(own.first) * row_floats, strip.data() + static_cast<size_t>(own.first - st.first) * row_floats,
+                  static_cast<size_t>(own.second - own.first) * row_floats * sizeof(float));
+    }
+    return img;
+  }
   // after rtpt_end_frame IMAGE and PREVIOUS hold the same pixels (main.cpp:1364)
   check(rtpt_readback(last_, RTPT_PLANE_PREVIOUS, img.data(), img.size() * sizeof(float)), "rtpt_readback");
   return img;
@@ -182,6 +373,14 @@ std::vector<float> PathTracingApplication::readImage() {
 
 uint64_t PathTracingApplication::rayCount() {
   uint64_t total = 0;
+  if (multi()) {
+    for (auto& rs : ranks_) {
+      uint64_t n = 0;
+      check(rtpt_readback(rs.ctx, RTPT_PLANE_RAYCOUNT, &n, sizeof n), "rtpt_readback");
+      total += n;
+    }
+    return total;
+  }
   for (int i = 0; i < opt_.frames_in_flight; i++) {
     uint64_t n = 0;
     check(rtpt_readback(ctxs_[i], RTPT_PLANE_RAYCOUNT, &n, sizeof n), "rtpt_readback");

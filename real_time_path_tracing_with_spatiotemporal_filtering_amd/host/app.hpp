@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/rtpt.h"
+#include "strips.hpp"
 
 namespace rtpt_host {
 
@@ -20,6 +21,14 @@ struct Options {
   uint32_t flags = 0;
   int frames_in_flight = 1;             // 2: even/odd frames in two contexts on two streams (rtpt_stream_wait)
   std::string scene;                    // scenes/CornellBox-Original-Merged.obj (main.cpp:417)
+  // row strips across GPUs (new work, the reference is single-device)
+  int ranks = 1;                        // strips the frame is split into
+  int rank = -1;                        // >= 0: this process is that rank (one GPU per process, RCCL between them);
+                                        // -1 with ranks > 1: every strip is a context of THIS process on one GPU
+                                        // (rehearsal / tests: a message is a device-to-device copy)
+  bool exchange_halo = false;           // true: k rows per neighbour travel before iteration k; false: redundant rows
+  std::string rccl_id_file;             // rendezvous file for the ncclUniqueId (rank >= 0)
+  int device = -1;                      // HIP device of this process (-1: rank % device count, or the current device)
 };
 
 class PathTracingApplication {
@@ -50,6 +59,7 @@ class PathTracingApplication {
   // read-back helpers (the reference's only output is the swapchain image)
   std::vector<float> readImage();              // RGBA32F, width*height*4
   uint64_t rayCount();
+  uint64_t bytesSent() const;                  // strips: bytes this process sent (halo rows + history bands)
   void writePFM(const std::string& path);      // linear RGB, bottom-up rows as PFM prescribes
   void sync();
 
@@ -65,6 +75,20 @@ class PathTracingApplication {
   rtpt_ctx* ctxs_[2] = {nullptr, nullptr};
   rtpt_ctx* ctx_ = nullptr;
   rtpt_ctx* last_ = nullptr;
+  // strips: the ranks this process runs (all of them in local mode, one with RCCL), sharing stream_
+  struct RankState {
+    StripPlan plan;
+    rtpt_ctx* ctx = nullptr;
+    void* history = nullptr;  // full-frame device buffer the previous frame's bands are gathered into (lazily allocated)
+  };
+  std::vector<RankState> ranks_;
+  Transport* transport_ = nullptr;
+  void* stream_ = nullptr;
+  float sceneMin_[3] = {0, 0, 0}, sceneMax_[3] = {0, 0, 0};
+  bool multi() const { return opt_.ranks > 1; }
+  bool cameraStatic() const;
+  void exchangeHalo(int k);
+  void prepareHistory();
   std::vector<float> objVertices;              // main.cpp:255
   std::vector<uint32_t> objIndices;            // main.cpp:256
   float cameraOrigin[3] = {-0.001f, 1.0f, 6.0f};  // main.cpp:65

@@ -16,6 +16,9 @@ static void usage(const char* argv0) {
       "usage: %s [--width W] [--height H] [--frames N] [--segments S] [--iterations K]\n"
       "          [--scene file.obj] [--script \"keys0,keys1,...\"] [--dump out.pfm] [--exact-filter]\n"
       "          [--frames-in-flight 1|2]\n"
+      "          [--ranks R [--rank r --rccl-id-file F] [--halo redundant|exchange] [--device D]]\n"
+      "  --ranks R splits the frame into R row strips: with --rank r this process is rank r on its own GPU and talks RCCL\n"
+      "  (start R processes; rank 0 publishes the ncclUniqueId in F); without --rank all R strips run in this process\n"
       "          [--flags N   (RTPT_FLAG_* bits of include/rtpt.h, e.g. 0xF0 = all extension modes)]\n"
       "  keys per frame are the reference's GLFW keys: WASDQE move the camera, IJKLUO the light\n"
       "  defaults are the reference's constants: 1000x800, 32 segments, 9 iterations (main.cpp:52-55)\n",
@@ -48,6 +51,11 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--dump")) dump = need("--dump");
     else if (!std::strcmp(argv[i], "--exact-filter")) opt.flags |= RTPT_FLAG_EXACT_FILTER;
     else if (!std::strcmp(argv[i], "--frames-in-flight")) opt.frames_in_flight = std::atoi(need("--frames-in-flight"));
+    else if (!std::strcmp(argv[i], "--ranks")) opt.ranks = std::atoi(need("--ranks"));
+    else if (!std::strcmp(argv[i], "--rank")) opt.rank = std::atoi(need("--rank"));
+    else if (!std::strcmp(argv[i], "--halo")) opt.exchange_halo = !std::strcmp(need("--halo"), "exchange");
+    else if (!std::strcmp(argv[i], "--rccl-id-file")) opt.rccl_id_file = need("--rccl-id-file");
+    else if (!std::strcmp(argv[i], "--device")) opt.device = std::atoi(need("--device"));
     else if (!std::strcmp(argv[i], "--flags") && i + 1 < argc) opt.flags |= static_cast<uint32_t>(std::strtoul(argv[++i], nullptr, 0));
     else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) { usage(argv[0]); return 0; }
     else { std::fprintf(stderr, "unknown option %s\n", argv[i]); usage(argv[0]); return 2; }
@@ -67,8 +75,10 @@ int main(int argc, char** argv) {
     app.sync();
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     uint64_t rays = app.rayCount();
-    std::printf("{\"frames\": %d, \"width\": %u, \"height\": %u, \"ms_per_frame\": %.4f, \"rays\": %llu, \"mray_per_s\": %.1f}\n", frames,
-                opt.width, opt.height, ms / frames, static_cast<unsigned long long>(rays), rays / (ms * 1e-3) / 1e6);
+    std::printf("{\"frames\": %d, \"width\": %u, \"height\": %u, \"ranks\": %d, \"rank\": %d, \"ms_per_frame\": %.4f, \"rays\": %llu, "
+                "\"mray_per_s\": %.1f, \"bytes_sent\": %llu}\n",
+                frames, opt.width, opt.height, opt.ranks, opt.rank, ms / frames, static_cast<unsigned long long>(rays),
+                rays / (ms * 1e-3) / 1e6, static_cast<unsigned long long>(app.bytesSent()));
     if (!dump.empty()) app.writePFM(dump);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "rtpt_app: %s\n", e.what());

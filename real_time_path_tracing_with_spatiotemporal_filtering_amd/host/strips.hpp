@@ -1,0 +1,91 @@
+// strips.hpp — row-strip sharding of one frame across ranks for the C++ host.  New work: the
+// reference is single-device (its only multi-device hook, useDeviceGroups, is dead: context.hpp:153,
+// context.cpp:406-412).  Same plan as the Python mirror (strips.py), which the CPU tests exercise with gloo ranks.
+//
+// Rank r of R owns frame rows [r*H/R, (r+1)*H/R).  K0/K1/K2 are per-pixel independent and the RNG seed depends only on
+// absolute (x, y, frame, batch) (raytrace.comp.glsl:297), so any partition reproduces the single-GPU image bit for
+// bit.  K3 iteration k reads rows y-k, y, y+k (temporalFiltering.comp.glsl:135) with a GLOBAL border clamp (:136):
+//   exchange   k rows per neighbour per iteration travel (the one real exchange step of the path)
+//   redundant  nothing travels: every rank traces and filters the sum_{j>k} j extra rows it will need
+// The final pass fetches history at the REPROJECTED pixel (:253), which under camera motion lies in other strips:
+// reprojection_rows() bounds the rows a strip can reach from the camera matrices and the scene bounds, and the ranks
+// swap exactly those bands of the previous frame.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/rtpt.h"
+
+namespace rtpt_host {
+
+using Rows = std::pair<int, int>;  // [first, second)
+
+struct StripPlan {
+  int height = 0, world = 1, rank = 0, iterations = 0;
+  bool exchange = false;  // halo mode: exchange | redundant
+
+  static Rows bounds(int height, int world, int rank) {
+    return {static_cast<int>(static_cast<int64_t>(rank) * height / world), static_cast<int>(static_cast<int64_t>(rank + 1) * height / world)};
+  }
+  Rows own() const { return bounds(height, world, rank); }
+  int reach(int k) const { return k; }  // temporalFiltering.comp.glsl:135 (the extension modes are not served here)
+  int halo() const;                     // rows stored beyond the owned strip on each side
+  Rows stored() const;
+  Rows grow(int rows) const;
+  Rows gbuffer_rows() const { return stored(); }
+  Rows gradient_rows() const { return own(); }
+  Rows raytrace_rows() const;
+  Rows filter_rows(int k) const;
+  struct Exchange {
+    int peer;
+    Rows send, recv;
+  };
+  // what travels before iteration k in exchange mode; throws std::runtime_error when a strip is shorter than k rows
+  std::vector<Exchange> exchange_rows(int k) const;
+};
+
+// previous-frame rows the final pass of frame rows `rows` can fetch history from; see strips.py:reprojection_rows for
+// the argument (extremes of a function monotone along x, y and view depth are at the 8 corners of the box)
+Rows reprojection_rows(const rtpt_ubo& ubo, int width, int height, Rows rows, const float bounds_min[3], const float bounds_max[3],
+                       float z_near, int pad = 2);
+
+struct HistoryOp {
+  int peer;
+  bool send;  // false: receive
+  Rows rows;
+};
+// per rank: what it sends of its own strip / receives of the peers' strips so that it holds needs[rank]
+std::vector<std::vector<HistoryOp>> history_exchange_plan(int height, int world, const std::vector<Rows>& needs);
+
+// ---- transports: how rows move between ranks -----------------------------------------------------------------------
+// One message = `bytes` bytes from a device pointer of rank `src` to a device pointer of rank `dst`.  All messages of
+// one exchange step are posted between begin() and end(); they are ordered on the stream passed to begin().
+class Transport {
+ public:
+  virtual ~Transport() = default;
+  virtual void begin(void* hip_stream) = 0;
+  virtual void send(int src_rank, const void* src, int dst_rank, size_t bytes) = 0;  // called by the process owning src_rank
+  virtual void recv(int dst_rank, void* dst, int src_rank, size_t bytes) = 0;        // called by the process owning dst_rank
+  virtual void end() = 0;
+  virtual uint64_t bytes_sent() const = 0;
+};
+
+// every rank lives in this process (strip contexts on one GPU, one shared stream): a message is a device-to-device copy
+Transport* make_local_transport();
+// one rank per process, one GPU per rank: ncclSend / ncclRecv in a group on the context's stream (RCCL over xGMI).
+// Rendezvous without MPI: rank 0 writes the ncclUniqueId to `id_file`, the others wait for it.
+Transport* make_rccl_transport(int world, int rank, const std::string& id_file);
+
+// HIP runtime calls the host needs besides the C ABI (kept out of app.cpp, which sees rtpt.h only)
+int host_device_count();
+void host_set_device(int dev);
+void* host_stream_create();
+void host_stream_destroy(void* stream);
+void* host_device_alloc(size_t bytes);
+void host_device_free(void* p);
+void host_device_copy(void* dst, const void* src, size_t bytes, void* stream);
+
+}  // namespace rtpt_host
