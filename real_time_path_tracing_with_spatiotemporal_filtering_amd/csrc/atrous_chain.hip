@@ -35,10 +35,11 @@ namespace {
 #endif
 constexpr int kChG = RTPT_CHAIN_G;  // rows per level per step
 #ifndef RTPT_CHAIN_P
-#define RTPT_CHAIN_P 2
+#define RTPT_CHAIN_P 1
 #endif
-constexpr int kChP = RTPT_CHAIN_P;  // steps between staging an input row and its first use: a step of arithmetic is
-                                    // ~0.8 us per workgroup, less than a loaded HBM round trip, so the DMA gets kChP of them
+constexpr int kChP = RTPT_CHAIN_P;  // steps between staging an input row and its first use.  Measured at 4K (pair launches
+                                    // averaged): 1: 100.7 us, 2: 103.6, 3: 104.1 — with two workgroups per CU the other one's
+                                    // arithmetic already covers the DMA flight, and every extra step costs G ring rows of LDS
 constexpr int kChCols = 128;        // columns a level computes at most: two waves per row
 
 __device__ __forceinline__ int posmod(int n, int r) {

@@ -14,6 +14,7 @@ SCENE = os.path.join(ROOT, "real_time_path_tracing_with_spatiotemporal_filtering
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "default_policy: test_chain_gpu.py — run with the shipped kernel-selection thresholds")
 
 
 @pytest.fixture(scope="session")
