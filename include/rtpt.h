@@ -234,11 +234,27 @@ int rtpt_stream_wait(rtpt_ctx* ctx, rtpt_ctx* other);
 int rtpt_scene_upload(rtpt_ctx* ctx, const float* xyz, uint32_t n_verts, const uint32_t* idx,
                       uint32_t n_tris, const float* instance_xforms, uint32_t n_instances);
 
+/* Per-triangle materials (SURVEY.md 8(f) rank 4 — NOT reference behaviour: the reference keys its colours on the
+ * normal, raytrace.comp.glsl:155-163, and ships no material library).  tri_material[t] indexes `materials` for
+ * triangle t of the mesh given to rtpt_scene_upload (instances share them).  A hit then takes Kd as its albedo
+ * instead of the normal-keyed colour (:244), and a surface with Ke != 0 ends the path like the analytic light does
+ * (:226-234): throughput *= Ke.  NULL / 0 returns to the reference's colours; rtpt_scene_upload drops them. */
+typedef struct rtpt_material {
+  float albedo[3];   /* .mtl Kd */
+  float emission[3]; /* .mtl Ke */
+} rtpt_material;
+int rtpt_scene_set_materials(rtpt_ctx* ctx, const uint32_t* tri_material, uint32_t n_tris, const rtpt_material* materials,
+                             uint32_t n_materials);
+
 /* ---- per-frame passes, one call per reference dispatch ----------------------------------- */
 
 /* drawVisbilityBuffer (main.cpp:1187-1199; visibility.{vert,geom,frag}.glsl): id, world
  * position, NDC depth planes + LUT for all triangles.  Rows [y0,y1) of the frame (clamped to
- * the stored rows); y0=y1=0 means all stored rows. */
+ * the stored rows); y0=y1=0 means all stored rows.
+ * ubo->model poses the scene (visibility.vert.glsl:24; recomputed per frame at main.cpp:1469, the identity there):
+ * when it differs from the last call's, every triangle is re-posed (model * v, the LUT's arithmetic), the BVH is
+ * refit and the tables are rebuilt before the pass runs, and rtpt_raytrace traces the posed scene too.  It must be
+ * affine and invertible.  LUT_PREV keeps the previous frame's pose, which is what K1 and the reprojection read. */
 int rtpt_gbuffer(rtpt_ctx* ctx, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1);
 /* computeTemporalGradient (main.cpp:1201-1220; temporalGradient.comp.glsl:104-172) */
 int rtpt_temporal_gradient(rtpt_ctx* ctx, const rtpt_push_constants* pc, uint32_t y0, uint32_t y1);
@@ -319,6 +335,12 @@ void rtpt_util_perspective(float fovy, float aspect, float z_near, float z_far, 
  * polygons fan-triangulated (0,1,2),(0,2,3) in file order (D5).  Two-call pattern: pass NULL
  * arrays to obtain counts. */
 int rtpt_util_load_obj(const char* path, float* xyz, uint32_t* n_verts, uint32_t* idx, uint32_t* n_tris);
+/* the material side of the same file: `mtllib` (looked up next to the OBJ), `usemtl`, and Kd / Ke of every `newmtl`.
+ * tri_material lines up with rtpt_util_load_obj's triangles; material 0 is the default (Kd 0.7, Ke 0).  Two-call
+ * pattern (NULL arrays: counts; *n_materials in = capacity).  A missing library is not an error — the reference's own
+ * OBJ names one that does not exist (scenes/CornellBox-Original-Merged.obj:3) — *n_materials comes back 0. */
+int rtpt_util_load_obj_materials(const char* path, uint32_t* tri_material, uint32_t* n_tris, rtpt_material* materials,
+                                 uint32_t* n_materials);
 /* Host-only self check of the acceleration-structure builder that stands in for the driver's BLAS/TLAS build
  * (buildAccelerationStructure, main.cpp:687-742): builds the BVH over `n_tris` world-space triangles (9 floats
  * each), packs the device nodes and verifies the invariants the traversal relies on.  Needs no GPU.
@@ -326,6 +348,9 @@ int rtpt_util_load_obj(const char* path, float* xyz, uint32_t* n_verts, uint32_t
  *   [4] triangles not referenced exactly once, [5] boxes that do not contain their subtree,
  *   [6] device (16-bit grid) boxes that do not contain the binary32 box, [7] dangling child references */
 int rtpt_util_bvh_check(const float* tris, uint32_t n_tris, uint64_t stats[8]);
+/* the same invariants after a REFIT: the tree is built over `built_for` and refit to `moved` (the same n_tris
+ * triangles after an animated model matrix, rtpt_gbuffer) — topology and leaf order kept, boxes recomputed */
+int rtpt_util_bvh_refit_check(const float* built_for, const float* moved, uint32_t n_tris, uint64_t stats[8]);
 
 #ifdef __cplusplus
 }

@@ -200,14 +200,28 @@ def temporal_gradient(cfg, pc: PushConstants, vis, worldpos, lut_, lut_prev, y0=
     return grad
 
 
-def raytrace(cfg, pc: PushConstants, tris, y0=0, y1=None, want_hit_id=True):
+def material_records(tri_material, materials) -> np.ndarray:
+    """n_base x 8 floats (Kd.rgb, 0, Ke.rgb, emissive flag) from per-triangle indices + (Kd, Ke) rows"""
+    mats = np.asarray(materials, np.float32).reshape(-1, 6)[np.asarray(tri_material, np.int64)]
+    rec = np.zeros((len(mats), 8), np.float32)
+    rec[:, 0:3] = mats[:, 0:3]
+    rec[:, 4:7] = mats[:, 3:6]
+    rec[:, 7] = (mats[:, 3:6] != 0).any(axis=1)
+    return rec
+
+
+def raytrace(cfg, pc: PushConstants, tris, y0=0, y1=None, want_hit_id=True, tri_mat=None):
+    """tri_mat: material_records(...) of the base mesh (extension), None = the reference's normal-keyed colours"""
     W, H = cfg.width, cfg.height
     y1 = H if y1 is None else y1
     img = np.zeros((H, W, 4), np.float32)
     rc = C.c_uint64(0)
     hid = np.zeros((H, W), np.uint32) if want_hit_id else None
-    lib().oracle_raytrace(C.byref(cfg), C.byref(pc), _p(tris), C.c_uint32(len(tris)),
-                          C.c_uint32(y0), C.c_uint32(y1), _p(img), C.byref(rc), _p(hid))
+    if tri_mat is not None:
+        tri_mat = np.ascontiguousarray(tri_mat, np.float32)
+    lib().oracle_raytrace_mat(C.byref(cfg), C.byref(pc), _p(tris), C.c_uint32(len(tris)), _p(tri_mat),
+                              C.c_uint32(0 if tri_mat is None else len(tri_mat)),
+                              C.c_uint32(y0), C.c_uint32(y1), _p(img), C.byref(rc), _p(hid))
     return img, int(rc.value), hid
 
 
@@ -274,12 +288,14 @@ class OracleApp:
 
     def __init__(self, width, height, tris, max_segments=32, iterations=9,
                  camera=(-0.001, 1.0, 6.0), light=(1.0, 1.0, -0.4), light_color=(0.5, 0.5, 0.5), z_near=0.1, z_far=10.0,
-                 ext_flags=0):
+                 ext_flags=0, tri_mat=None):
         self.cfg = config_default(width, height)
         self.cfg.max_segments = max_segments
         self.cfg.ext_flags = ext_flags
         self.iterations = iterations          # main.cpp:55
-        self.tris = np.ascontiguousarray(tris, np.float32)
+        self.tris = np.ascontiguousarray(tris, np.float32)   # as uploaded: the model matrix poses them per frame
+        self.model = np.eye(4, dtype=np.float32).T.ravel().copy()  # column-major, main.cpp:1469 (identity there)
+        self.tri_mat = tri_mat
         self.camera = np.array(camera, np.float32)   # main.cpp:65
         self.light = np.array(light, np.float32)     # main.cpp:70
         self.light_color = np.array(light_color, np.float32)  # main.cpp:72
@@ -310,7 +326,7 @@ class OracleApp:
         u.modelPrev[:] = u.model[:]
         u.viewPrev[:] = u.view[:]
         u.projPrev[:] = u.proj[:]
-        u.model[:] = np.eye(4, dtype=np.float32).ravel()
+        u.model[:] = self.model
         c = self.camera
         u.view[:] = look_at(c, (c[0], c[1], np.float32(c[2] - np.float32(6.0))), (0.0, 1.0, 0.0))
         proj = perspective(np.float32(0.20) * 2, np.float32(self.cfg.width) / np.float32(self.cfg.height), self.z_near, self.z_far)
@@ -341,10 +357,22 @@ class OracleApp:
         lut_ = lut(self.tris, model)
         if self.lut_prev is None:
             self.lut_prev = lut_.copy()  # D3
+        posed = self.tris
+        if not np.array_equal(model, np.eye(4, dtype=np.float32).ravel()):
+            # world triangle = model * uploaded triangle (visibility.vert.glsl:24): exactly the LUT's vertices
+            posed = np.ascontiguousarray(lut_[1:].reshape(-1, 3, 4)[:, :, :3].reshape(-1, 9))
+        tris_up, self.tris = self.tris, posed
+        try:
+            return self._draw_posed(lut_)
+        finally:
+            self.tris = tris_up
+
+    def _draw_posed(self, lut_) -> FrameOut:
+        cfg = self.cfg
         vis, wp, depth = gbuffer(cfg, self.tris, self.ubo)
         grad = temporal_gradient(cfg, self.pc, vis, wp, lut_, self.lut_prev)
         self.pc.sample_batch = 0  # main.cpp:1237
-        traced, rays, hid = raytrace(cfg, self.pc, self.tris)
+        traced, rays, hid = raytrace(cfg, self.pc, self.tris, tri_mat=self.tri_mat)
         self.pc.maxWaveletIteration = self.iterations  # main.cpp:1258
         cur = traced
         pp = None

@@ -419,6 +419,15 @@ static inline int ray_hits_light(vec3 o, vec3 d, vec3 center, float radius) {
 void oracle_raytrace(const oracle_config* cfg, const oracle_push_constants* pc, const float* tris,
                      uint32_t n, uint32_t y0, uint32_t y1, float* image, uint64_t* raycount,
                      uint32_t* hit_id) {
+  oracle_raytrace_mat(cfg, pc, tris, n, NULL, 0, y0, y1, image, raycount, hit_id);
+}
+
+/* materials (not reference behaviour): tri_mat = n_base x 8 floats (Kd.rgb, 0, Ke.rgb, emissive
+ * flag), triangle id reads record id % n_base (instances share the base mesh's materials); NULL = the reference's
+ * normal-keyed colours (raytrace.comp.glsl:155-163) */
+void oracle_raytrace_mat(const oracle_config* cfg, const oracle_push_constants* pc, const float* tris,
+                         uint32_t n, const float* tri_mat, uint32_t n_base, uint32_t y0, uint32_t y1, float* image,
+                         uint64_t* raycount, uint32_t* hit_id) {
   const int W = (int)cfg->width, H = (int)cfg->height;
   vec3 light_c = v3(pc->lightPos[0], pc->lightPos[1], pc->lightPos[2]); /* :279 */
   vec3 light_col = v3(pc->currentCameraColor[0] * cfg->light_intensity, pc->currentCameraColor[1] * cfg->light_intensity,
@@ -468,6 +477,14 @@ void oracle_raytrace(const oracle_config* cfg, const oracle_push_constants* pc, 
             if (nrm.x > 0.99f) alb = v3(1.f, 0.f, 0.f);        /* :155 dot(n,(1,0,0)) == n.x exactly */
             else if (-nrm.x > 0.99f) alb = v3(0.f, 1.f, 0.f);  /* :158 */
             else alb = v3(0.7f, 0.7f, 0.7f);                   /* :162 */
+            if (tri_mat) {
+              const float* m = tri_mat + 8 * (uint64_t)((id - 1) % n_base);
+              if (m[7] != 0.0f) { /* an emissive surface ends the path like the analytic light (:226-234) */
+                acc = v3_mul(acc, v3(m[4], m[5], m[6]));
+                break;
+              }
+              alb = v3(m[0], m[1], m[2]);
+            }
             acc = v3_mul(acc, alb);                            /* :244 */
             if (!(v3_dot(nrm, d) < 0.0f)) nrm = v3_neg(nrm);   /* :247 faceforward(N,I,Nref) */
             o = v3(dm_fma(cfg->ray_offset, nrm.x, pos.x), dm_fma(cfg->ray_offset, nrm.y, pos.y), dm_fma(cfg->ray_offset, nrm.z, pos.z)); /* :250 */

@@ -114,6 +114,9 @@ void oracle_temporal_gradient(const oracle_config* cfg, const oracle_push_consta
 void oracle_raytrace(const oracle_config* cfg, const oracle_push_constants* pc, const float* tris,
                      uint32_t n, uint32_t y0, uint32_t y1, float* image, uint64_t* raycount,
                      uint32_t* hit_id);
+void oracle_raytrace_mat(const oracle_config* cfg, const oracle_push_constants* pc, const float* tris,
+                         uint32_t n, const float* tri_mat, uint32_t n_base, uint32_t y0, uint32_t y1, float* image,
+                         uint64_t* raycount, uint32_t* hit_id);
 /* K3: temporalFiltering.comp.glsl:191-265, one iteration.  `in` is the colorImage snapshot (D1),
  * `out` receives the filtered colour (k < max) or the blend (k == max).  prev_pixel (nullable,
  * 2 ints per pixel) receives previousPixelPos when k == max. */

@@ -66,6 +66,11 @@ class Ubo(C.Structure):
     _fields_ = [(n, C.c_float * 16) for n in ("model", "view", "proj", "modelPrev", "viewPrev", "projPrev")]
 
 
+class Material(C.Structure):
+    """rtpt_material: .mtl Kd / Ke"""
+    _fields_ = [("albedo", C.c_float * 3), ("emission", C.c_float * 3)]
+
+
 class Config(C.Structure):
     """rtpt_config."""
     _fields_ = [
@@ -88,6 +93,7 @@ SYMBOLS = [
     "rtpt_raytrace", "rtpt_temporal_filter", "rtpt_end_frame", "rtpt_sync", "rtpt_readback", "rtpt_set_plane",
     "rtpt_reset_counters", "rtpt_set_count_rows", "rtpt_enable_debug", "rtpt_timing_enable", "rtpt_timing_collect", "rtpt_kernel_name",
     "rtpt_selftest_math", "rtpt_selftest_trace", "rtpt_util_look_at", "rtpt_util_perspective", "rtpt_util_load_obj", "rtpt_util_bvh_check",
+    "rtpt_scene_set_materials", "rtpt_util_load_obj_materials", "rtpt_util_bvh_refit_check",
 ]
 
 _lib = None
@@ -137,6 +143,9 @@ def load() -> C.CDLL:
         "rtpt_selftest_trace": [vp, vp, sz, vp, vp],
         "rtpt_util_load_obj": [C.c_char_p, vp, C.POINTER(u32), vp, C.POINTER(u32)],
         "rtpt_util_bvh_check": [vp, u32, C.POINTER(C.c_uint64 * 8)],
+        "rtpt_scene_set_materials": [vp, vp, u32, vp, u32],
+        "rtpt_util_bvh_refit_check": [vp, vp, u32, C.POINTER(C.c_uint64 * 8)],
+        "rtpt_util_load_obj_materials": [C.c_char_p, vp, C.POINTER(u32), vp, C.POINTER(u32)],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -187,6 +196,19 @@ def load_obj(path: str):
     idx = np.zeros((nt.value, 3), np.uint32)
     _check(load().rtpt_util_load_obj(path.encode(), _ptr(xyz), C.byref(nv), _ptr(idx), C.byref(nt)))
     return xyz, idx
+
+
+def load_obj_materials(path: str):
+    """(tri_material[t] u32, materials[m, 6] f32 = Kd, Ke) of an OBJ's `mtllib`/`usemtl`; (None, None) when the OBJ names
+    no readable library (the reference's Cornell box: its .mtl is missing upstream)"""
+    nt, nm = C.c_uint32(), C.c_uint32()
+    _check(load().rtpt_util_load_obj_materials(path.encode(), None, C.byref(nt), None, C.byref(nm)))
+    if nm.value == 0:
+        return None, None
+    tri = np.zeros(nt.value, np.uint32)
+    mats = np.zeros((nm.value, 6), np.float32)
+    _check(load().rtpt_util_load_obj_materials(path.encode(), _ptr(tri), C.byref(nt), _ptr(mats), C.byref(nm)))
+    return tri, mats
 
 
 _PLANE_DTYPE = {
@@ -274,6 +296,15 @@ class Context:
         _check(self._lib.rtpt_scene_upload(self._h, _ptr(xyz), len(xyz), _ptr(idx), len(idx), _ptr(xf), ni))
         self.n_tris = len(idx) * max(ni, 1)
 
+    def set_materials(self, tri_material: np.ndarray | None, materials: np.ndarray | None):
+        """per-triangle material indices + (Kd, Ke) rows; None returns to the reference's normal-keyed colours"""
+        if tri_material is None or materials is None:
+            _check(self._lib.rtpt_scene_set_materials(self._h, None, 0, None, 0))
+            return
+        tri = np.ascontiguousarray(tri_material, np.uint32)
+        mats = np.ascontiguousarray(materials, np.float32).reshape(-1, 6)
+        _check(self._lib.rtpt_scene_set_materials(self._h, _ptr(tri), len(tri), _ptr(mats), len(mats)))
+
     # -- passes
     def gbuffer(self, ubo: Ubo, y0=0, y1=0):
         _check(self._lib.rtpt_gbuffer(self._h, C.byref(ubo), y0, y1))
@@ -345,10 +376,16 @@ class Context:
         return ids, ts
 
 
-def bvh_check(tris: np.ndarray) -> dict:
-    """host-only self check of the BVH builder + device node packing (needs no GPU): see rtpt_util_bvh_check"""
+def bvh_check(tris: np.ndarray, built_for: np.ndarray | None = None) -> dict:
+    """host-only self check of the BVH builder + device node packing (needs no GPU): see rtpt_util_bvh_check;
+    with `built_for` the tree is built over those triangles and REFIT to `tris` (rtpt_util_bvh_refit_check)"""
     tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
     st = (C.c_uint64 * 8)()
-    _check(load().rtpt_util_bvh_check(_ptr(tris), len(tris), C.byref(st)))
+    if built_for is not None:
+        built_for = np.ascontiguousarray(built_for, np.float32).reshape(-1, 9)
+        assert built_for.shape == tris.shape
+        _check(load().rtpt_util_bvh_refit_check(_ptr(built_for), _ptr(tris), len(tris), C.byref(st)))
+    else:
+        _check(load().rtpt_util_bvh_check(_ptr(tris), len(tris), C.byref(st)))
     keys = ("nodes", "leaves", "max_depth", "largest_leaf", "bad_triangle_refs", "loose_boxes", "loose_device_boxes", "bad_child_refs")
     return dict(zip(keys, (int(v) for v in st)))

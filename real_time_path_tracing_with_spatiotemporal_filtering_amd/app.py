@@ -255,6 +255,9 @@ class PathTracingApplication:
         self.lightPos = np.array(lightPos, np.float32)                 # main.cpp:70
         self.lightColor = np.array(lightColor, np.float32)             # main.cpp:72
         self.cameraMoved = False
+        # ubo.model: the reference recomputes it every frame as the identity (main.cpp:1469); an animated scene sets
+        # modelMatrix (16 floats, column-major, affine) before drawScene — SURVEY 8(f) rank 4
+        self.modelMatrix = np.eye(4, dtype=np.float32).ravel()
         self.frameCount = 0
         self.history_bytes_sent = 0   # bytes this rank sent for the last frame's history exchange
         self.history_rows = None
@@ -314,7 +317,7 @@ class PathTracingApplication:
         u.modelPrev[:] = u.model[:]
         u.viewPrev[:] = u.view[:]
         u.projPrev[:] = u.proj[:]
-        u.model[:] = np.eye(4, dtype=np.float32).ravel()
+        u.model[:] = np.asarray(self.modelMatrix, np.float32).ravel()   # :1469
         c = self.cameraOrigin
         u.view[:] = abi.look_at(c, (c[0], c[1], np.float32(c[2] - np.float32(6.0))), (0.0, 1.0, 0.0))
         u.proj[:] = self._perspective()

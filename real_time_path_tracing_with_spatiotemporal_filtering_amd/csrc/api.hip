@@ -85,10 +85,18 @@ struct rtpt_ctx {
   rt::BvhGrid bvh_grid{};
   int bvh_depth = 0;
   std::vector<float> host_tris;  // flattened world-space triangles, kept for small scenes (screen bounds)
+  // animated model matrix (main.cpp:1469 recomputes ubo.model every frame; it is the identity there): the scene as
+  // uploaded (object space = instance transforms applied, model not), its BVH topology, and the model it is posed with
+  std::vector<float> obj_tris;
+  rt::Bvh bvh_host;
+  float model[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  uint64_t model_version = 0;          // bumped whenever the posed geometry changes
+  uint64_t lut_version[2] = {~0ull, ~0ull};  // model_version each LUT buffer was built for
+  Buf materials;                       // optional per-base-triangle (Kd, Ke) records, rtpt_scene_set_materials
+  uint32_t n_base_tris = 0;
 
   // frame state
   bool lut_prev_valid = false;   // D3
-  bool lut_holds_scene[2] = {false, false};  // buffer holds LUT(scene, model = identity): no need to rebuild it
   bool tables_valid = false;     // normal / id-pair tables match the scene
   bool final_swapped = false;    // the final filter pass already rotated IMAGE <-> FILTERED this frame
   bool image_alias = false;      // between rtpt_end_frame and the next rtpt_raytrace IMAGE reads as PREVIOUS
@@ -252,6 +260,8 @@ rt::SceneView scene_view(const rtpt_ctx* c) {
   s.n_tris = c->n_tris;
   s.use_bvh = c->use_bvh ? 1u : 0u;
   s.stack_depth = static_cast<uint32_t>(c->bvh_depth + 2 < 8 ? 8 : c->bvh_depth + 2);
+  s.materials = static_cast<const float4*>(c->materials.ptr);
+  s.n_base_tris = c->n_base_tris ? c->n_base_tris : 1u;
   return s;
 }
 
@@ -471,7 +481,7 @@ int rtpt_destroy(rtpt_ctx* c) {
   for (auto& b : c->variance) free_buf(b);
   for (auto& b : c->lut) free_buf(b);
   for (Buf* b : {&c->worldpos, &c->gradient, &c->depth, &c->prev_pixel, &c->hit_id, &c->raycount, &c->normal_tab, &c->pair_tab, &c->tris,
-                 &c->leaf_order, &c->isect_id, &c->isect_leaf, &c->shade, &c->nodes})
+                 &c->leaf_order, &c->isect_id, &c->isect_leaf, &c->shade, &c->nodes, &c->materials})
     free_buf(*b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -617,7 +627,7 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
           o[2] = v[2];
         }
       }
-  rt::Bvh bvh;
+  rt::Bvh& bvh = c->bvh_host;
   rt::build_bvh(tris.data(), total, bvh);
   if (bvh.max_depth >= rt::kBvhMaxDepth) return fail(RTPT_E_INVALID, "BVH deeper than the traversal stack");
   if (bvh.leaf_order.size() != total) return fail(RTPT_E_INVALID, "internal: BVH lost triangles");
@@ -651,16 +661,93 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   if ((rc = launch_check("scene_prepare"))) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));  // host staging vectors die at return
   c->n_tris = total;
+  c->n_base_tris = n_tris;
+  free_buf(c->materials);  // materials belong to the mesh that was replaced
   if (total <= static_cast<uint32_t>(rt::kCullMaxTris))
     c->host_tris = tris;
   else
     c->host_tris.clear();
+  c->obj_tris.swap(tris);
+  for (int i = 0; i < 16; i++) c->model[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  c->model_version++;
   c->use_bvh = (total > 64) || (c->cfg.flags & RTPT_FLAG_FORCE_BVH);
   c->bvh_depth = bvh.max_depth;
   c->lut_prev_valid = false;
-  c->lut_holds_scene[0] = c->lut_holds_scene[1] = false;
+  c->lut_version[0] = c->lut_version[1] = ~0ull;
   c->tables_valid = false;
   c->normals_y0 = c->normals_y1 = 0;  // the per-pixel normal plane belongs to the previous scene
+  return RTPT_OK;
+}
+
+// Pose the scene with a new model matrix (visibility.vert.glsl:24 `model * position`; the reference recomputes
+// ubo.model every frame, main.cpp:1469, as the identity): world triangle = model * uploaded triangle, in the same
+// fixed-order fma arithmetic the LUT uses (mat_row_point), the BVH keeps its topology and is REFIT to the moved
+// triangles, the device records are rebuilt.  Every pass — K0, K2, the LUT — sees the posed geometry.
+static int apply_model(rtpt_ctx* c, const float* model) {
+  const uint32_t total = c->n_tris;
+  std::vector<float> tris(static_cast<size_t>(total) * 9);
+  const bool ident = is_identity(model);
+  for (size_t v = 0; v < static_cast<size_t>(total) * 3; v++) {
+    const float* p = c->obj_tris.data() + 3 * v;
+    float* o = tris.data() + 3 * v;
+    if (ident) {
+      o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+    } else {
+      const rt::f3 q{p[0], p[1], p[2]};
+      o[0] = rt::exact::mat_row_point(model, 0, q);
+      o[1] = rt::exact::mat_row_point(model, 1, q);
+      o[2] = rt::exact::mat_row_point(model, 2, q);
+    }
+  }
+  rt::refit_bvh(tris.data(), total, c->bvh_host);
+  std::vector<rt::BvhNodeQ> nodes_h;
+  c->bvh_grid = rt::pack_quantised_nodes(c->bvh_host, nodes_h);
+  if (nodes_h.size() * sizeof(rt::BvhNodeQ) != c->nodes.bytes) return fail(RTPT_E_INVALID, "internal: refit changed the node count");
+  HIP_TRY(hipMemcpyAsync(c->tris.ptr, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->nodes.ptr, nodes_h.data(), nodes_h.size() * sizeof(rt::BvhNodeQ), hipMemcpyHostToDevice, c->stream));
+  rt::ScenePrepArgs sp;
+  sp.n_tris = total;
+  sp.tris = static_cast<const float*>(c->tris.ptr);
+  sp.leaf_order = static_cast<const uint32_t*>(c->leaf_order.ptr);
+  sp.isect_id = static_cast<float4*>(c->isect_id.ptr);
+  sp.isect_leaf = static_cast<float4*>(c->isect_leaf.ptr);
+  sp.shade = static_cast<float4*>(c->shade.ptr);
+  rt::launch_scene_prepare(sp, c->stream);
+  int rc = launch_check("scene_prepare");
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // host staging vectors die at return
+  if (total <= static_cast<uint32_t>(rt::kCullMaxTris)) c->host_tris.swap(tris);
+  std::memcpy(c->model, model, sizeof c->model);
+  c->model_version++;
+  c->tables_valid = false;  // per-id normals and pair weights follow the posed triangles
+  return RTPT_OK;
+}
+
+int rtpt_scene_set_materials(rtpt_ctx* c, const uint32_t* tri_material, uint32_t n_tris, const rtpt_material* materials,
+                             uint32_t n_materials) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  if (!c->n_tris) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");
+  HIP_TRY(hipSetDevice(c->device));
+  FLUSH_FILTER(c);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!tri_material || !materials || !n_materials) {  // back to the reference's normal-keyed colours
+    free_buf(c->materials);
+    return RTPT_OK;
+  }
+  if (n_tris != c->n_base_tris) return fail(RTPT_E_INVALID, "one material index per triangle of the uploaded mesh");
+  std::vector<float> rec(static_cast<size_t>(n_tris) * 8);
+  for (uint32_t t = 0; t < n_tris; t++) {
+    if (tri_material[t] >= n_materials) return fail(RTPT_E_INVALID, "material index out of range");
+    const rtpt_material& m = materials[tri_material[t]];
+    float* r = rec.data() + 8 * static_cast<size_t>(t);
+    r[0] = m.albedo[0]; r[1] = m.albedo[1]; r[2] = m.albedo[2]; r[3] = 0.0f;
+    r[4] = m.emission[0]; r[5] = m.emission[1]; r[6] = m.emission[2];
+    r[7] = (m.emission[0] != 0.0f || m.emission[1] != 0.0f || m.emission[2] != 0.0f) ? 1.0f : 0.0f;
+  }
+  int rc = alloc_buf(c->materials, rec.size() * sizeof(float));
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->materials.ptr, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return RTPT_OK;
 }
 
@@ -671,24 +758,35 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
   int rc = check_rows(c, y0, y1);
   if (rc) return rc;
   FLUSH_FILTER(c);
-  if (!is_identity(ubo->model))
-    return fail(RTPT_E_INVALID, "ubo.model must be identity (the reference's is, main.cpp:1469; animated models are out of scope)");
+  {
+    // an affine model only (last row 0 0 0 1): the posed vertex is the xyz of model * (v, 1), visibility.vert.glsl:24
+    const float* m = ubo->model;
+    if (!(m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f))
+      return fail(RTPT_E_INVALID, "ubo.model must be affine (bottom row 0 0 0 1)");
+    float det = m[0] * (m[5] * m[10] - m[9] * m[6]) - m[4] * (m[1] * m[10] - m[9] * m[2]) + m[8] * (m[1] * m[6] - m[5] * m[2]);
+    if (!(det != 0.0f) || det != det) return fail(RTPT_E_INVALID, "ubo.model is singular");
+  }
   HIP_TRY(hipSetDevice(c->device));
-  // The LUT is a function of (scene, model) and the model is the identity, so the geometry stage's
-  // per-frame rewrite (visibility.geom.glsl:57-59) produces the same bytes every frame: rebuild only
-  // a buffer that does not hold them yet (after rtpt_scene_upload / rtpt_set_plane).
-  if (!c->lut_holds_scene[c->lut_cur] || !c->tables_valid) {
+  if (std::memcmp(ubo->model, c->model, sizeof c->model) != 0) {
+    int rcm = apply_model(c, ubo->model);
+    if (rcm) return rcm;
+  }
+  // The LUT is a function of the posed scene: the geometry stage's per-frame rewrite (visibility.geom.glsl:57-59)
+  // produces the same bytes every frame while the model rests, so only a buffer that does not hold the current
+  // pose yet is rebuilt (after rtpt_scene_upload / a model change / rtpt_set_plane).  The device triangles are
+  // already posed, so the kernel's own model is the identity.
+  if (c->lut_version[c->lut_cur] != c->model_version || !c->tables_valid) {
     Timer tm(c, RTPT_K_LUT);
     rt::LutArgs la;
     la.n_tris = c->n_tris;
     la.shade = static_cast<const float4*>(c->shade.ptr);
-    std::memcpy(la.model, ubo->model, sizeof la.model);
+    for (int i = 0; i < 16; i++) la.model[i] = (i % 5 == 0) ? 1.0f : 0.0f;
     la.lut = static_cast<float4*>(c->lut[c->lut_cur].ptr);
     la.normal_tab = static_cast<float4*>(c->normal_tab.ptr);
     la.pair_tab = static_cast<float*>(c->pair_tab.ptr);
     la.sigma_n = c->cfg.sigma_n;
     rt::launch_lut(la, c->stream);
-    c->lut_holds_scene[c->lut_cur] = true;
+    c->lut_version[c->lut_cur] = c->model_version;
     c->tables_valid = true;
   }
   if ((rc = launch_check("lut"))) return rc;
@@ -697,7 +795,7 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
     HIP_TRY(hipMemcpyAsync(c->lut[c->lut_cur ^ 1].ptr, c->lut[c->lut_cur].ptr, c->lut[c->lut_cur].bytes, hipMemcpyDeviceToDevice,
                            c->stream));
     c->lut_prev_valid = true;
-    c->lut_holds_scene[c->lut_cur ^ 1] = true;
+    c->lut_version[c->lut_cur ^ 1] = c->model_version;
   }
   rt::GbufferArgs a;
   a.g = geom(c, y0, y1);
@@ -1177,9 +1275,9 @@ int rtpt_set_plane(rtpt_ctx* c, rtpt_plane which, const void* src, size_t bytes)
   }
   if (which == RTPT_PLANE_LUT_PREV) {
     c->lut_prev_valid = true;
-    c->lut_holds_scene[c->lut_cur ^ 1] = false;  // injected content: rebuild when it becomes current
+    c->lut_version[c->lut_cur ^ 1] = ~0ull;  // injected content: rebuild when it becomes current
   }
-  if (which == RTPT_PLANE_LUT) c->lut_holds_scene[c->lut_cur] = false;
+  if (which == RTPT_PLANE_LUT) c->lut_version[c->lut_cur] = ~0ull;
   if (which == RTPT_PLANE_VIS_ID) c->normals_y0 = c->normals_y1 = 0;  // the normal plane no longer matches the ids
   return RTPT_OK;
 }
@@ -1320,10 +1418,11 @@ void rtpt_util_perspective(float fovy, float aspect, float zn, float zf, float m
   m[14] = -(zf * zn) / (zf - zn);
 }
 
-int rtpt_util_bvh_check(const float* tris, uint32_t n, uint64_t stats[8]) {
+static int bvh_check_impl(const float* build_tris, const float* tris, uint32_t n, uint64_t stats[8]) {
   if (!tris || !stats || n == 0) return fail(RTPT_E_INVALID, "NULL argument / empty scene");
   rt::Bvh bvh;
-  rt::build_bvh(tris, n, bvh);
+  rt::build_bvh(build_tris ? build_tris : tris, n, bvh);
+  if (build_tris) rt::refit_bvh(tris, n, bvh);  // same topology, boxes recomputed for the moved triangles
   std::vector<rt::BvhNodeQ> q;
   const rt::BvhGrid g = rt::pack_quantised_nodes(bvh, q);
   for (int i = 0; i < 8; i++) stats[i] = 0;
@@ -1414,6 +1513,12 @@ int rtpt_util_bvh_check(const float* tris, uint32_t n, uint64_t stats[8]) {
   return RTPT_OK;
 }
 
+int rtpt_util_bvh_check(const float* tris, uint32_t n, uint64_t stats[8]) { return bvh_check_impl(nullptr, tris, n, stats); }
+int rtpt_util_bvh_refit_check(const float* built_for, const float* moved, uint32_t n, uint64_t stats[8]) {
+  if (!built_for) return fail(RTPT_E_INVALID, "NULL argument");
+  return bvh_check_impl(built_for, moved, n, stats);
+}
+
 int rtpt_util_load_obj(const char* path, float* xyz, uint32_t* n_verts, uint32_t* idx, uint32_t* n_tris) {
   if (!path || !n_verts || !n_tris) return fail(RTPT_E_INVALID, "NULL argument");
   FILE* fp = std::fopen(path, "r");
@@ -1467,6 +1572,101 @@ int rtpt_util_load_obj(const char* path, float* xyz, uint32_t* n_verts, uint32_t
   *n_verts = nv;
   *n_tris = nt;
   return rc;
+}
+
+
+// Materials of an OBJ (tinyobjloader hands main.cpp:416-428 the same information, which the
+// reference ignores — its colours are keyed on the normal, raytrace.comp.glsl:155-163, and the .mtl its OBJ names is
+// missing upstream).  `mtllib` files are looked up next to the OBJ; `usemtl` selects the material of the faces that
+// follow; a face fan-triangulates into poly - 2 triangles exactly like rtpt_util_load_obj (D5), so tri_material lines
+// up with its index array.  Material 0 is the default (Kd 0.7, the reference's grey; Ke 0) for faces without a usable
+// `usemtl`.  A missing library is not an error: *n_materials comes back 0 and the caller keeps the normal-keyed colours.
+int rtpt_util_load_obj_materials(const char* path, uint32_t* tri_material, uint32_t* n_tris, rtpt_material* materials,
+                                 uint32_t* n_materials) {
+  if (!path || !n_tris || !n_materials) return fail(RTPT_E_INVALID, "NULL argument");
+  FILE* fp = std::fopen(path, "r");
+  if (!fp) return fail(RTPT_E_INVALID, std::string("cannot open ") + path);
+  std::string dir(path);
+  const size_t slash = dir.find_last_of('/');
+  dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+  std::vector<std::string> names{"<default>"};
+  std::vector<rtpt_material> mats(1);
+  mats[0] = rtpt_material{{0.7f, 0.7f, 0.7f}, {0.f, 0.f, 0.f}};
+  bool any_library = false;
+  auto word = [](const char* q, std::string& out) {
+    while (*q == ' ' || *q == '\t') q++;
+    out.clear();
+    while (*q && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') out.push_back(*q++);
+  };
+  auto load_mtl = [&](const std::string& file) {
+    FILE* mf = std::fopen((dir + file).c_str(), "r");
+    if (!mf) return;
+    any_library = true;
+    char ln[1024];
+    int cur = -1;
+    while (std::fgets(ln, sizeof ln, mf)) {
+      const char* p = ln;
+      while (*p == ' ' || *p == '\t') p++;
+      if (!std::strncmp(p, "newmtl", 6) && (p[6] == ' ' || p[6] == '\t')) {
+        std::string nm;
+        word(p + 6, nm);
+        names.push_back(nm);
+        mats.push_back(rtpt_material{{0.7f, 0.7f, 0.7f}, {0.f, 0.f, 0.f}});
+        cur = static_cast<int>(mats.size()) - 1;
+      } else if (cur >= 0 && (p[0] == 'K') && (p[1] == 'd' || p[1] == 'e') && (p[2] == ' ' || p[2] == '\t')) {
+        float v[3];
+        if (std::sscanf(p + 2, "%f %f %f", &v[0], &v[1], &v[2]) == 3)
+          std::memcpy(p[1] == 'd' ? mats[static_cast<size_t>(cur)].albedo : mats[static_cast<size_t>(cur)].emission, v, sizeof v);
+      }
+    }
+    std::fclose(mf);
+  };
+  uint32_t nt = 0, cur_mat = 0;
+  char line[2048];
+  while (std::fgets(line, sizeof line, fp)) {
+    const char* p = line;
+    while (*p == ' ' || *p == '\t') p++;
+    if (!std::strncmp(p, "mtllib", 6) && (p[6] == ' ' || p[6] == '\t')) {
+      std::string file;
+      word(p + 6, file);
+      load_mtl(file);
+    } else if (!std::strncmp(p, "usemtl", 6) && (p[6] == ' ' || p[6] == '\t')) {
+      std::string nm;
+      word(p + 6, nm);
+      cur_mat = 0;
+      for (size_t i = 1; i < names.size(); i++)
+        if (names[i] == nm) cur_mat = static_cast<uint32_t>(i);
+    } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+      size_t corners = 0;
+      const char* q = p + 2;
+      while (*q) {
+        while (*q == ' ' || *q == '\t') q++;
+        if (*q == '\0' || *q == '\n' || *q == '\r') break;
+        char* end = nullptr;
+        (void)std::strtol(q, &end, 10);
+        if (end == q) break;
+        corners++;
+        q = end;
+        while (*q && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') q++;
+      }
+      for (size_t k = 1; k + 1 < corners; k++) {
+        if (tri_material) tri_material[nt] = cur_mat;
+        nt++;
+      }
+    }
+  }
+  std::fclose(fp);
+  *n_tris = nt;
+  if (!any_library) {
+    *n_materials = 0;
+    return RTPT_OK;
+  }
+  if (materials) {
+    if (*n_materials < mats.size()) return fail(RTPT_E_INVALID, "materials array too small");
+    std::memcpy(materials, mats.data(), mats.size() * sizeof(rtpt_material));
+  }
+  *n_materials = static_cast<uint32_t>(mats.size());
+  return RTPT_OK;
 }
 
 }  // extern "C"

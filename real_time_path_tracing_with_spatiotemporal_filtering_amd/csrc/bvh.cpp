@@ -249,6 +249,56 @@ void build_bvh(const float* tris, uint32_t n, Bvh& out, float pad_rel) {
 }
 
 
+void refit_bvh(const float* tris, uint32_t n, Bvh& bvh, float pad_rel) {
+  Box scene;
+  scene.reset();
+  for (uint32_t i = 0; i < n; i++)
+    for (int k = 0; k < 3; k++) scene.grow(tris + 9 * static_cast<size_t>(i) + 3 * k);
+  for (int a = 0; a < 3; a++) {
+    bvh.scene_min[a] = n ? scene.mn[a] : 0.f;
+    bvh.scene_max[a] = n ? scene.mx[a] : 0.f;
+  }
+  float diag = 0.f;
+  if (n) {
+    float dx = scene.mx[0] - scene.mn[0], dy = scene.mx[1] - scene.mn[1], dz = scene.mx[2] - scene.mn[2];
+    diag = std::sqrt(dx * dx + dy * dy + dz * dz);
+    float mag = 0.f;
+    for (int a = 0; a < 3; a++) mag = std::max(mag, std::max(std::fabs(scene.mn[a]), std::fabs(scene.mx[a])));
+    diag = std::max(diag, mag);
+  }
+  const float pad = pad_rel * diag;
+  // nodes are numbered in pre-order (a parent before its subtrees), so walking the array backwards meets every child
+  // before its parent; sub[i] = unpadded bounds of the subtree under node i
+  std::vector<Box> sub(bvh.nodes.size());
+  for (size_t ii = bvh.nodes.size(); ii-- > 0;) {
+    BvhNode& nd = bvh.nodes[ii];
+    Box me;
+    me.reset();
+    for (int side = 0; side < 2; side++) {
+      const uint32_t idx = side ? nd.ridx : nd.lidx, cnt = side ? nd.rcnt : nd.lcnt;
+      float* bmn = side ? nd.rmin : nd.lmin;
+      float* bmx = side ? nd.rmax : nd.lmax;
+      if (idx == kBvhEmpty) continue;
+      Box cb;
+      cb.reset();
+      if (cnt) {
+        for (uint32_t j = 0; j < cnt; j++) {
+          const uint32_t id = bvh.leaf_order[idx + j];
+          for (int k = 0; k < 3; k++) cb.grow(tris + 9 * static_cast<size_t>(id) + 3 * k);
+        }
+      } else {
+        cb = sub[idx];
+      }
+      for (int a = 0; a < 3; a++) {
+        bmn[a] = cb.mn[a] - pad;
+        bmx[a] = cb.mx[a] + pad;
+      }
+      me.grow(cb);
+    }
+    sub[ii] = me;
+  }
+}
+
 BvhGrid pack_quantised_nodes(const Bvh& bvh, std::vector<BvhNodeQ>& out) {
   double lo[3], hi[3];
   for (int a = 0; a < 3; a++) {

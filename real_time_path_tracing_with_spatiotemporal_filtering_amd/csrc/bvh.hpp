@@ -71,4 +71,9 @@ BvhGrid pack_quantised_nodes(const Bvh& bvh, std::vector<BvhNodeQ>& out);
 // would accept (closest hit = min over (t, id) must not depend on the structure, D4).
 void build_bvh(const float* tris, uint32_t n, Bvh& out, float pad_rel = 1e-5f);
 
+// Same topology and leaf order, new vertex positions (an animated `model` matrix, main.cpp:1469): recomputes every
+// child box bottom-up from the moved triangles, the scene bounds and the padding.  The tree stays valid for any motion;
+// its quality is that of the pose it was built for.
+void refit_bvh(const float* tris, uint32_t n, Bvh& bvh, float pad_rel = 1e-5f);
+
 }  // namespace rt

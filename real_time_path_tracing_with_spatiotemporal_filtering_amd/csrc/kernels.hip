@@ -478,6 +478,17 @@ __device__ __forceinline__ bool shade_segment(const PathtraceArgs& a, const HitR
   f3 pos = bary_point(xyz(s0), xyz(s1), xyz(s2), b0, b1, b2);      // :137
   f3 n{s0.w, s1.w, s2.w};                                          // :150 (precomputed per triangle)
   f3 alb = (n.x > 0.99f) ? f3{1.f, 0.f, 0.f} : ((-n.x > 0.99f) ? f3{0.f, 1.f, 0.f} : f3{0.7f, 0.7f, 0.7f});  // :155-163
+  if (a.scene.materials) {
+    // SURVEY 8(f) rank 4, not reference behaviour: a material library replaces the normal-keyed colours; a surface
+    // with emission ends the path like the analytic light does (:226-234), throughput *= Ke
+    const float4* m = a.scene.materials + 2 * static_cast<size_t>((h.id1 - 1) % a.scene.n_base_tris);
+    const float4 m0 = m[0], m1 = m[1];
+    if (m1.w != 0.0f) {
+      acc = acc * f3{m1.x, m1.y, m1.z};
+      return true;
+    }
+    alb = f3{m0.x, m0.y, m0.z};
+  }
   acc = acc * alb;                                                 // :244
   if (!(exact::dot(n, d) < 0.0f)) n = -n;                          // :247 faceforward
   o = f3{fmaf_(a.ray_offset, n.x, pos.x), fmaf_(a.ray_offset, n.y, pos.y), fmaf_(a.ray_offset, n.z, pos.z)};  // :250

@@ -22,6 +22,10 @@ struct SceneView {
   uint32_t n_tris;
   uint32_t use_bvh;  // 0: brute force over isect_id, 1: BVH traversal
   uint32_t stack_depth;  // BVH traversal stack entries per lane (tree depth + 2)
+  // optional per-triangle materials of the BASE mesh (.mtl Kd / Ke; instance i, triangle t reads record t):
+  //   m0 = (Kd.rgb, 0)  m1 = (Ke.rgb, 1 if emissive else 0).  NULL: the reference's normal-keyed colours
+  const float4* materials;
+  uint32_t n_base_tris;
 };
 
 // Screen-space bounds of every triangle of a small scene (<= 64), computed on the host per call and

@@ -56,6 +56,17 @@ void PathTracingApplication::loadMesh() {
   objVertices.resize(static_cast<size_t>(nv) * 3);
   objIndices.resize(static_cast<size_t>(nt) * 3);
   check(rtpt_util_load_obj(opt_.scene.c_str(), objVertices.data(), &nv, objIndices.data(), &nt), "loadMesh");
+  // the material side of the file (tinyobjloader returns it too, main.cpp:416-421; the reference ignores it and its
+  // OBJ's library is missing upstream): used when the OBJ names a readable .mtl, otherwise the normal-keyed colours stay
+  uint32_t nm = 0, ntm = 0;
+  check(rtpt_util_load_obj_materials(opt_.scene.c_str(), nullptr, &ntm, nullptr, &nm), "loadMesh");
+  objMaterials.clear();
+  triMaterial.clear();
+  if (nm > 0 && ntm == nt) {
+    objMaterials.resize(nm);
+    triMaterial.resize(ntm);
+    check(rtpt_util_load_obj_materials(opt_.scene.c_str(), triMaterial.data(), &ntm, objMaterials.data(), &nm), "loadMesh");
+  }
 }
 
 void PathTracingApplication::createBuffers() {
@@ -113,17 +124,27 @@ void PathTracingApplication::buildAccelerationStructure() {
       sceneMin_[a] = std::min(sceneMin_[a], objVertices[3 * static_cast<size_t>(i) + a]);
       sceneMax_[a] = std::max(sceneMax_[a], objVertices[3 * static_cast<size_t>(i) + a]);
     }
+  auto materials = [&](rtpt_ctx* ctx) {
+    if (!objMaterials.empty())
+      check(rtpt_scene_set_materials(ctx, triMaterial.data(), static_cast<uint32_t>(triMaterial.size()), objMaterials.data(),
+                                     static_cast<uint32_t>(objMaterials.size())),
+            "rtpt_scene_set_materials");
+  };
   if (multi()) {
-    for (auto& rs : ranks_)
+    for (auto& rs : ranks_) {
       check(rtpt_scene_upload(rs.ctx, objVertices.data(), static_cast<uint32_t>(objVertices.size() / 3), objIndices.data(),
                               static_cast<uint32_t>(objIndices.size() / 3), nullptr, 0),
             "buildAccelerationStructure");
+      materials(rs.ctx);
+    }
     return;
   }
-  for (int i = 0; i < opt_.frames_in_flight; i++)
+  for (int i = 0; i < opt_.frames_in_flight; i++) {
     check(rtpt_scene_upload(ctxs_[i], objVertices.data(), static_cast<uint32_t>(objVertices.size() / 3), objIndices.data(),
                             static_cast<uint32_t>(objIndices.size() / 3), nullptr, 0),
           "buildAccelerationStructure");
+    materials(ctxs_[i]);
+  }
 }
 
 void PathTracingApplication::initializeSceneConstants() {

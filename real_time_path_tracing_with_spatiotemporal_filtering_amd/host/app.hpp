@@ -91,6 +91,8 @@ class PathTracingApplication {
   void prepareHistory();
   std::vector<float> objVertices;              // main.cpp:255
   std::vector<uint32_t> objIndices;            // main.cpp:256
+  std::vector<rtpt_material> objMaterials;     // tinyobj's `materials` (main.cpp:419), used when the OBJ has a library
+  std::vector<uint32_t> triMaterial;           // material index per triangle
   float cameraOrigin[3] = {-0.001f, 1.0f, 6.0f};  // main.cpp:65
   float lightPos[3] = {1.0f, 1.0f, -0.4f};        // main.cpp:70
   float lightColor[3] = {0.5f, 0.5f, 0.5f};       // main.cpp:72

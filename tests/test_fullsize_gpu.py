@@ -79,7 +79,7 @@ def test_million_triangle_4k_frame_row_band_against_oracle(hip_lib, oracle, corn
                 cover = (vis[H4K // 2 - 200:H4K // 2 + 200] > 0).sum(axis=1)
                 ROW = H4K // 2 - 200 + int(np.argmax(cover))
                 B0, B1 = ROW - 5, ROW + 6
-                assert cover.max() > W4K // 2
+                assert cover.max() > W4K // 4
             ctx.set_count_rows(ROW, ROW + 1)
             ctx.reset_counters()
             app.drawSceneToImage()
@@ -91,7 +91,7 @@ def test_million_triangle_4k_frame_row_band_against_oracle(hip_lib, oracle, corn
             opc, oubo = _ostruct(oracle.PushConstants, app.pushConstants), _ostruct(oracle.Ubo, app.ubo)
             # ---- the traced row, brute force
             ovis, owp, odepth = oracle.gbuffer(ocfg, tris, oubo, ROW, ROW + 1)
-            assert np.array_equal(vis[ROW], ovis[ROW]) and vis[ROW].max() > 100_000
+            assert np.array_equal(vis[ROW], ovis[ROW]) and vis[ROW].max() > 100_000 and (vis[ROW] > 0).sum() > W4K // 4
             assert np.array_equal(bits(wp[ROW]), bits(owp[ROW]))
             assert np.array_equal(bits(depth[ROW]), bits(odepth[ROW]))
             oimg, orays, ohit = oracle.raytrace(ocfg, opc, tris, ROW, ROW + 1)
