@@ -100,6 +100,9 @@ typedef struct rtpt_visibility_data {
                                               handing the paths that survive 4 / 8 / 16 segments to follow-up launches
                                               through a queue (A/B switch; the image is the same) */
 
+#define RTPT_FLAG_NO_BINNED_PATHS 0x800u  /* path tracer, small scenes with separate objects: hand the paths from segment
+                                             to segment through the segment windows above instead of the queues binned by
+                                             which objects' bounds the next ray enters (A/B switch; the image is the same) */
 #define RTPT_FLAG_NO_FILTER_FUSION 0x400u /* K3: launch every rtpt_temporal_filter call at once, one kernel per
                                              iteration, instead of recording the frame's calls and chaining
                                              consecutive iterations into one launch (A/B switch; same pixels) */
@@ -341,6 +344,10 @@ int rtpt_util_load_obj(const char* path, float* xyz, uint32_t* n_verts, uint32_t
  * OBJ names one that does not exist (scenes/CornellBox-Original-Merged.obj:3) — *n_materials comes back 0. */
 int rtpt_util_load_obj_materials(const char* path, uint32_t* tri_material, uint32_t* n_tris, rtpt_material* materials,
                                  uint32_t* n_materials);
+/* Host-only view of the object clusters a small scene (<= 64 triangles, 9 floats each) is split into for the path
+ * tracer's class-binned hand-over (RTPT_FLAG_NO_BINNED_PATHS): masks[0] = triangles tested for every ray, masks[1..2] =
+ * the cull clusters, bounds = their padded min xyz / max xyz.  Returns the number of clusters (0..2) or a negative code. */
+int rtpt_util_clusters(const float* tris, uint32_t n_tris, uint64_t masks[3], float bounds[12]);
 /* Host-only self check of the acceleration-structure builder that stands in for the driver's BLAS/TLAS build
  * (buildAccelerationStructure, main.cpp:687-742): builds the BVH over `n_tris` world-space triangles (9 floats
  * each), packs the device nodes and verifies the invariants the traversal relies on.  Needs no GPU.

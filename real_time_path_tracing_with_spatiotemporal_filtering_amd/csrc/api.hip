@@ -92,6 +92,9 @@ struct rtpt_ctx {
   float model[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   uint64_t model_version = 0;          // bumped whenever the posed geometry changes
   uint64_t lut_version[2] = {~0ull, ~0ull};  // model_version each LUT buffer was built for
+  rt::ClusterInfo clusters{};          // small scenes: cull clusters of the class-binned path hand-over (kernels.hpp)
+  Buf bin_queue[2][2], bin_count;      // its record buffers [direction][buffer] and counters
+  uint32_t bin_region_cap = 0;
   Buf materials;                       // optional per-base-triangle (Kd, Ke) records, rtpt_scene_set_materials
   uint32_t n_base_tris = 0;
 
@@ -361,6 +364,9 @@ static int alloc_planes(rtpt_ctx* c) {
   if (rc == RTPT_OK) rc = alloc_buf(c->depth, px * 4);
   if (rc == RTPT_OK && !c->raycount.ptr) rc = alloc_buf(c->raycount, 8 * rt::kRayCounters);
   for (auto& b : c->path_queue) free_buf(b);  // sized per frame: re-created by the next rtpt_raytrace
+  for (auto& d : c->bin_queue)
+    for (auto& b : d) free_buf(b);
+  c->bin_region_cap = 0;
   free_buf(c->normals);  // sized per frame: re-created by the next rtpt_gbuffer
   c->normals_y0 = c->normals_y1 = 0;
   if (c->cfg.flags & RTPT_FLAG_EXT_VARIANCE) {
@@ -476,6 +482,9 @@ int rtpt_destroy(rtpt_ctx* c) {
   for (auto& b : c->vis) free_buf(b);
   free_buf(c->normals);
   free_buf(c->path_queue_count);
+  free_buf(c->bin_count);
+  for (auto& d : c->bin_queue)
+    for (auto& b : d) free_buf(b);
   for (auto& b : c->path_queue) free_buf(b);
   for (auto& b : c->moments) free_buf(b);
   for (auto& b : c->variance) free_buf(b);
@@ -597,6 +606,8 @@ int rtpt_enable_debug(rtpt_ctx* c, uint32_t mask) {
 }
 
 // ------------------------------------------------------------------------------------------ scene
+static void compute_clusters(rtpt_ctx* c);
+
 int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uint32_t* idx, uint32_t n_tris,
                       const float* xf, uint32_t n_instances) {
   if (!c || !xyz || !idx) return fail(RTPT_E_INVALID, "NULL argument");
@@ -671,12 +682,98 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   for (int i = 0; i < 16; i++) c->model[i] = (i % 5 == 0) ? 1.0f : 0.0f;
   c->model_version++;
   c->use_bvh = (total > 64) || (c->cfg.flags & RTPT_FLAG_FORCE_BVH);
+  compute_clusters(c);
+  c->use_bvh = (total > 64) || (c->cfg.flags & RTPT_FLAG_FORCE_BVH);
   c->bvh_depth = bvh.max_depth;
   c->lut_prev_valid = false;
   c->lut_version[0] = c->lut_version[1] = ~0ull;
   c->tables_valid = false;
   c->normals_y0 = c->normals_y1 = 0;  // the per-pixel normal plane belongs to the previous scene
   return RTPT_OK;
+}
+
+// Cull clusters of a small scene (kernels.hpp ClusterInfo): connected components of the posed triangle soup (two
+// triangles are connected when they share a vertex position), of which up to kMaxClusters become clusters — those that
+// save the most tests: triangles x (1 - bounds area / scene bounds area) — and everything else is always tested.  The
+// bounds are padded like the BVH's boxes so the slab test never rejects a ray the triangle routine would accept (D4).
+static rt::ClusterInfo find_clusters(const float* T, uint32_t n) {
+  rt::ClusterInfo ci{};
+  ci.n = 0;
+  if (n == 0 || n > static_cast<uint32_t>(rt::kCullMaxTris)) return ci;
+  std::vector<uint32_t> parent(n);
+  for (uint32_t i = 0; i < n; i++) parent[i] = i;
+  auto find = [&](uint32_t x) {
+    while (parent[x] != x) x = parent[x] = parent[parent[x]];
+    return x;
+  };
+  for (uint32_t i = 0; i < n; i++)
+    for (uint32_t j = i + 1; j < n; j++) {
+      bool touch = false;
+      for (int a = 0; a < 3 && !touch; a++)
+        for (int b = 0; b < 3 && !touch; b++) touch = std::memcmp(T + 9 * i + 3 * a, T + 9 * j + 3 * b, 3 * sizeof(float)) == 0;
+      if (touch) parent[find(i)] = find(j);
+    }
+  struct Comp {
+    unsigned long long mask = 0;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    int tris = 0;
+    double score = 0;
+  };
+  std::vector<Comp> comps;
+  std::vector<int> comp_of(n, -1);
+  float slo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, shi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t r = find(i);
+    if (comp_of[r] < 0) {
+      comp_of[r] = static_cast<int>(comps.size());
+      comps.emplace_back();
+    }
+    Comp& cp = comps[static_cast<size_t>(comp_of[r])];
+    cp.mask |= 1ull << i;
+    cp.tris++;
+    for (int v = 0; v < 3; v++)
+      for (int a = 0; a < 3; a++) {
+        const float x = T[9 * i + 3 * v + a];
+        cp.lo[a] = std::min(cp.lo[a], x); cp.hi[a] = std::max(cp.hi[a], x);
+        slo[a] = std::min(slo[a], x); shi[a] = std::max(shi[a], x);
+      }
+  }
+  auto area = [](const float* lo, const float* hi) {
+    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  };
+  const double scene_area = std::max(area(slo, shi), 1e-30);
+  for (auto& cp : comps) cp.score = cp.tris * (1.0 - std::min(1.0, area(cp.lo, cp.hi) / scene_area));
+  std::vector<size_t> order(comps.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return comps[x].score > comps[y].score || (comps[x].score == comps[y].score && x < y); });
+  float diag = 0.f, mag = 0.f;
+  for (int a = 0; a < 3; a++) {
+    diag += (shi[a] - slo[a]) * (shi[a] - slo[a]);
+    mag = std::max(mag, std::max(std::fabs(slo[a]), std::fabs(shi[a])));
+  }
+  const float pad = 1e-5f * std::max(std::sqrt(diag), mag);
+  unsigned long long used = 0;
+  for (size_t oi = 0; oi < order.size() && ci.n < rt::kMaxClusters; oi++) {
+    const Comp& cp = comps[order[oi]];
+    if (cp.score < 2.0) break;  // saves fewer than two triangle tests per ray: not worth a class bit
+    ci.mask[ci.n] = cp.mask;
+    for (int a = 0; a < 3; a++) {
+      ci.lo[ci.n][a] = cp.lo[a] - pad;
+      ci.hi[ci.n][a] = cp.hi[a] + pad;
+    }
+    used |= cp.mask;
+    ci.n++;
+  }
+  const unsigned long long all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+  ci.always = all & ~used;
+  return ci;
+}
+
+static void compute_clusters(rtpt_ctx* c) {
+  c->clusters = rt::ClusterInfo{};
+  if (c->host_tris.empty() || c->use_bvh) return;
+  c->clusters = find_clusters(c->host_tris.data(), c->n_tris);
 }
 
 // Pose the scene with a new model matrix (visibility.vert.glsl:24 `model * position`; the reference recomputes
@@ -717,6 +814,7 @@ static int apply_model(rtpt_ctx* c, const float* model) {
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));  // host staging vectors die at return
   if (total <= static_cast<uint32_t>(rt::kCullMaxTris)) c->host_tris.swap(tris);
+  compute_clusters(c);
   std::memcpy(c->model, model, sizeof c->model);
   c->model_version++;
   c->tables_valid = false;  // per-id normals and pair weights follow the posed triangles
@@ -929,6 +1027,43 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
     a.queue[1] = c->path_queue[1].ptr;
     a.queue_count = static_cast<uint32_t*>(c->path_queue_count.ptr);
     a.queue_region = static_cast<uint32_t>(region);
+  }
+  a.clusters = rt::ClusterInfo{};
+  a.bq[0][0] = a.bq[0][1] = a.bq[1][0] = a.bq[1][1] = nullptr;
+  a.bq_count = nullptr;
+  a.bq_out[0] = a.bq_out[1] = nullptr;
+  a.bq_in[0] = a.bq_in[1] = nullptr;
+  a.bq_out_count = nullptr;
+  a.bq_in_count = nullptr;
+  a.bq_region_cap = 0;
+  if (c->clusters.n > 0 && !c->use_bvh && a.compact && a.spp == 1 && a.max_segments >= 2 && a.max_segments <= rt::kBinnedMaxSegments &&
+      !(c->cfg.flags & (RTPT_FLAG_SINGLE_LAUNCH_PATHS | RTPT_FLAG_NO_BINNED_PATHS)) && c->cfg.width < 65536 && c->cfg.height < 65536) {
+    // class-binned hand-over (kernels.hpp): a region holds at most the survivors of the workgroups mapped to it —
+    // ceil(tiles / regions) tiles of 256 paths from the tile kernel; from a queue launch, (grid / regions) workgroups
+    // of at most ceil(chunks / grid) chunks each, chunks <= paths / 256 + one partial chunk per list
+    const size_t tiles = ((static_cast<size_t>(c->cfg.width) + 63) / 64) * ((c->rows() + 3) / 4);
+    const size_t grid = static_cast<size_t>(c->n_cu) * 8;
+    const size_t lists = rt::kBinRegions * rt::kPathClasses;
+    const size_t chunks = tiles + lists;
+    const size_t per_region = std::max((tiles + rt::kBinRegions - 1) / rt::kBinRegions,
+                                       ((grid + rt::kBinRegions - 1) / rt::kBinRegions) * ((chunks + grid - 1) / grid));
+    const uint32_t cap = static_cast<uint32_t>(per_region * 256);
+    if (c->bin_region_cap != cap) {
+      for (auto& d : c->bin_queue)
+        for (auto& b : d) free_buf(b);
+      c->bin_region_cap = 0;
+    }
+    if (!c->bin_count.ptr && (rc = alloc_buf(c->bin_count, 2 * lists * sizeof(uint32_t)))) return rc;
+    const int dirs = a.max_segments > 2 ? 2 : 1;
+    for (int d = 0; d < dirs; d++)
+      for (int b = 0; b < 2; b++)
+        if (!c->bin_queue[d][b].ptr && (rc = alloc_buf(c->bin_queue[d][b], static_cast<size_t>(cap) * rt::kBinRegions * 48))) return rc;
+    c->bin_region_cap = cap;
+    a.clusters = c->clusters;
+    for (int d = 0; d < 2; d++)
+      for (int b = 0; b < 2; b++) a.bq[d][b] = c->bin_queue[d][b].ptr;
+    a.bq_count = static_cast<uint32_t*>(c->bin_count.ptr);
+    a.bq_region_cap = cap;
   }
   a.cull = 0;
   if (!c->use_bvh && c->width_fits_i16()) {
@@ -1511,6 +1646,21 @@ static int bvh_check_impl(const float* build_tris, const float* tris, uint32_t n
     done[ni] = 1;
   }
   return RTPT_OK;
+}
+
+int rtpt_util_clusters(const float* tris, uint32_t n, uint64_t masks[3], float bounds[12]) {
+  if (!tris || !masks || !bounds) return fail(RTPT_E_INVALID, "NULL argument");
+  if (n == 0 || n > static_cast<uint32_t>(rt::kCullMaxTris)) return fail(RTPT_E_INVALID, "1..64 triangles");
+  const rt::ClusterInfo ci = find_clusters(tris, n);
+  masks[0] = ci.always;
+  for (int g = 0; g < rt::kMaxClusters; g++) {
+    masks[1 + g] = g < ci.n ? ci.mask[g] : 0;
+    for (int a = 0; a < 3; a++) {
+      bounds[6 * g + a] = g < ci.n ? ci.lo[g][a] : 0.f;
+      bounds[6 * g + 3 + a] = g < ci.n ? ci.hi[g][a] : 0.f;
+    }
+  }
+  return ci.n;
 }
 
 int rtpt_util_bvh_check(const float* tris, uint32_t n, uint64_t stats[8]) { return bvh_check_impl(nullptr, tris, n, stats); }

@@ -531,6 +531,68 @@ __device__ __forceinline__ void enqueue_paths(const PathtraceArgs& a, uint32_t r
   __syncthreads();  // wave_cnt / bcast may be reused right away
 }
 
+// ------------------------------------------------------------------------------------------
+// class-binned paths (ClusterInfo, kernels.hpp)
+// which cull clusters' bounds does the ray enter?  Conservative slab test: the bounds are padded like the BVH's boxes, a
+// direction component that is exactly 0 is clamped (inf - inf would drop the axis), NaN rays enter nothing (they cannot
+// hit, D7).
+__device__ __forceinline__ uint32_t ray_class(const ClusterInfo& ci, f3 o, f3 d, float tmax) {
+  auto nz = [](float v) { return __builtin_fabsf(v) < 1e-20f ? __builtin_copysignf(1e-20f, v) : v; };
+  const f3 rd{fast::rcp_(nz(d.x)), fast::rcp_(nz(d.y)), fast::rcp_(nz(d.z))};
+  uint32_t cls = 0;
+#pragma unroll
+  for (int g = 0; g < kMaxClusters; g++) {
+    if (g >= ci.n) break;
+    const float t0x = (ci.lo[g][0] - o.x) * rd.x, t1x = (ci.hi[g][0] - o.x) * rd.x;
+    const float t0y = (ci.lo[g][1] - o.y) * rd.y, t1y = (ci.hi[g][1] - o.y) * rd.y;
+    const float t0z = (ci.lo[g][2] - o.z) * rd.z, t1z = (ci.hi[g][2] - o.z) * rd.z;
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                     __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+                                     __builtin_fminf(__builtin_fmaxf(t0z, t1z), tmax));
+    // "not (tn > tf)": a NaN anywhere keeps the cluster (conservative); rays with NaN components are caught below
+    if (!(tn > tf)) cls |= 1u << g;
+  }
+  if (__builtin_isunordered(o.x, d.x) || __builtin_isunordered(o.y, d.y) || __builtin_isunordered(o.z, d.z)) cls = 0;
+  return cls;
+}
+
+// append the workgroup's surviving paths to the class-binned queues: one atomic per class present per workgroup, on the
+// counter of the workgroup's region
+__device__ __forceinline__ void enqueue_binned(const PathtraceArgs& a, uint32_t region, uint32_t (*wave_cnt)[kPathClasses], uint32_t* bases,
+                                               bool alive, uint32_t cls, int wave, uint32_t lane, uint32_t pixg, uint32_t rng, f3 o, f3 d,
+                                               f3 acc) {
+  unsigned long long mine = 0;
+#pragma unroll
+  for (uint32_t c = 0; c < kPathClasses; c++) {
+    const unsigned long long m = __ballot(alive && cls == c);
+    if (lane == 0) wave_cnt[wave][c] = static_cast<uint32_t>(__builtin_popcountll(m));
+    if (cls == c) mine = m;
+  }
+  __syncthreads();
+  const uint32_t tid = static_cast<uint32_t>(wave) * 64u + lane;
+  if (tid < kPathClasses) {
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < kPtRows; w++) total += wave_cnt[w][tid];
+    bases[tid] = total ? atomicAdd(a.bq_out_count + region * kPathClasses + tid, total) : 0u;
+  }
+  __syncthreads();
+  if (alive) {
+    uint32_t before = 0;
+    for (int w = 0; w < wave; w++) before += wave_cnt[w][cls];
+    const uint32_t off = bases[cls] + before +
+                         __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mine >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mine), 0u));
+    const size_t rbase = static_cast<size_t>(region) * a.bq_region_cap;
+    const size_t slot = (cls & 1u) ? rbase + a.bq_region_cap - 1u - off : rbase + off;  // odd classes grow down
+    float4* q = reinterpret_cast<float4*>(a.bq_out[cls >> 1]) + 3 * slot;
+    q[0] = make_float4(__uint_as_float(pixg), __uint_as_float(rng), o.x, o.y);
+    q[1] = make_float4(o.z, d.x, d.y, d.z);
+    q[2] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+  }
+  __syncthreads();  // wave_cnt / bases may be reused right away
+}
+
 // K2 tile kernel with optional per-segment compaction (PathtraceArgs::compact).
 //
 // A 256-thread block owns a 64x4 pixel tile and advances all of its paths one segment at a time
@@ -572,6 +634,8 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
   uint32_t* const rng_pix = reinterpret_cast<uint32_t*>(sum_b + kPtThreads);
   __shared__ uint32_t wave_cnt[kPtRows];
   __shared__ uint32_t q_base;
+  __shared__ uint32_t bin_cnt[kPtRows][kPathClasses];
+  __shared__ uint32_t bin_bases[kPathClasses];
   __shared__ unsigned int block_rays;
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
@@ -677,11 +741,15 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
       }
       __syncthreads();  // everybody has read its slot before the next compaction writes
     }
-    if (a.seg_end < a.max_segments) {  // only with spp == 1: the unfinished paths continue in k_pathtrace_queue
+    if (a.seg_end < a.max_segments) {  // only with spp == 1: the unfinished paths continue in a queue kernel
       const uint32_t pixg = (static_cast<uint32_t>(tile_y0 + static_cast<int>(pix >> 6)) << 16) |
                             static_cast<uint32_t>(tile_x0 + static_cast<int>(pix & 63u));
       const uint32_t blk = blockIdx.y * gridDim.x + blockIdx.x;
-      enqueue_paths(a, blk % kPathQueues, wave_cnt, &q_base, alive, wave, lane, pixg, rng, o, d, acc);
+      if (!BVH && a.bq_out_count) {
+        const uint32_t cls = alive ? ray_class(a.clusters, o, d, a.tmax) : 0u;
+        enqueue_binned(a, blk % kBinRegions, bin_cnt, bin_bases, alive, cls, wave, lane, pixg, rng, o, d, acc);
+      } else
+        enqueue_paths(a, blk % kPathQueues, wave_cnt, &q_base, alive, wave, lane, pixg, rng, o, d, acc);
     }
   }
   __syncthreads();
@@ -701,6 +769,91 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
   // the workgroups' slots occupied until acknowledged (a 1-segment launch took 397 us, of which the arithmetic is ~110)
   if (tid == 0 && block_rays)
     atomicAdd(a.raycount + ((blockIdx.y * gridDim.x + blockIdx.x) & (kRayCounters - 1u)), static_cast<unsigned long long>(block_rays));
+}
+
+// ------------------------------------------------------------------------------------------
+// class-binned paths: the queue kernel
+// One segment (a.seg_begin) of every queued path.  A workgroup takes 256-record chunks of ONE list = (region, class), so
+// all of its waves test the same triangle set: always | the class's clusters, in ascending id order (equal-t ties keep
+// the lower id, D4 — the triangles left out cannot be hit: the ray misses their cluster's padded bounds).  Survivors are
+// classified by their new ray and appended to the out queues; a path that ends writes its pixel.
+__global__ __launch_bounds__(kPtThreads) void k_pathtrace_binned(PathtraceArgs a) {
+  constexpr uint32_t kLists = kBinRegions * kPathClasses;
+  static_assert(kLists == kPtThreads, "one list per thread in the prefix scan");
+  __shared__ uint32_t prefix[kLists + 1];   // chunks before list l
+  __shared__ uint32_t counts[kLists];
+  __shared__ uint32_t wave_cnt[kPtRows][kPathClasses];
+  __shared__ uint32_t bases[kPathClasses];
+  __shared__ unsigned int block_rays;
+  const int tid = threadIdx.y * kBlockX + threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const uint32_t lane = threadIdx.x;
+  if (tid == 0) block_rays = 0;
+  {
+    const uint32_t cnt = a.bq_in_count[tid];
+    counts[tid] = cnt;
+    prefix[tid + 1] = (cnt + kPtThreads - 1) / kPtThreads;
+    if (tid == 0) prefix[0] = 0;
+    __syncthreads();
+    for (uint32_t step = 1; step < kLists; step <<= 1) {  // inclusive scan of prefix[1..kLists]
+      const uint32_t v = (static_cast<uint32_t>(tid) >= step) ? prefix[tid + 1 - step] : 0u;
+      __syncthreads();
+      prefix[tid + 1] += v;
+      __syncthreads();
+    }
+  }
+  const uint32_t total_chunks = prefix[kLists];
+  const f3 light_c = ld3(a.light_c);
+  const uint32_t seg = a.seg_begin;
+  const bool more = seg + 1 < a.max_segments;  // survivors are handed on (otherwise shade_segment ends every path)
+  unsigned int rays = 0;
+  for (uint32_t j = blockIdx.x; j < total_chunks; j += gridDim.x) {  // block-uniform
+    uint32_t lo = 0, hi = kLists;  // the list holding chunk j: the largest l with prefix[l] <= j
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (prefix[mid] <= j) lo = mid; else hi = mid;
+    }
+    const uint32_t list = __builtin_amdgcn_readfirstlane(lo);
+    const uint32_t region = list / kPathClasses, cls_in = list % kPathClasses;
+    const uint32_t off = (j - prefix[list]) * kPtThreads + static_cast<uint32_t>(tid);
+    bool alive = off < counts[list];
+    uint32_t pix = 0, rng = 0;
+    f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, -1.f}, acc{1.f, 1.f, 1.f};
+    if (alive) {
+      const size_t rbase = static_cast<size_t>(region) * a.bq_region_cap;
+      const size_t slot = (cls_in & 1u) ? rbase + a.bq_region_cap - 1u - off : rbase + off;
+      const float4* q = reinterpret_cast<const float4*>(a.bq_in[cls_in >> 1]) + 3 * slot;
+      const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+      pix = __float_as_uint(q0.x);
+      rng = __float_as_uint(q0.y);
+      o = f3{q0.z, q0.w, q1.x};
+      d = f3{q1.y, q1.z, q1.w};
+      acc = f3{q2.x, q2.y, q2.z};
+    }
+    unsigned long long set = a.clusters.always;
+#pragma unroll
+    for (int g = 0; g < kMaxClusters; g++)
+      if (cls_in & (1u << g)) set |= a.clusters.mask[g];
+    uint32_t cls_out = 0;
+    if (alive) {
+      HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
+      closest_hit_brute_set(a.scene, set, o, d, h);  // :208-222
+      const int x = static_cast<int>(pix & 0xFFFFu), y = static_cast<int>(pix >> 16);
+      if (y >= a.count_y0 && y < a.count_y1) rays++;
+      if (shade_segment(a, h, seg, light_c, o, d, acc, rng)) {
+        alive = false;
+        const size_t gi = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
+        a.image[gi] = make_float4(acc.x, acc.y, acc.z, a.depth[gi]);  // :328,:343 (+ depth in alpha)
+      } else {
+        cls_out = ray_class(a.clusters, o, d, a.tmax);
+      }
+    }
+    if (more) enqueue_binned(a, blockIdx.x % kBinRegions, wave_cnt, bases, alive, cls_out, wave, lane, pix, rng, o, d, acc);
+  }
+  for (int off2 = 32; off2 > 0; off2 >>= 1) rays += __shfl_down(rays, off2, 64);
+  if ((tid & 63) == 0 && rays) atomicAdd(&block_rays, rays);
+  __syncthreads();
+  if (tid == 0 && block_rays) atomicAdd(a.raycount + (blockIdx.x & (kRayCounters - 1u)), static_cast<unsigned long long>(block_rays));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -862,6 +1015,43 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
   b.multi_off = static_cast<uint32_t>(dyn / 4);
   const size_t dyn_queue = dyn;
   if (a.spp > 1) dyn += 4 * kPtThreads * 4;  // sum_r, sum_g, sum_b, rng_pix
+  if (a.clusters.n > 0 && !a.scene.use_bvh && a.spp == 1 && a.compact && a.bq[0][0] && a.bq_count && a.max_segments >= 2 &&
+      a.max_segments <= kBinnedMaxSegments) {
+    // class-binned wavefront: the tile kernel traces the (coherent, screen-culled) primary segment and bins the
+    // survivors by the class of their next ray; one launch per later segment consumes the bins
+    const size_t cbytes = kBinRegions * kPathClasses * sizeof(uint32_t);
+    (void)hipMemsetAsync(a.bq_count, 0, 2 * cbytes, s);
+    b.seg_begin = 0;
+    b.seg_end = 1;
+    b.q_in = b.q_out = nullptr;
+    b.q_in_count = b.q_out_count = nullptr;
+    b.bq_in[0] = b.bq_in[1] = nullptr;
+    b.bq_in_count = nullptr;
+    b.bq_out[0] = a.bq[0][0];
+    b.bq_out[1] = a.bq[0][1];
+    b.bq_out_count = a.bq_count;
+    hipLaunchKernelGGL((k_pathtrace<false, true>), grid, block, dyn, s, b);
+    const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
+    const dim3 qgrid(static_cast<uint32_t>(n_cu) * 8u);
+    for (uint32_t seg = 1; seg < a.max_segments; seg++) {
+      const uint32_t in = (seg - 1) & 1u, out = seg & 1u;
+      const bool more = seg + 1 < a.max_segments;
+      PathtraceArgs c = b;
+      c.seg_begin = seg;
+      c.seg_end = seg + 1;
+      c.bq_in[0] = a.bq[in][0];
+      c.bq_in[1] = a.bq[in][1];
+      c.bq_in_count = a.bq_count + in * kBinRegions * kPathClasses;
+      c.bq_out[0] = more ? a.bq[out][0] : nullptr;
+      c.bq_out[1] = more ? a.bq[out][1] : nullptr;
+      c.bq_out_count = more ? a.bq_count + out * kBinRegions * kPathClasses : nullptr;
+      if (more && seg >= 2) (void)hipMemsetAsync(a.bq_count + out * kBinRegions * kPathClasses, 0, cbytes, s);
+      hipLaunchKernelGGL(k_pathtrace_binned, qgrid, block, 0, s, c);
+    }
+    return;
+  }
+  b.bq_out_count = nullptr;  // the windowed paths below hand over through the plain queue
+  b.bq_in_count = nullptr;
   const uint32_t phase0 = pt_first_window(a.scene.use_bvh != 0);
   const bool split = a.spp == 1 && a.compact && a.queue[0] && a.queue_count && a.max_segments > phase0 &&
                      (a.max_segments <= 2 * phase0 || a.queue[1]);
