@@ -100,9 +100,12 @@ typedef struct rtpt_visibility_data {
                                               handing the paths that survive 4 / 8 / 16 segments to follow-up launches
                                               through a queue (A/B switch; the image is the same) */
 
-#define RTPT_FLAG_NO_BINNED_PATHS 0x800u  /* path tracer, small scenes with separate objects: hand the paths from segment
-                                             to segment through the segment windows above instead of the queues binned by
-                                             which objects' bounds the next ray enters (A/B switch; the image is the same) */
+#define RTPT_FLAG_BINNED_PATHS 0x800u     /* path tracer, small scenes with separate objects, <= 8 segments: one launch per
+                                             segment, the paths handed on through queues binned by which objects' bounds the
+                                             next ray enters, so a wave tests only its class's triangles (16.5 instead of 32
+                                             per secondary ray on the Cornell box).  Same image; measured SLOWER than the
+                                             default (4K: 566 vs 500 us) — the per-ray queue traffic and bookkeeping cost
+                                             more VALU issue than the skipped tests save — so it is opt-in (A/B switch) */
 #define RTPT_FLAG_NO_FILTER_FUSION 0x400u /* K3: launch every rtpt_temporal_filter call at once, one kernel per
                                              iteration, instead of recording the frame's calls and chaining
                                              consecutive iterations into one launch (A/B switch; same pixels) */

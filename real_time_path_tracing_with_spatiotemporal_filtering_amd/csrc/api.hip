@@ -94,6 +94,8 @@ struct rtpt_ctx {
   uint64_t lut_version[2] = {~0ull, ~0ull};  // model_version each LUT buffer was built for
   rt::ClusterInfo clusters{};          // small scenes: cull clusters of the class-binned path hand-over (kernels.hpp)
   Buf bin_queue[2][2], bin_count;      // its record buffers [direction][buffer] and counters
+  Buf class_recs, class_ids;           // per class: the isect records / ids of its triangle set, contiguous
+  uint32_t class_off[rt::kPathClasses] = {0, 0, 0, 0}, class_cnt[rt::kPathClasses] = {0, 0, 0, 0};
   uint32_t bin_region_cap = 0;
   Buf materials;                       // optional per-base-triangle (Kd, Ke) records, rtpt_scene_set_materials
   uint32_t n_base_tris = 0;
@@ -483,6 +485,8 @@ int rtpt_destroy(rtpt_ctx* c) {
   free_buf(c->normals);
   free_buf(c->path_queue_count);
   free_buf(c->bin_count);
+  free_buf(c->class_recs);
+  free_buf(c->class_ids);
   for (auto& d : c->bin_queue)
     for (auto& b : d) free_buf(b);
   for (auto& b : c->path_queue) free_buf(b);
@@ -606,7 +610,7 @@ int rtpt_enable_debug(rtpt_ctx* c, uint32_t mask) {
 }
 
 // ------------------------------------------------------------------------------------------ scene
-static void compute_clusters(rtpt_ctx* c);
+static int compute_clusters(rtpt_ctx* c);
 
 int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uint32_t* idx, uint32_t n_tris,
                       const float* xf, uint32_t n_instances) {
@@ -682,7 +686,7 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   for (int i = 0; i < 16; i++) c->model[i] = (i % 5 == 0) ? 1.0f : 0.0f;
   c->model_version++;
   c->use_bvh = (total > 64) || (c->cfg.flags & RTPT_FLAG_FORCE_BVH);
-  compute_clusters(c);
+  if ((rc = compute_clusters(c))) return rc;
   c->use_bvh = (total > 64) || (c->cfg.flags & RTPT_FLAG_FORCE_BVH);
   c->bvh_depth = bvh.max_depth;
   c->lut_prev_valid = false;
@@ -770,10 +774,33 @@ static rt::ClusterInfo find_clusters(const float* T, uint32_t n) {
   return ci;
 }
 
-static void compute_clusters(rtpt_ctx* c) {
+// (re)derive the clusters of the posed scene and the per-class record runs; enqueued on the context's stream behind
+// k_scene_prepare, whose isect records the gather reads
+static int compute_clusters(rtpt_ctx* c) {
   c->clusters = rt::ClusterInfo{};
-  if (c->host_tris.empty() || c->use_bvh) return;
-  c->clusters = find_clusters(c->host_tris.data(), c->n_tris);
+  if (c->host_tris.empty() || c->use_bvh) return RTPT_OK;
+  const rt::ClusterInfo ci = find_clusters(c->host_tris.data(), c->n_tris);
+  if (ci.n == 0) return RTPT_OK;
+  std::vector<uint32_t> ids;
+  for (uint32_t cls = 0; cls < rt::kPathClasses; cls++) {
+    unsigned long long set = ci.always;
+    for (int g = 0; g < rt::kMaxClusters; g++)
+      if ((cls & (1u << g)) && g < ci.n) set |= ci.mask[g];
+    c->class_off[cls] = static_cast<uint32_t>(ids.size());
+    for (uint32_t t = 0; t < c->n_tris; t++)
+      if (set >> t & 1ull) ids.push_back(t);  // ascending id: equal-t ties keep the lower id (D4)
+    c->class_cnt[cls] = static_cast<uint32_t>(ids.size()) - c->class_off[cls];
+  }
+  int rc;
+  if ((rc = alloc_buf(c->class_ids, ids.size() * sizeof(uint32_t)))) return rc;
+  if ((rc = alloc_buf(c->class_recs, ids.size() * 48))) return rc;
+  HIP_TRY(hipMemcpyAsync(c->class_ids.ptr, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  rt::launch_class_records(static_cast<const float4*>(c->isect_id.ptr), static_cast<const uint32_t*>(c->class_ids.ptr),
+                           static_cast<uint32_t>(ids.size()), static_cast<float4*>(c->class_recs.ptr), c->stream);
+  if ((rc = launch_check("class_records"))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // `ids` dies at return
+  c->clusters = ci;
+  return RTPT_OK;
 }
 
 // Pose the scene with a new model matrix (visibility.vert.glsl:24 `model * position`; the reference recomputes
@@ -814,7 +841,7 @@ static int apply_model(rtpt_ctx* c, const float* model) {
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));  // host staging vectors die at return
   if (total <= static_cast<uint32_t>(rt::kCullMaxTris)) c->host_tris.swap(tris);
-  compute_clusters(c);
+  if ((rc = compute_clusters(c))) return rc;
   std::memcpy(c->model, model, sizeof c->model);
   c->model_version++;
   c->tables_valid = false;  // per-id normals and pair weights follow the posed triangles
@@ -1036,13 +1063,17 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   a.bq_out_count = nullptr;
   a.bq_in_count = nullptr;
   a.bq_region_cap = 0;
+  a.class_recs = nullptr;
+  a.class_ids = nullptr;
+  for (uint32_t i = 0; i < rt::kPathClasses; i++) a.class_off[i] = a.class_cnt[i] = 0;
   if (c->clusters.n > 0 && !c->use_bvh && a.compact && a.spp == 1 && a.max_segments >= 2 && a.max_segments <= rt::kBinnedMaxSegments &&
-      !(c->cfg.flags & (RTPT_FLAG_SINGLE_LAUNCH_PATHS | RTPT_FLAG_NO_BINNED_PATHS)) && c->cfg.width < 65536 && c->cfg.height < 65536) {
+      (c->cfg.flags & RTPT_FLAG_BINNED_PATHS) && !(c->cfg.flags & RTPT_FLAG_SINGLE_LAUNCH_PATHS) && c->cfg.width < 65536 &&
+      c->cfg.height < 65536) {
     // class-binned hand-over (kernels.hpp): a region holds at most the survivors of the workgroups mapped to it —
     // ceil(tiles / regions) tiles of 256 paths from the tile kernel; from a queue launch, (grid / regions) workgroups
     // of at most ceil(chunks / grid) chunks each, chunks <= paths / 256 + one partial chunk per list
     const size_t tiles = ((static_cast<size_t>(c->cfg.width) + 63) / 64) * ((c->rows() + 3) / 4);
-    const size_t grid = static_cast<size_t>(c->n_cu) * 8;
+    const size_t grid = static_cast<size_t>(c->n_cu) * 8;  // >= the queue launches' grid
     const size_t lists = rt::kBinRegions * rt::kPathClasses;
     const size_t chunks = tiles + lists;
     const size_t per_region = std::max((tiles + rt::kBinRegions - 1) / rt::kBinRegions,
@@ -1064,6 +1095,12 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
       for (int b = 0; b < 2; b++) a.bq[d][b] = c->bin_queue[d][b].ptr;
     a.bq_count = static_cast<uint32_t*>(c->bin_count.ptr);
     a.bq_region_cap = cap;
+    a.class_recs = static_cast<const float4*>(c->class_recs.ptr);
+    a.class_ids = static_cast<const uint32_t*>(c->class_ids.ptr);
+    for (uint32_t i = 0; i < rt::kPathClasses; i++) {
+      a.class_off[i] = c->class_off[i];
+      a.class_cnt[i] = c->class_cnt[i];
+    }
   }
   a.cull = 0;
   if (!c->use_bvh && c->width_fits_i16()) {

@@ -557,11 +557,44 @@ __device__ __forceinline__ uint32_t ray_class(const ClusterInfo& ci, f3 o, f3 d,
   return cls;
 }
 
-// append the workgroup's surviving paths to the class-binned queues: one atomic per class present per workgroup, on the
-// counter of the workgroup's region
-__device__ __forceinline__ void enqueue_binned(const PathtraceArgs& a, uint32_t region, uint32_t (*wave_cnt)[kPathClasses], uint32_t* bases,
-                                               bool alive, uint32_t cls, int wave, uint32_t lane, uint32_t pixg, uint32_t rng, f3 o, f3 d,
-                                               f3 acc) {
+// append a wave's surviving paths to the class-binned queues: one atomic per class present, all issued before the first
+// is waited for, no workgroup barrier (a workgroup-wide append — one atomic per class per workgroup behind two barriers —
+// cost the persistent queue kernel 100 of its 260 us: every wave of the workgroup idled through the atomic's round trip).
+// Records are stored as three float4 planes (structure of arrays) so that a wave's 64 records are three 1 KiB stores.
+__device__ __forceinline__ void enqueue_binned(const PathtraceArgs& a, uint32_t region, bool alive, uint32_t cls, uint32_t pixg, uint32_t rng,
+                                               f3 o, f3 d, f3 acc) {
+  unsigned long long mine = 0;
+  uint32_t base = 0;
+#pragma unroll
+  for (uint32_t c = 0; c < kPathClasses; c++) {
+    const unsigned long long m = __ballot(alive && cls == c);
+    if (m == 0ull) continue;  // wave-uniform
+    uint32_t b = 0;
+    if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(m)))
+      b = atomicAdd(a.bq_out_count + region * kPathClasses + c, static_cast<uint32_t>(__builtin_popcountll(m)));
+    b = __shfl(b, __builtin_ctzll(m), 64);
+    if (cls == c) {
+      mine = m;
+      base = b;
+    }
+  }
+  if (alive) {
+    const uint32_t off = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mine >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mine), 0u));
+    const size_t rbase = static_cast<size_t>(region) * a.bq_region_cap;
+    const size_t slot = (cls & 1u) ? rbase + a.bq_region_cap - 1u - off : rbase + off;  // odd classes grow down
+    const size_t plane = static_cast<size_t>(kBinRegions) * a.bq_region_cap;
+    float4* q = reinterpret_cast<float4*>(a.bq_out[cls >> 1]);
+    q[slot] = make_float4(__uint_as_float(pixg), __uint_as_float(rng), o.x, o.y);
+    q[plane + slot] = make_float4(o.z, d.x, d.y, d.z);
+    q[2 * plane + slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+  }
+}
+
+// the same append for a whole workgroup that is about to retire (the tile kernel): per-wave counts meet in LDS and ONE
+// atomic per class present serves the workgroup — a third of the returning atomics of the per-wave form
+__device__ __forceinline__ void enqueue_binned_block(const PathtraceArgs& a, uint32_t region, uint32_t (*wave_cnt)[kPathClasses],
+                                                     uint32_t* bases, bool alive, uint32_t cls, int wave, uint32_t lane, uint32_t pixg,
+                                                     uint32_t rng, f3 o, f3 d, f3 acc) {
   unsigned long long mine = 0;
 #pragma unroll
   for (uint32_t c = 0; c < kPathClasses; c++) {
@@ -585,12 +618,12 @@ __device__ __forceinline__ void enqueue_binned(const PathtraceArgs& a, uint32_t 
                          __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mine >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mine), 0u));
     const size_t rbase = static_cast<size_t>(region) * a.bq_region_cap;
     const size_t slot = (cls & 1u) ? rbase + a.bq_region_cap - 1u - off : rbase + off;  // odd classes grow down
-    float4* q = reinterpret_cast<float4*>(a.bq_out[cls >> 1]) + 3 * slot;
-    q[0] = make_float4(__uint_as_float(pixg), __uint_as_float(rng), o.x, o.y);
-    q[1] = make_float4(o.z, d.x, d.y, d.z);
-    q[2] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    const size_t plane = static_cast<size_t>(kBinRegions) * a.bq_region_cap;
+    float4* q = reinterpret_cast<float4*>(a.bq_out[cls >> 1]);
+    q[slot] = make_float4(__uint_as_float(pixg), __uint_as_float(rng), o.x, o.y);
+    q[plane + slot] = make_float4(o.z, d.x, d.y, d.z);
+    q[2 * plane + slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
   }
-  __syncthreads();  // wave_cnt / bases may be reused right away
 }
 
 // K2 tile kernel with optional per-segment compaction (PathtraceArgs::compact).
@@ -747,7 +780,7 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
       const uint32_t blk = blockIdx.y * gridDim.x + blockIdx.x;
       if (!BVH && a.bq_out_count) {
         const uint32_t cls = alive ? ray_class(a.clusters, o, d, a.tmax) : 0u;
-        enqueue_binned(a, blk % kBinRegions, bin_cnt, bin_bases, alive, cls, wave, lane, pixg, rng, o, d, acc);
+        enqueue_binned_block(a, blk % kBinRegions, bin_cnt, bin_bases, alive, cls, wave, lane, pixg, rng, o, d, acc);
       } else
         enqueue_paths(a, blk % kPathQueues, wave_cnt, &q_base, alive, wave, lane, pixg, rng, o, d, acc);
     }
@@ -773,71 +806,128 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // class-binned paths: the queue kernel
-// One segment (a.seg_begin) of every queued path.  A workgroup takes 256-record chunks of ONE list = (region, class), so
-// all of its waves test the same triangle set: always | the class's clusters, in ascending id order (equal-t ties keep
-// the lower id, D4 — the triangles left out cannot be hit: the ray misses their cluster's padded bounds).  Survivors are
-// classified by their new ray and appended to the out queues; a path that ends writes its pixel.
+// One segment (a.seg_begin) of every queued path.  A WAVE takes 64-record pieces of one list = (region, class), so it
+// tests one triangle set: always | the class's clusters, stored as a contiguous run of records in ascending id order
+// (equal-t ties keep the lower id, D4 — the triangles left out cannot be hit: the ray misses their cluster's padded
+// bounds).  Survivors are classified by their new ray and appended to the out queues; a path that ends writes its pixel.
+// Waves are independent after the prologue: no workgroup barrier in the loop.
 __global__ __launch_bounds__(kPtThreads) void k_pathtrace_binned(PathtraceArgs a) {
   constexpr uint32_t kLists = kBinRegions * kPathClasses;
-  static_assert(kLists == kPtThreads, "one list per thread in the prefix scan");
-  __shared__ uint32_t prefix[kLists + 1];   // chunks before list l
+  constexpr uint32_t kPer = (kLists + kPtThreads - 1) / kPtThreads;  // lists per thread in the prefix scan
+  __shared__ uint32_t prefix[kLists + 1];   // 64-record pieces before list l
   __shared__ uint32_t counts[kLists];
-  __shared__ uint32_t wave_cnt[kPtRows][kPathClasses];
-  __shared__ uint32_t bases[kPathClasses];
+  __shared__ uint32_t part[kPtThreads + 1];
   __shared__ unsigned int block_rays;
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   const uint32_t lane = threadIdx.x;
   if (tid == 0) block_rays = 0;
   {
-    const uint32_t cnt = a.bq_in_count[tid];
-    counts[tid] = cnt;
-    prefix[tid + 1] = (cnt + kPtThreads - 1) / kPtThreads;
-    if (tid == 0) prefix[0] = 0;
+    uint32_t mine = 0;
+    for (uint32_t i = 0; i < kPer; i++) {
+      const uint32_t l = static_cast<uint32_t>(tid) * kPer + i;
+      if (l >= kLists) break;
+      const uint32_t cnt = a.bq_in_count[l];
+      counts[l] = cnt;
+      mine += (cnt + 63u) / 64u;
+    }
+    part[tid + 1] = mine;
+    if (tid == 0) part[0] = 0;
     __syncthreads();
-    for (uint32_t step = 1; step < kLists; step <<= 1) {  // inclusive scan of prefix[1..kLists]
-      const uint32_t v = (static_cast<uint32_t>(tid) >= step) ? prefix[tid + 1 - step] : 0u;
+    for (uint32_t step = 1; step < kPtThreads; step <<= 1) {  // inclusive scan of part[1..]
+      const uint32_t v = (static_cast<uint32_t>(tid) >= step) ? part[tid + 1 - step] : 0u;
       __syncthreads();
-      prefix[tid + 1] += v;
+      part[tid + 1] += v;
       __syncthreads();
     }
+    uint32_t run = part[tid];
+    for (uint32_t i = 0; i < kPer; i++) {
+      const uint32_t l = static_cast<uint32_t>(tid) * kPer + i;
+      if (l >= kLists) break;
+      prefix[l] = run;
+      run += (counts[l] + 63u) / 64u;
+    }
+    if (tid == kPtThreads - 1) prefix[kLists] = part[kPtThreads];
+    __syncthreads();
   }
-  const uint32_t total_chunks = prefix[kLists];
+  const uint32_t total_pieces = prefix[kLists];
   const f3 light_c = ld3(a.light_c);
   const uint32_t seg = a.seg_begin;
   const bool more = seg + 1 < a.max_segments;  // survivors are handed on (otherwise shade_segment ends every path)
+  const uint32_t n_waves = gridDim.x * kPtRows, my_wave = blockIdx.x * kPtRows + static_cast<uint32_t>(wave);
+  const size_t plane = static_cast<size_t>(kBinRegions) * a.bq_region_cap;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  using cv4f = const __attribute__((address_space(4))) v4f;
+  using cu32 = const __attribute__((address_space(4))) uint32_t;
   unsigned int rays = 0;
-  for (uint32_t j = blockIdx.x; j < total_chunks; j += gridDim.x) {  // block-uniform
-    uint32_t lo = 0, hi = kLists;  // the list holding chunk j: the largest l with prefix[l] <= j
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (prefix[mid] <= j) lo = mid; else hi = mid;
-    }
-    const uint32_t list = __builtin_amdgcn_readfirstlane(lo);
-    const uint32_t region = list / kPathClasses, cls_in = list % kPathClasses;
-    const uint32_t off = (j - prefix[list]) * kPtThreads + static_cast<uint32_t>(tid);
-    bool alive = off < counts[list];
-    uint32_t pix = 0, rng = 0;
-    f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, -1.f}, acc{1.f, 1.f, 1.f};
-    if (alive) {
+  // this wave's pieces are j = my_wave + i * n_waves.  Which list holds piece j — the largest l with prefix[l] <= j — is
+  // found for 64 pieces at a time, lane i searching for piece i, so the ten dependent LDS reads of the binary search are
+  // paid once per 64 pieces instead of once per piece; the loop below fetches lane i's answer with a readlane.
+  const uint32_t my_pieces = my_wave < total_pieces ? (total_pieces - 1u - my_wave) / n_waves + 1u : 0u;
+  auto locate = [&](uint32_t i0) -> uint32_t {
+    const uint32_t j = my_wave + (i0 + lane) * n_waves;
+    uint32_t lo = 0, hi = kLists;
+    if (j < total_pieces)
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (prefix[mid] <= j) lo = mid; else hi = mid;
+      }
+    return lo;
+  };
+  // one piece of 64 records, read ahead of its use: the loads of piece i + 1 are in flight while piece i is traced
+  struct Piece {
+    float4 q0, q1, q2;
+    uint32_t list;
+    bool alive;
+  };
+  auto fetch = [&](uint32_t list, uint32_t j) -> Piece {
+    Piece p;
+    p.list = list;
+    const uint32_t region = list / kPathClasses, cls = list % kPathClasses;
+    const uint32_t off = (j - prefix[list]) * 64u + lane;
+    p.alive = off < counts[list];
+    p.q0 = p.q1 = p.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.alive) {
       const size_t rbase = static_cast<size_t>(region) * a.bq_region_cap;
-      const size_t slot = (cls_in & 1u) ? rbase + a.bq_region_cap - 1u - off : rbase + off;
-      const float4* q = reinterpret_cast<const float4*>(a.bq_in[cls_in >> 1]) + 3 * slot;
-      const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-      pix = __float_as_uint(q0.x);
-      rng = __float_as_uint(q0.y);
-      o = f3{q0.z, q0.w, q1.x};
-      d = f3{q1.y, q1.z, q1.w};
-      acc = f3{q2.x, q2.y, q2.z};
+      const size_t slot = (cls & 1u) ? rbase + a.bq_region_cap - 1u - off : rbase + off;
+      const float4* q = reinterpret_cast<const float4*>(a.bq_in[cls >> 1]);
+      p.q0 = q[slot];
+      p.q1 = q[plane + slot];
+      p.q2 = q[2 * plane + slot];
     }
-    unsigned long long set = a.clusters.always;
-#pragma unroll
-    for (int g = 0; g < kMaxClusters; g++)
-      if (cls_in & (1u << g)) set |= a.clusters.mask[g];
+    return p;
+  };
+  uint32_t tbl = my_pieces ? locate(0) : 0u;
+  Piece nxt{};
+  if (my_pieces) nxt = fetch(__builtin_amdgcn_readlane(tbl, 0), my_wave);
+#pragma unroll 1
+  for (uint32_t i = 0; i < my_pieces; i++) {  // wave-uniform
+    const Piece cur = nxt;
+    if (i + 1 < my_pieces) {
+      if (((i + 1) & 63u) == 0u) tbl = locate(i + 1);
+      const uint32_t nl = __builtin_amdgcn_readfirstlane(__shfl(tbl, static_cast<int>((i + 1) & 63u), 64));
+      nxt = fetch(nl, my_wave + (i + 1) * n_waves);
+    }
+    const uint32_t cls_in = cur.list % kPathClasses;
+    bool alive = cur.alive;
+    uint32_t pix = __float_as_uint(cur.q0.x), rng = __float_as_uint(cur.q0.y);
+    f3 o{cur.q0.z, cur.q0.w, cur.q1.x}, d{cur.q1.y, cur.q1.z, cur.q1.w}, acc{cur.q2.x, cur.q2.y, cur.q2.z};
     uint32_t cls_out = 0;
     if (alive) {
       HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
-      closest_hit_brute_set(a.scene, set, o, d, h);  // :208-222
+      {
+        // :208-222 over the class's triangle run; the records are read through the constant address space (scalar
+        // loads into SGPR operands, like closest_hit_brute)
+        cv4f* rec = (cv4f*)(a.class_recs + 3 * static_cast<size_t>(a.class_off[cls_in]));
+        cu32* ids = (cu32*)(a.class_ids + a.class_off[cls_in]);
+        const uint32_t n = a.class_cnt[cls_in];
+#pragma unroll 4
+        for (uint32_t t = 0; t < n; t++) {
+          const v4f a0 = rec[3 * t], a1 = rec[3 * t + 1], a2 = rec[3 * t + 2];
+          tri_test<false>(o, d, make_float4(a0.x, a0.y, a0.z, a0.w), make_float4(a1.x, a1.y, a1.z, a1.w),
+                          make_float4(a2.x, a2.y, a2.z, a2.w), ids[t] + 1, h);
+        }
+      }
       const int x = static_cast<int>(pix & 0xFFFFu), y = static_cast<int>(pix >> 16);
       if (y >= a.count_y0 && y < a.count_y1) rays++;
       if (shade_segment(a, h, seg, light_c, o, d, acc, rng)) {
@@ -848,12 +938,21 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace_binned(PathtraceArgs a
         cls_out = ray_class(a.clusters, o, d, a.tmax);
       }
     }
-    if (more) enqueue_binned(a, blockIdx.x % kBinRegions, wave_cnt, bases, alive, cls_out, wave, lane, pix, rng, o, d, acc);
+    if (more) enqueue_binned(a, my_wave % kBinRegions, alive, cls_out, pix, rng, o, d, acc);
   }
   for (int off2 = 32; off2 > 0; off2 >>= 1) rays += __shfl_down(rays, off2, 64);
   if ((tid & 63) == 0 && rays) atomicAdd(&block_rays, rays);
   __syncthreads();
   if (tid == 0 && block_rays) atomicAdd(a.raycount + (blockIdx.x & (kRayCounters - 1u)), static_cast<unsigned long long>(block_rays));
+}
+
+__global__ void k_class_records(const float4* isect_id, const uint32_t* ids, uint32_t n, float4* out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint32_t id = ids[t];
+  out[3 * t] = isect_id[3 * id];
+  out[3 * t + 1] = isect_id[3 * id + 1];
+  out[3 * t + 2] = isect_id[3 * id + 2];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -987,6 +1086,10 @@ void launch_scene_prepare(const ScenePrepArgs& a, hipStream_t s) {
   if (!a.n_tris) return;
   hipLaunchKernelGGL(k_scene_prepare, dim3((a.n_tris + 255) / 256), dim3(256), 0, s, a);
 }
+void launch_class_records(const float4* isect_id, const uint32_t* ids, uint32_t n, float4* out, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_class_records, dim3((n + 255) / 256), dim3(256), 0, s, isect_id, ids, n, out);
+}
 void launch_lut(const LutArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_lut, dim3((a.n_tris + 256) / 256), dim3(256), 0, s, a);
   if (a.pair_tab) {
@@ -1031,8 +1134,10 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
     b.bq_out[1] = a.bq[0][1];
     b.bq_out_count = a.bq_count;
     hipLaunchKernelGGL((k_pathtrace<false, true>), grid, block, dyn, s, b);
+    // one resident generation of waves (the kernel's registers admit 7 waves per SIMD = 7 workgroups of 4 per CU) —
+    // a grid of 8 per CU ran its last workgroups as a second round behind the first
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
-    const dim3 qgrid(static_cast<uint32_t>(n_cu) * 8u);
+    const dim3 qgrid(static_cast<uint32_t>(n_cu) * 7u);
     for (uint32_t seg = 1; seg < a.max_segments; seg++) {
       const uint32_t in = (seg - 1) & 1u, out = seg & 1u;
       const bool more = seg + 1 < a.max_segments;
