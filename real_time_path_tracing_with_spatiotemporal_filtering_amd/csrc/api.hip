@@ -580,8 +580,11 @@ int rtpt_set_external_history(rtpt_ctx* c, const void* device_ptr, uint32_t row_
 
 int rtpt_stream_wait(rtpt_ctx* c, rtpt_ctx* other) {
   if (!c || !other) return fail(RTPT_E_INVALID, "NULL argument");
-  FLUSH_FILTER(other);  // "everything submitted to `other` so far" includes its recorded iterations
-  FLUSH_FILTER(c);
+  // "everything submitted to `other` so far" includes its recorded iterations; this context's own recorded iterations
+  // do not depend on `other` and go out ahead of the wait.  Neither call looks at a plane, so both may run chained.
+  int rcw = filter_flush(other, true);
+  if (rcw == RTPT_OK) rcw = filter_flush(c, true);
+  if (rcw) return rcw;
   if (c == other || c->stream == other->stream) return RTPT_OK;  // one stream is already in order
   if (c->device != other->device) return fail(RTPT_E_INVALID, "rtpt_stream_wait: the contexts are on different devices");
   HIP_TRY(hipSetDevice(c->device));

@@ -361,11 +361,16 @@ constexpr int kShThreads = 64 * kShWaves;
 // 16-byte plane written by k_gbuffer (normal_tab[id]: n.xyz and the self weight) — and the normal weight is computed
 // per tap from the two staged normals with the same arithmetic as the direct kernel.  32 instead of 20 staged bytes
 // per pixel, but 3 vector-memory instructions per staged row instead of the direct kernel's 27 per pixel.
-template <int CWp, bool FINAL, bool EXACT, bool NRM = false>
+// R / EXTA: the extension modes that only change the TAPS (RTPT_FLAG_EXT_GAUSS5: radius R = 2 with the gaussianKernel2D
+// weights the reference declares and never uses, temporalFiltering.comp.glsl:93-99; RTPT_FLAG_EXT_POW2_STRIDE: stride
+// 2^(k-1), passed as a.stride) run in this kernel too — the same comb staging with 2R halo rows per workgroup and 2R*s
+// halo columns per segment, and the arithmetic of k_atrous_ext (h kept per tap, correctly-rounded final division), so
+// the two are bit-identical.  25 taps are 25 LDS reads here instead of 75 global loads per pixel.
+template <int CWp, bool FINAL, bool EXACT, bool NRM = false, int R = 1, bool EXTA = false>
 __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int W = a.g.W, H = a.g.H, k = a.k;
-  constexpr int rows = kShWaves * kCombM + 2, cells = rows * CWp;  // block-shared rows
+  const int W = a.g.W, H = a.g.H, k = a.stride;  // a.stride == a.k (main.cpp:1259-1260, :135) unless POW2_STRIDE
+  constexpr int rows = kShWaves * kCombM + 2 * R, cells = rows * CWp;  // block-shared rows
   const int NP = NRM ? 0 : static_cast<int>(a.n_tris) + 1;
   const int lane = static_cast<int>(threadIdx.x);
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
   const uint32_t lb_lo = x_lo + static_cast<uint32_t>((static_cast<uint64_t>(x_hi - x_lo) * jx) / per_xcd);
   const uint32_t lb_hi = x_lo + static_cast<uint32_t>((static_cast<uint64_t>(x_hi - x_lo) * (jx + 1)) / per_xcd);
   const int row_lo = a.g.row_base, row_hi = a.g.row_base + a.rows_stored - 1;
-  const bool tail_lane = lane < 2 * k;  // columns 64 .. 64+2k-1
+  const bool tail_lane = lane < 2 * R * k;  // columns 64 .. 64+2Rk-1
   const float h = 1.0f / 9.0f;  // :145
   // (residue, column, chunk group) of lb_lo, then advanced incrementally (scalar adds, no divisions)
   int r = static_cast<int>(lb_lo / per_res);
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
   uint32_t o16[kShHalves + 1], o4[kShHalves + 1];  // per-lane source offsets of the full chunks and the tail chunk
 #pragma unroll
   for (int hf = 0; hf <= kShHalves; hf++) {
-    int gx = x0 - k + hf * 64 + lane;
+    int gx = x0 - R * k + hf * 64 + lane;
     gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);  // :136
     o16[hf] = static_cast<uint32_t>(gx) * 16u;
     o4[hf] = static_cast<uint32_t>(gx) * 4u;
@@ -453,10 +458,10 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
   __builtin_amdgcn_s_setprio(3);  // issue this item's DMAs ahead of the other waves' arithmetic
 #endif
   // wave w stages rows w*M+1 .. w*M+M; wave 0 also row 0, the last wave also row 4M+1
-  const int j_lo = wave * kCombM + (wave == 0 ? 0 : 1);
-  const int j_hi = wave * kCombM + kCombM + (wave == kShWaves - 1 ? 1 : 0);
+  const int j_lo = wave * kCombM + (wave == 0 ? 0 : R);
+  const int j_hi = wave * kCombM + kCombM + R - 1 + (wave == kShWaves - 1 ? R : 0);
   for (int j = j_lo; j <= j_hi; j++) {
-    int gy = yg + (j - 1) * k;
+    int gy = yg + (j - R) * k;
     gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);              // :136
     gy = gy < row_lo ? row_lo : (gy > row_hi ? row_hi : gy);  // rows only masked outputs could reach
     const size_t grow = static_cast<size_t>(gy - a.g.row_base) * W;  // wave-uniform
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
     const int x = x0 + hf * 64 + lane;
     const int y = yg + (wave * kCombM + m) * k;
     if (x >= W || y >= a.g.y1) continue;
-    const int cc = (wave * kCombM + m + 1) * CWp + hf * 64 + lane + k;
+    const int cc = (wave * kCombM + m + R) * CWp + hf * 64 + lane + R * k;
     const float4 cp4 = col[cc];
     const f3 cp = xyz(cp4);
     const float dp = cp4.w;
@@ -506,12 +511,12 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
     f3 num{0.f, 0.f, 0.f};
     float den = 0.f;
 #pragma unroll
-    for (int i = -1; i < 2; i++) {  // :132 (x offset outer: the reference's accumulation order)
+    for (int i = -R; i <= R; i++) {  // :132 (x offset outer: the reference's accumulation order)
 #pragma unroll
-      for (int jj = -1; jj < 2; jj++) {  // :133
+      for (int jj = -R; jj <= R; jj++) {  // :133
         float w;
         f3 cq;
-        if (i == 0 && jj == 0) {
+        if (!EXTA && i == 0 && jj == 0) {
           cq = cp;
           w = wself;  // centre tap: q == p, both exponentials are exactly 1
         } else {
@@ -536,7 +541,15 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
             w = wn * __builtin_amdgcn_exp2f(e);
           }
         }
-        if (EXACT) {
+        if (EXTA) {
+          // k_atrous_ext's accumulation: the tap's own h (gaussianKernel2D / 273, :93-99, or 1/9, :145) stays in
+          constexpr float kG5[5] = {1.f, 4.f, 7.f, 4.f, 1.f}, kG5m[5] = {4.f, 16.f, 26.f, 16.f, 4.f}, kG5c[5] = {7.f, 26.f, 41.f, 26.f, 7.f};
+          const float g = R == 2 ? ((i == 0) ? kG5c[jj + 2] : ((i == -1 || i == 1) ? kG5m[jj + 2] : kG5[jj + 2])) : 9.0f;
+          const float hh = R == 2 ? g * (1.0f / 273.0f) : 1.0f / 9.0f;
+          const float hw = hh * w;
+          num = f3{fmaf_(hw, cq.x, num.x), fmaf_(hw, cq.y, num.y), fmaf_(hw, cq.z, num.z)};  // :146
+          den = den + hw;                                                                    // :147
+        } else if (EXACT) {
           const float hw = h * w;
           num = f3{fmaf_(hw, cq.x, num.x), fmaf_(hw, cq.y, num.y), fmaf_(hw, cq.z, num.z)};  // :146
           den = den + hw;                                                                    // :147
@@ -548,7 +561,7 @@ __global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
       }
     }
     f3 filtered;
-    if (EXACT) {
+    if (EXACT || EXTA) {
       filtered = f3{num.x / den, num.y / den, num.z / den};  // :150
     } else {
       filtered = num * fast::rcp_(den);
@@ -635,7 +648,25 @@ static hipError_t comb_attrs() {
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, false, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
   return e;
 }
+template <int CW, int RR>
+static hipError_t comb_ext_attrs() {
+  constexpr int kMax = 160 * 1024;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, true, false, RR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, false, false, RR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  return e;
+}
 hipError_t prepare_device_atrous() {
+  {
+    hipError_t e = comb_ext_attrs<72, 1>();
+    if (e == hipSuccess) e = comb_ext_attrs<80, 1>();
+    if (e == hipSuccess) e = comb_ext_attrs<96, 1>();
+    if (e == hipSuccess) e = comb_ext_attrs<128, 1>();
+    if (e == hipSuccess) e = comb_ext_attrs<72, 2>();
+    if (e == hipSuccess) e = comb_ext_attrs<80, 2>();
+    if (e == hipSuccess) e = comb_ext_attrs<96, 2>();
+    if (e == hipSuccess) e = comb_ext_attrs<128, 2>();
+    if (e != hipSuccess) return e;
+  }
   constexpr int b = kBlockX * kShHalves;
   hipError_t e = comb_attrs<b + 8, false>();
   if (e == hipSuccess) e = comb_attrs<b + 16, false>();
@@ -653,6 +684,52 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
   a.cl = -1.44269504088896341f / a.sigma_l;
   dim3 block(kBlockX, kBlockY);
   const int np = static_cast<int>(a.n_tris) + 1;
+  {
+    // the tap-shape extensions (5x5 taps, 2^(k-1) stride) of a non-final pass run LDS-staged when the scene has an
+    // id-pair table and the halo 2*R*s fits the widest staged row; everything else that is an extension mode (variance
+    // guidance, the final pass's adaptive alpha / disocclusion test) stays in the generic direct-load kernel
+    const int R = (a.ext & kExtGauss5) ? 2 : 1, sk = a.stride;
+    const bool taps_only = (a.ext & (kExtGauss5 | kExtPow2Stride)) && !(a.ext & kExtVariance) && !final_pass;
+    if (taps_only && !a.direct && a.pair_tab && np <= kPairMax && sk >= 1 && kBlockX + 2 * R * sk <= 128) {
+      const int seg_w = kBlockX;
+      a.tiles_x = (a.g.W + seg_w - 1) / seg_w;
+      const int nrows = a.g.y1 - a.g.y0;
+      const int chunks = (nrows + kCombM * sk - 1) / (kCombM * sk);
+      a.tiles_y = (chunks + kShWaves - 1) / kShWaves;
+      const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
+      const uint32_t nlb = static_cast<uint32_t>(a.tiles_x) * static_cast<uint32_t>(a.tiles_y) * static_cast<uint32_t>(sk);
+      const int need = seg_w + 2 * R * sk;
+      const int cw = need <= 72 ? 72 : (need <= 80 ? 80 : (need <= 96 ? 96 : 128));
+      const size_t lds = static_cast<size_t>((np * np * 4 + 15) & ~15) + static_cast<size_t>(kShWaves * kCombM + 2 * R) * cw * 20;
+      uint32_t per_cu = static_cast<uint32_t>((160u * 1024u) / lds);
+      if (per_cu > 32u / kShWaves) per_cu = 32u / kShWaves;
+      if (per_cu < 1u) per_cu = 1u;
+      uint32_t per_xcd = static_cast<uint32_t>((n_cu + 7) / 8) * per_cu;
+      if (per_xcd > (nlb + 7) / 8) per_xcd = (nlb + 7) / 8;
+      const dim3 grid(per_xcd * 8u), sblock(kBlockX, kShWaves);
+#define RTPT_LAUNCH_EXT(CW, RR)                                                                                     \
+  do {                                                                                                              \
+    if (a.exact)                                                                                                    \
+      hipLaunchKernelGGL((k_atrous_comb_sh<CW, false, true, false, RR, true>), grid, sblock, lds, s, a);           \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_atrous_comb_sh<CW, false, false, false, RR, true>), grid, sblock, lds, s, a);          \
+  } while (0)
+#define RTPT_LAUNCH_EXT_CW(RR)                   \
+  do {                                           \
+    if (cw == 72) RTPT_LAUNCH_EXT(72, RR);       \
+    else if (cw == 80) RTPT_LAUNCH_EXT(80, RR);  \
+    else if (cw == 96) RTPT_LAUNCH_EXT(96, RR);  \
+    else RTPT_LAUNCH_EXT(128, RR);               \
+  } while (0)
+      if (R == 2)
+        RTPT_LAUNCH_EXT_CW(2);
+      else
+        RTPT_LAUNCH_EXT_CW(1);
+#undef RTPT_LAUNCH_EXT_CW
+#undef RTPT_LAUNCH_EXT
+      return;
+    }
+  }
   if (a.ext) {
     const dim3 g2 = grid_for(a.g);
     a.tiles_x = static_cast<int32_t>(g2.x);

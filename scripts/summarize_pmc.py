@@ -12,6 +12,14 @@ from collections import defaultdict
 
 def short(name):
     import re
+    if "k_atrous_chain" in name:
+        # k_atrous_chain<L, FINAL, EXACT>
+        m = re.search(r"k_atrous_chain<\d+, (true|false)", name)
+        return "k_atrous_chain_final" if (m and m.group(1) == "true") else "k_atrous_chain"
+    if "k_pathtrace_binned" in name:
+        return "k_pathtrace_binned"
+    if "k_pathtrace_queue" in name:
+        return "k_pathtrace_queue"
     if "k_atrous" in name:
         # k_atrous_comb_sh<CW, FINAL, EXACT> / k_atrous<FINAL, EXACT>
         m = re.search(r"k_atrous(?:_comb_sh<\d+, |<)(true|false)", name)
