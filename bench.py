@@ -89,7 +89,9 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
     # 0.173 ms), which a 36 ms timed region at 8 ranks would otherwise measure instead of the kernels
     # The same loop fills the context's pool of timing events (created on first use; on some boxes
     # hipEventCreate is slow enough that creating them inside the timed region cost +0.2 ms per step).
-    timing_period = 8 if steps >= 32 else 1
+    # sample the per-kernel events: bracketing every launch costs ~6 % of the frame (the driver's --steps 20 run of
+    # round 1 paid that); at least 4 sampled frames per run
+    timing_period = 8 if steps >= 32 else (4 if steps >= 16 else (2 if steps >= 8 else 1))
     if args.prewarm_seconds > 0:
         ctx.timing_enable(timing_period if collect_kernels else 0)
         t_wake = time.perf_counter()

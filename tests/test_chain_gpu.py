@@ -120,3 +120,18 @@ def test_chain_on_strips(hip_lib, mode):
     from test_parity_gpu import _strips_vs_single
     _strips_vs_single(250, 301, 3, 5, 4, mode, 0, [(), ("E",), ("J",)])
     _strips_vs_single(250, 301, 3, 4, 3, mode, hip_lib.FLAG_EXACT_FILTER, [(), ("Q",), ()])
+
+
+@pytest.mark.parametrize("ext", [0x20, 0x40, 0x60, 0x70])
+@pytest.mark.parametrize("exact", [0, 1])
+def test_lds_staged_extension_taps_equal_the_direct_kernel(hip_lib, ext, exact):
+    """RTPT_FLAG_EXT_GAUSS5 / _POW2_STRIDE (not reference behaviour): the non-final passes run in the comb kernel's 5x5 /
+    wide-stride instances; RTPT_FLAG_DIRECT_FILTER forces the generic direct-load kernel the oracle tests pin.  Same
+    arithmetic, so the frames are equal bit for bit — ragged sizes, N = 5 (strides up to 16, halos up to 32 columns)"""
+    keys = [(), ("J",), ("D", "E")]
+    for (w, h) in ((130, 33), (333, 170), (1000, 800)):
+        a, _ = _frames(hip_lib, w, h, 5, ext | exact, keys)
+        b, _ = _frames(hip_lib, w, h, 5, ext | exact | hip_lib.FLAG_DIRECT_FILTER, keys)
+        for f, ((ia, pa), (ib, pb)) in enumerate(zip(a, b)):
+            assert np.array_equal(bits(ia), bits(ib)), (w, h, hex(ext), exact, f)
+            assert np.array_equal(pa, pb)
