@@ -25,12 +25,13 @@ for WL in 4k 1080p; do
     "WRITE_SIZE" \
     "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" ; do
     i=$((i+1))
-    timeout -k 10 240 rocprofv3 --kernel-trace --pmc $G --output-format csv -d "$OUT/pmc_$WL/pass$i" -- python3 bench.py --workload $WL --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > "$OUT/pmc_$WL/pass$i.json" 2> "$OUT/pmc_$WL/pass$i.err" || { echo "pmc $WL pass $i failed"; tail -3 "$OUT/pmc_$WL/pass$i.err"; }
+    timeout -k 10 240 rocprofv3 --kernel-trace --pmc $G --output-format csv -d "$OUT/pmc_$WL/pass$i" -- python3 bench.py --workload $WL --steps 10 --warmup 3 --prewarm-seconds 0 --no-cpu-baseline --no-secondary > "$OUT/pmc_$WL/pass$i.json" 2> "$OUT/pmc_$WL/pass$i.err" || { echo "pmc $WL pass $i failed"; tail -3 "$OUT/pmc_$WL/pass$i.err"; }
     find "$OUT/pmc_$WL/pass$i" -name "*counter_collection.csv" -exec cp {} "$OUT/pmc_${WL}_pass${i}_counter_collection.csv" \;
     echo "pmc $WL pass $i done: $G"
   done
   python3 scripts/summarize_pmc.py "$OUT/pmc_$WL" > "$OUT/pmc_${WL}_summary.json"
   rm -rf "$OUT/pmc_$WL"
+  python3 scripts/fold_pmc.py "$OUT"/pmc_${WL}_pass*_counter_collection.csv
 done
 python3 - "$OUT" "${COMMIT:-unknown}" <<'PY'
 import json, sys, datetime

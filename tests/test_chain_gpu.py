@@ -135,3 +135,20 @@ def test_lds_staged_extension_taps_equal_the_direct_kernel(hip_lib, ext, exact):
         for f, ((ia, pa), (ib, pb)) in enumerate(zip(a, b)):
             assert np.array_equal(bits(ia), bits(ib)), (w, h, hex(ext), exact, f)
             assert np.array_equal(pa, pb)
+
+
+@pytest.mark.parametrize("exact", [0, 1])
+def test_three_level_and_final_chains(hip_lib, monkeypatch, exact):
+    """the chain kernel's other instances — three iterations per launch, and a chain that ends in the FINAL pass
+    (reprojection + blend in the last level's epilogue) — selected through the tuning knobs rtpt_create reads; N = 5 then
+    runs as (1,2,3) + (4,5 final), N = 4 as (1,2,3) + 4, N = 3 as (1,2,3 final).  Same bits as one kernel per iteration."""
+    monkeypatch.setenv("RTPT_CHAIN_MAX", "3")
+    monkeypatch.setenv("RTPT_CHAIN_FINAL", "1")
+    keys = [(), ("J",), ("D", "E"), ()]
+    for (w, h) in ((121, 64), (333, 170), (1000, 800)):
+        for n in (3, 4, 5):
+            a, _ = _frames(hip_lib, w, h, n, exact, keys)
+            b, _ = _frames(hip_lib, w, h, n, exact | hip_lib.FLAG_NO_FILTER_FUSION, keys)
+            for f, ((ia, pa), (ib, pb)) in enumerate(zip(a, b)):
+                assert np.array_equal(bits(ia), bits(ib)), (w, h, n, exact, f)
+                assert np.array_equal(pa, pb)
