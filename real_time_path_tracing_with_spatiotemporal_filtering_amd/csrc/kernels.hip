@@ -69,7 +69,10 @@ __device__ __forceinline__ void closest_hit_brute(const SceneView& sc, f3 o, f3 
   using cv4f = const __attribute__((address_space(4))) v4f;
   cv4f* rec = (cv4f*)sc.isect_id;
   const uint32_t n = sc.n_tris;
-#pragma unroll 4
+#ifndef RTPT_BRUTE_UNROLL
+#define RTPT_BRUTE_UNROLL 8  // triangles whose records are fetched per batch of scalar loads; K2 at 4K: 2: 517, 4: 505, 8: 499, 16: 498 us
+#endif
+#pragma unroll RTPT_BRUTE_UNROLL
   for (uint32_t i = 0; i < n; i++) {
     const v4f a0 = rec[3 * i], a1 = rec[3 * i + 1], a2 = rec[3 * i + 2];
     tri_test<false>(o, d, make_float4(a0.x, a0.y, a0.z, a0.w), make_float4(a1.x, a1.y, a1.z, a1.w),
@@ -651,8 +654,14 @@ struct PathState {  // SoA in LDS, one slot per thread
   float ar[kPtThreads], ag[kPtThreads], ab[kPtThreads];
 };
 
+// The kernel needs its 8 waves per SIMD to hide the scalar-load latency of the brute-force loop; left alone the
+// compiler keeps 106 SGPRs of kernel arguments live (7 waves).  Measured at 4K: 6 / 7 (compiler's choice) / 8 waves
+// 506 / 505 / 479 us (a few dwords of scalar spills are cheaper than the lost wave).
+#ifndef RTPT_PT_WAVES
+#define RTPT_PT_WAVES 8
+#endif
 template <bool BVH, bool COMPACT>
-__global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
+__device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
   // dynamic LDS, two tenants that are never live together: the BVH node stack (stack_depth x 256 entries, only
   // inside closest_hit) and the compaction exchange buffer (only between the barriers of the compaction step).
   // Sharing it takes the BVH kernel from 41 to 30 KB per block: 5 instead of 3 resident blocks per CU for a
@@ -802,6 +811,21 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
   // the workgroups' slots occupied until acknowledged (a 1-segment launch took 397 us, of which the arithmetic is ~110)
   if (tid == 0 && block_rays)
     atomicAdd(a.raycount + ((blockIdx.y * gridDim.x + blockIdx.x) & (kRayCounters - 1u)), static_cast<unsigned long long>(block_rays));
+}
+
+// the two kernels of the tile body: the wave-uniform brute-force one is pinned at 8 waves per SIMD (above), the BVH one
+// is LDS-limited anyway and loses 4 % to the scalar spills the pin costs (1.15M-triangle trace 3.69 -> 3.85 ms)
+template <bool BVH, bool COMPACT>
+__global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
+  pathtrace_tile<BVH, COMPACT>(a);
+}
+template <bool COMPACT>
+__global__ __launch_bounds__(kPtThreads)
+#if RTPT_PT_WAVES
+__attribute__((amdgpu_waves_per_eu(RTPT_PT_WAVES, RTPT_PT_WAVES)))
+#endif
+void k_pathtrace_small(PathtraceArgs a) {
+  pathtrace_tile<false, COMPACT>(a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1133,7 +1157,7 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
     b.bq_out[0] = a.bq[0][0];
     b.bq_out[1] = a.bq[0][1];
     b.bq_out_count = a.bq_count;
-    hipLaunchKernelGGL((k_pathtrace<false, true>), grid, block, dyn, s, b);
+    hipLaunchKernelGGL((k_pathtrace_small<true>), grid, block, dyn, s, b);
     // one resident generation of waves (the kernel's registers admit 7 waves per SIMD = 7 workgroups of 4 per CU) —
     // a grid of 8 per CU ran its last workgroups as a second round behind the first
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
@@ -1171,12 +1195,12 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
     if (a.scene.use_bvh)
       hipLaunchKernelGGL((k_pathtrace<true, true>), grid, block, dyn, s, b);
     else
-      hipLaunchKernelGGL((k_pathtrace<false, true>), grid, block, dyn, s, b);
+      hipLaunchKernelGGL((k_pathtrace_small<true>), grid, block, dyn, s, b);
   } else {
     if (a.scene.use_bvh)
       hipLaunchKernelGGL((k_pathtrace<true, false>), grid, block, dyn, s, b);
     else
-      hipLaunchKernelGGL((k_pathtrace<false, false>), grid, block, dyn, s, b);
+      hipLaunchKernelGGL((k_pathtrace_small<false>), grid, block, dyn, s, b);
   }
   if (!split) return;
   const int n_cu = a.n_cu > 0 ? a.n_cu : 256;  // of the context's device (rtpt_create)
