@@ -127,8 +127,11 @@ typedef struct rtpt_visibility_data {
                                               a = max(alpha, 1/(n+1)); short histories n < 4 scale the variance by
                                               4/n); the colour term of the tap weight becomes
                                               exp(-|lum_p - lum_q| / (sigma_l * sqrt(var_p) + 1e-4)) and the variance
-                                              is filtered along with weights (h w)^2.  Whole-frame contexts only
-                                              (row_begin = 0, row_end = height).  RTPT_PLANE_MOMENTS / _VARIANCE. */
+                                              is filtered along with weights (h w)^2.  RTPT_PLANE_MOMENTS / _VARIANCE.
+                                              On strip contexts every stored row must have been traced (redundant
+                                              halo rows), and under camera motion the host gathers the previous
+                                              frame's id and moment rows the strip can reach from the other strips
+                                              (rtpt_set_external_guides) like it does for the history image. */
 
 typedef struct rtpt_config {
   uint32_t struct_size;          /* = sizeof(rtpt_config), ABI guard */
@@ -174,7 +177,8 @@ typedef enum rtpt_plane {
                                jittered primary ray of rtpt_raytrace, only if enabled */
   RTPT_PLANE_MOMENTS = 13,  /* extension RTPT_FLAG_EXT_VARIANCE: (m1, m2, history length, variance) float4 */
   RTPT_PLANE_VARIANCE = 14, /* extension: f32 variance written by the last filter iteration (or by the moments pass) */
-  RTPT_PLANE_COUNT = 15
+  RTPT_PLANE_MOMENTS_PREV = 15, /* extension: the previous frame's moments (what this frame's accumulation reads) */
+  RTPT_PLANE_COUNT = 16
 } rtpt_plane;
 
 typedef struct rtpt_ctx rtpt_ctx;
@@ -222,6 +226,12 @@ int rtpt_plane_bytes(const rtpt_ctx* ctx, rtpt_plane which, size_t* bytes);
  * [row_begin,row_end) and registers it here; the final pass then reads history from it instead of
  * the context's own PREVIOUS plane.  NULL returns to the PREVIOUS plane. */
 int rtpt_set_external_history(rtpt_ctx* ctx, const void* device_ptr, uint32_t row_begin, uint32_t row_end);
+
+/* The same for the other two per-pixel planes of the previous frame that a strip reads at reprojected pixels: the id
+ * plane (RTPT_FLAG_EXT_DISOCCLUSION, RTPT_FLAG_EXT_VARIANCE) and the moment plane (RTPT_FLAG_EXT_VARIANCE; may be NULL
+ * otherwise).  Both buffers cover frame rows [row_begin,row_end), u32 and float4 per pixel.  NULL, NULL returns to the
+ * context's own planes. */
+int rtpt_set_external_guides(rtpt_ctx* ctx, const void* prev_vis, const void* moments_prev, uint32_t row_begin, uint32_t row_end);
 
 /* Two frames in flight.  The reference serialises everything with vkQueueWaitIdle (main.cpp:110-111); the only
  * dependency between consecutive frames of this path is the final pass's history fetch, so a host may render

@@ -31,7 +31,7 @@ DEBUG_HIT_ID, DEBUG_PREV_PIXEL = 0x1, 0x2
 # rtpt_plane
 (PLANE_IMAGE, PLANE_FILTERED, PLANE_PREVIOUS, PLANE_WORLDPOS, PLANE_GRADIENT, PLANE_DEPTH, PLANE_VIS_ID,
  PLANE_PREV_VIS_ID, PLANE_LUT, PLANE_LUT_PREV, PLANE_PREV_PIXEL, PLANE_RAYCOUNT, PLANE_HIT_ID, PLANE_MOMENTS,
- PLANE_VARIANCE) = range(15)
+ PLANE_VARIANCE, PLANE_MOMENTS_PREV) = range(16)
 # rtpt_kernel_id
 K_GBUFFER, K_LUT, K_GRADIENT, K_PATHTRACE, K_ATROUS, K_ATROUS_FINAL, K_ATROUS_CHAIN, K_ATROUS_CHAIN_FINAL, K_COUNT = range(9)
 KERNEL_NAMES = ["k_gbuffer", "k_lut", "k_gradient", "k_pathtrace", "k_atrous", "k_atrous_final", "k_atrous_chain",
@@ -94,7 +94,7 @@ SYMBOLS = [
     "rtpt_raytrace", "rtpt_temporal_filter", "rtpt_end_frame", "rtpt_sync", "rtpt_readback", "rtpt_set_plane",
     "rtpt_reset_counters", "rtpt_set_count_rows", "rtpt_enable_debug", "rtpt_timing_enable", "rtpt_timing_collect", "rtpt_kernel_name",
     "rtpt_selftest_math", "rtpt_selftest_trace", "rtpt_util_look_at", "rtpt_util_perspective", "rtpt_util_load_obj", "rtpt_util_bvh_check",
-    "rtpt_scene_set_materials", "rtpt_util_load_obj_materials", "rtpt_util_bvh_refit_check", "rtpt_util_clusters",
+    "rtpt_scene_set_materials", "rtpt_util_load_obj_materials", "rtpt_util_bvh_refit_check", "rtpt_util_clusters", "rtpt_set_external_guides",
 ]
 
 _lib = None
@@ -126,6 +126,7 @@ def load() -> C.CDLL:
         "rtpt_plane_bytes": [vp, C.c_int, C.POINTER(sz)],
         "rtpt_set_external_history": [vp, vp, u32, u32],
         "rtpt_stream_wait": [vp, vp],
+        "rtpt_set_external_guides": [vp, vp, vp, u32, u32],
         "rtpt_scene_upload": [vp, vp, u32, vp, u32, vp, u32],
         "rtpt_gbuffer": [vp, C.POINTER(Ubo), u32, u32],
         "rtpt_temporal_gradient": [vp, C.POINTER(PushConstants), u32, u32],
@@ -218,6 +219,7 @@ _PLANE_DTYPE = {
     PLANE_WORLDPOS: (np.float32, 4), PLANE_GRADIENT: (np.float32, 4), PLANE_DEPTH: (np.float32, 1),
     PLANE_VIS_ID: (np.uint32, 1), PLANE_PREV_VIS_ID: (np.uint32, 1), PLANE_PREV_PIXEL: (np.int32, 2),
     PLANE_HIT_ID: (np.uint32, 1), PLANE_MOMENTS: (np.float32, 4), PLANE_VARIANCE: (np.float32, 1),
+    PLANE_MOMENTS_PREV: (np.float32, 4),
 }
 
 
@@ -278,6 +280,15 @@ class Context:
 
     def set_external_history(self, device_ptr: int | None, row_begin: int = 0, row_end: int = 0):
         _check(self._lib.rtpt_set_external_history(self._h, C.c_void_p(device_ptr or 0), row_begin, row_end))
+
+    def set_external_guides(self, prev_vis_ptr: int | None, moments_ptr: int | None, row_begin: int = 0, row_end: int = 0):
+        """previous frame's id (u32) and moment (float4) rows [row_begin,row_end) gathered across strips; None, None:
+        the context's own planes"""
+        _check(self._lib.rtpt_set_external_guides(self._h, C.c_void_p(prev_vis_ptr or 0), C.c_void_p(moments_ptr or 0),
+                                                  row_begin, row_end))
+
+    def plane_dtype(self, which: int):
+        return _PLANE_DTYPE[which]
 
     def stream_wait(self, other: "Context"):
         """work submitted to this context from now on starts after everything submitted to `other` so far"""

@@ -100,6 +100,38 @@ class HipBackend:
                 return t[y0 - base:y1 - base]
         raise RuntimeError("colour plane is not one of the bound torch tensors")
 
+    # previous-frame guide planes (ids, moments) of the extension modes, gathered like the history ---------------
+    def guide_rows(self, plane: int, y0: int, y1: int):
+        """torch view (no copy) of frame rows [y0,y1) of a context-owned per-pixel plane, through the device pointer"""
+        import torch
+        dt, ch = self.ctx.plane_dtype(plane)
+        base = self.ctx.cfg.row_begin
+        ptr = self.ctx.plane_ptr(plane) + (y0 - base) * self.width * ch * 4
+        shape = (y1 - y0, self.width) + ((ch,) if ch > 1 else ())
+
+        class _Dev:  # the CUDA array interface is how torch adopts foreign device memory (ROCm included)
+            __cuda_array_interface__ = {"shape": shape, "typestr": "<f4" if dt == np.float32 else "<i4",
+                                        "data": (ptr, False), "version": 2}   # ids travel as int32 bit patterns
+        return torch.as_tensor(_Dev(), device=torch.device("cuda", torch.cuda.current_device()))
+
+    def guides_full(self):
+        """(ids [H, W] int32, moments [H, W, 4] f32) buffers the other strips' rows are gathered into"""
+        if getattr(self, "_guides_full", None) is None:
+            import torch
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self._guides_full = (torch.zeros((self.height, self.width), dtype=torch.int32, device=dev),
+                                 torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=dev))
+        return self._guides_full
+
+    def use_external_guides(self, on: bool, rows=None, moments=True):
+        if on:
+            ids, mom = self.guides_full()
+            a, b = rows
+            self.ctx.set_external_guides(ids.data_ptr() + a * self.width * 4,
+                                         mom.data_ptr() + a * self.width * 16 if moments else None, a, b)
+        else:
+            self.ctx.set_external_guides(None, None)
+
     # history all-gather support (multi-rank, moving camera) ----------------------------------
     def history_full(self):
         """torch tensor [H, W, 4] that receives every rank's final strip (allocated on first use)"""
@@ -374,6 +406,8 @@ class PathTracingApplication:
         """main.cpp:1255-1306: k = 1..N, ping-pong by parity; one ABI call per iteration."""
         pc = self.pushConstants
         pc.maxWaveletIteration = self.maxWaveletIteration  # :1258
+        if self.plan.world > 1 and (self.plan.ext_flags & (abi.FLAG_EXT_VARIANCE | abi.FLAG_EXT_DISOCCLUSION)):
+            self._prepare_guides()
         for k in range(1, self.maxWaveletIteration + 1):   # :1259
             pc.waveletIteration = k
             if self.plan.world > 1 and self.plan.mode == "exchange":
@@ -408,9 +442,31 @@ class PathTracingApplication:
                  for r in range(R)]
         full = be.history_full()
         self.history_bytes_sent = exchange_history(self.plan, needs, lambda a, b: be.color_rows(abi.PLANE_PREVIOUS, a, b),
-                                                   full, self.group)
+                                                   full, self.group) + getattr(self, "_guide_bytes", 0)
         self.history_rows = needs[self.plan.rank]
         be.use_external_history(True, needs[self.plan.rank])
+
+    def _prepare_guides(self):
+        """RTPT_FLAG_EXT_VARIANCE / _DISOCCLUSION on strips: the moment accumulation (before iteration 1) and the
+        disocclusion test (final pass) read the PREVIOUS frame's id and moment planes at reprojected pixels.  Every
+        rank holds them for its stored rows; under camera motion the rows a rank's stored pixels can reach beyond
+        that are gathered from their owners, with the same bound and plan as the history image."""
+        be = self.backend
+        self._guide_bytes = 0
+        if self.frameCount == 0 or self._camera_static():
+            be.use_external_guides(False)
+            return
+        from .strips import exchange_history
+        H, R = self.plan.height, self.plan.world
+        plans = [StripPlan(H, R, r, self.plan.iterations, self.plan.mode, self.plan.ext_flags) for r in range(R)]
+        needs = [reprojection_rows(self.ubo, self.render_width, H, p.stored, self.sceneBounds, self.z_near) for p in plans]
+        ids, mom = be.guides_full()
+        variance = bool(self.plan.ext_flags & abi.FLAG_EXT_VARIANCE)
+        sent = exchange_history(self.plan, needs, lambda a, b: be.guide_rows(abi.PLANE_PREV_VIS_ID, a, b), ids, self.group)
+        if variance:
+            sent += exchange_history(self.plan, needs, lambda a, b: be.guide_rows(abi.PLANE_MOMENTS_PREV, a, b), mom, self.group)
+        self._guide_bytes = sent
+        be.use_external_guides(True, needs[self.plan.rank], moments=variance)
 
     def drawScene(self, keys=()):
         """main.cpp:1090-1113."""
@@ -436,6 +492,9 @@ def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode=
     """createBuffers + loadMesh + buildAccelerationStructure for one rank.  `mesh` = (xyz, idx) replaces
     the OBJ (synthetic scenes of scenes.py)."""
     plan = StripPlan(height, world, rank, iterations, mode, flags & abi.FLAG_EXT_MASK)
+    if world > 1 and (flags & abi.FLAG_EXT_VARIANCE) and mode != "redundant":
+        raise ValueError("RTPT_FLAG_EXT_VARIANCE on strips needs the redundant halo mode (every stored row is traced, so "
+                         "its moments exist; the exchange mode would have to ship variance and moment halos per iteration)")
     if torch_planes is None:
         torch_planes = world > 1  # halo exchange and the history all-gather move rows of torch-owned planes
     def one():

@@ -109,6 +109,10 @@ struct rtpt_ctx {
   int final_y0 = 0, final_y1 = 0;
   uint32_t debug_mask = 0;
   const void* ext_history = nullptr;  // rtpt_set_external_history
+  const void* ext_prev_vis = nullptr; // rtpt_set_external_guides: previous frame's ids / moments gathered across strips
+  const void* ext_moments = nullptr;
+  int ext_guides_y0 = 0, ext_guides_y1 = 0;
+  int guides_y0 = 0, guides_y1 = 0;   // rows of the context's own previous id / moment planes that hold a previous frame
   hipEvent_t handoff_event = nullptr; // rtpt_stream_wait(x, this): recorded on this context's stream
   int ext_hist_y0 = 0, ext_hist_y1 = 0;
   int count_y0 = 0, count_y1 = 0;  // rows counted into RAYCOUNT
@@ -178,6 +182,7 @@ Buf* plane_buf(rtpt_ctx* c, rtpt_plane which) {
     case RTPT_PLANE_RAYCOUNT: return &c->raycount;
     case RTPT_PLANE_HIT_ID: return &c->hit_id;
     case RTPT_PLANE_MOMENTS: return &c->moments[c->moments_cur];
+    case RTPT_PLANE_MOMENTS_PREV: return &c->moments[c->moments_cur ^ 1];
     case RTPT_PLANE_VARIANCE: return &c->variance[c->variance_last];
     default: return nullptr;
   }
@@ -196,7 +201,8 @@ size_t plane_size(const rtpt_ctx* c, rtpt_plane which) {
     case RTPT_PLANE_PREV_VIS_ID:
     case RTPT_PLANE_HIT_ID:
     case RTPT_PLANE_VARIANCE: return px * 4;
-    case RTPT_PLANE_MOMENTS: return px * 16;
+    case RTPT_PLANE_MOMENTS:
+    case RTPT_PLANE_MOMENTS_PREV: return px * 16;
     case RTPT_PLANE_PREV_PIXEL: return px * 8;
     case RTPT_PLANE_LUT:
     case RTPT_PLANE_LUT_PREV: return (static_cast<size_t>(c->n_tris) + 1) * sizeof(rtpt_visibility_data);
@@ -404,7 +410,9 @@ static int alloc_planes(rtpt_ctx* c) {
   c->image_alias = false;
   c->hist_y0 = c->hist_y1 = 0;
   c->final_y0 = c->final_y1 = 0;
+  c->guides_y0 = c->guides_y1 = 0;
   c->ext_history = nullptr;
+  c->ext_prev_vis = c->ext_moments = nullptr;
   c->count_y0 = static_cast<int>(c->cfg.row_begin);
   c->count_y1 = static_cast<int>(c->cfg.row_end);
   return RTPT_OK;
@@ -416,8 +424,6 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   if (cfg->struct_size != sizeof(rtpt_config)) return fail(RTPT_E_INVALID, "rtpt_config.struct_size mismatch (ABI)");
   if (cfg->width == 0 || cfg->height == 0 || cfg->row_begin >= cfg->row_end || cfg->row_end > cfg->height)
     return fail(RTPT_E_INVALID, "bad frame / row range");
-  if ((cfg->flags & RTPT_FLAG_EXT_VARIANCE) && (cfg->row_begin != 0 || cfg->row_end != cfg->height))
-    return fail(RTPT_E_INVALID, "RTPT_FLAG_EXT_VARIANCE needs a whole-frame context");
   if (cfg->max_segments == 0 || cfg->samples_per_pixel == 0 || cfg->sigma_n < 1)
     return fail(RTPT_E_INVALID, "max_segments, samples_per_pixel and sigma_n must be >= 1");
   int ndev = 0;
@@ -575,6 +581,23 @@ int rtpt_set_external_history(rtpt_ctx* c, const void* device_ptr, uint32_t row_
   c->ext_history = device_ptr;
   c->ext_hist_y0 = static_cast<int>(row_begin);
   c->ext_hist_y1 = static_cast<int>(row_end);
+  return RTPT_OK;
+}
+
+int rtpt_set_external_guides(rtpt_ctx* c, const void* prev_vis, const void* moments_prev, uint32_t row_begin, uint32_t row_end) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  if (!prev_vis && !moments_prev) {
+    c->ext_prev_vis = c->ext_moments = nullptr;
+    return RTPT_OK;
+  }
+  if (!prev_vis) return fail(RTPT_E_INVALID, "the previous id plane is needed whenever guides are registered");
+  if (row_begin >= row_end || row_end > c->cfg.height) return fail(RTPT_E_INVALID, "bad guide row range");
+  if ((reinterpret_cast<uintptr_t>(prev_vis) & 3u) || (reinterpret_cast<uintptr_t>(moments_prev) & 15u))
+    return fail(RTPT_E_INVALID, "guide buffers must be 4- / 16-byte aligned");
+  c->ext_prev_vis = prev_vis;
+  c->ext_moments = moments_prev;
+  c->ext_guides_y0 = static_cast<int>(row_begin);
+  c->ext_guides_y1 = static_cast<int>(row_end);
   return RTPT_OK;
 }
 
@@ -1223,8 +1246,15 @@ int filter_launch(rtpt_ctx* c, const FilterCall& f, int levels) {
     a.hist_y1 = c->hist_y1;
     a.gradient = static_cast<const float4*>(c->gradient.ptr);
     a.prev_vis = static_cast<const uint32_t*>(c->vis[c->vis_cur ^ 1].ptr);
-    a.pvis_y0 = c->hist_y0;
-    a.pvis_y1 = c->hist_y1;
+    a.pvis_y0 = c->guides_y0;
+    a.pvis_y1 = c->guides_y1;
+    a.pvis_row_base = static_cast<int32_t>(c->cfg.row_begin);
+    if (c->ext_prev_vis) {  // gathered across strips
+      a.prev_vis = static_cast<const uint32_t*>(c->ext_prev_vis);
+      a.pvis_y0 = c->ext_guides_y0;
+      a.pvis_y1 = c->ext_guides_y1;
+      a.pvis_row_base = c->ext_guides_y0;
+    }
     if (c->ext_history) {  // all-gathered previous frame (multi-GPU strips)
       a.history = static_cast<const float4*>(c->ext_history);
       a.hist_row_base = c->ext_hist_y0;
@@ -1246,6 +1276,15 @@ int filter_launch(rtpt_ctx* c, const FilterCall& f, int levels) {
       rt::exact::mat_mul(ubo->projPrev, ubo->viewPrev, m.PVprev);
       m.prev_vis = static_cast<const uint32_t*>(c->vis[c->vis_cur ^ 1].ptr);
       m.moments_prev = static_cast<const float4*>(c->moments[c->moments_cur ^ 1].ptr);
+      m.hist_row_base = static_cast<int32_t>(c->cfg.row_begin);
+      m.hist_y0 = c->guides_y0;
+      m.hist_y1 = c->guides_y1;
+      if (c->ext_prev_vis && c->ext_moments) {  // gathered across strips (rtpt_set_external_guides)
+        m.prev_vis = static_cast<const uint32_t*>(c->ext_prev_vis);
+        m.moments_prev = static_cast<const float4*>(c->ext_moments);
+        m.hist_row_base = m.hist_y0 = c->ext_guides_y0;
+        m.hist_y1 = c->ext_guides_y1;
+      }
       m.moments_out = static_cast<float4*>(c->moments[c->moments_cur].ptr);
       m.var_out = static_cast<float*>(c->variance[0].ptr);
       rt::launch_moments(m, c->stream);
@@ -1383,6 +1422,9 @@ int rtpt_end_frame(rtpt_ctx* c) {
   c->image_alias = true;
   c->hist_y0 = c->final_y0;
   c->hist_y1 = c->final_y1;
+  // the id plane (and, with RTPT_FLAG_EXT_VARIANCE, the moment plane) of the frame just ended cover the stored rows
+  c->guides_y0 = static_cast<int>(c->cfg.row_begin);
+  c->guides_y1 = static_cast<int>(c->cfg.row_end);
   // main.cpp:1367 visibilityBuffer -> previousVisibilityBuffer; main.cpp:1372 LUT -> LUTprev
   c->vis_cur ^= 1;
   c->moments_cur ^= 1;
@@ -1447,6 +1489,10 @@ int rtpt_set_plane(rtpt_ctx* c, rtpt_plane which, const void* src, size_t bytes)
   if (which == RTPT_PLANE_PREVIOUS) {
     c->hist_y0 = static_cast<int>(c->cfg.row_begin);
     c->hist_y1 = static_cast<int>(c->cfg.row_end);
+  }
+  if (which == RTPT_PLANE_PREV_VIS_ID || which == RTPT_PLANE_MOMENTS_PREV) {
+    c->guides_y0 = static_cast<int>(c->cfg.row_begin);
+    c->guides_y1 = static_cast<int>(c->cfg.row_end);
   }
   if (which == RTPT_PLANE_LUT_PREV) {
     c->lut_prev_valid = true;

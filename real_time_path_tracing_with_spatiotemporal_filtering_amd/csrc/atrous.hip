@@ -199,8 +199,11 @@ __global__ __launch_bounds__(kThreads) void k_moments(MomentsArgs a) {
   const float lum = luminance(xyz(a.traced[ip]));
   int ppx, ppy;
   reproject_pixel(W, H, a.PVprev, id, xyz(a.worldpos[ip]), a.lut_prev, x, y, ppx, ppy);
-  bool valid = a.frame > 0 && ppx >= 0 && ppx < W && ppy >= 0 && ppy < H;
-  const size_t iq = valid ? static_cast<size_t>(ppy - a.g.row_base) * W + ppx : 0;
+  // the previous frame's id and moment planes hold frame rows [hist_y0, hist_y1) from hist_row_base on: the context's
+  // own rows, or the bands gathered from the other strips (rtpt_set_external_guides); inside the frame but outside
+  // those rows cannot happen when the host registered the rows the strip's pixels can reach
+  bool valid = a.frame > 0 && ppx >= 0 && ppx < W && ppy >= 0 && ppy < H && ppy >= a.hist_y0 && ppy < a.hist_y1;
+  const size_t iq = valid ? static_cast<size_t>(ppy - a.hist_row_base) * W + ppx : 0;
   if (valid) valid = a.prev_vis[iq] == id;
   float m1 = lum, m2 = lum * lum, n = 1.0f;
   if (valid) {
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void k_atrous_ext(AtrousArgs a) {
   if (use_history && (a.ext & kExtDisocclusion)) {
     // same primitive at the reprojected pixel; rows this context does not hold count as disoccluded
     use_history = inside && ppy >= a.pvis_y0 && ppy < a.pvis_y1 &&
-                  a.prev_vis[static_cast<size_t>(ppy - a.g.row_base) * W + ppx] == idp;
+                  a.prev_vis[static_cast<size_t>(ppy - a.pvis_row_base) * W + ppx] == idp;
   }
   f3 blend = filtered;  // :258
   if (use_history) {

@@ -185,8 +185,8 @@ struct AtrousArgs {
   uint32_t ext;
   int32_t stride;                 // tap stride (k, or 2^(k-1) with RTPT_FLAG_EXT_POW2_STRIDE)
   const float4* gradient;         // K1 output (adaptive alpha)
-  const uint32_t* prev_vis;       // previous frame's id plane, rows [pvis_y0,pvis_y1) valid, stored from g.row_base
-  int32_t pvis_y0, pvis_y1;
+  const uint32_t* prev_vis;       // previous frame's id plane, rows [pvis_y0,pvis_y1) valid, stored from pvis_row_base
+  int32_t pvis_y0, pvis_y1, pvis_row_base;
   const float* var_in;            // RTPT_FLAG_EXT_VARIANCE: per-pixel luminance variance read by this iteration
   float* var_out;                 //                         ... and the filtered variance it writes
 };
@@ -201,8 +201,9 @@ struct MomentsArgs {
   const float4* worldpos;
   const float4* lut_prev;
   float PVprev[16];
-  const uint32_t* prev_vis;
+  const uint32_t* prev_vis;     // previous frame's ids and moments: frame rows [hist_y0, hist_y1), stored from hist_row_base
   const float4* moments_prev;
+  int32_t hist_row_base, hist_y0, hist_y1;
   float4* moments_out;  // (m1, m2, n, var)
   float* var_out;
 };

@@ -1,0 +1,33 @@
+"""worker of tests/test_bench_gpu.py::test_gloo_ranks_on_one_gpu_*: one rank of a multi-rank PathTracingApplication on
+GPU 0 (gloo carries the messages: RCCL refuses two ranks on one device), dumping the rows it owns of every frame.
+python -m torch.distributed.run --nproc-per-node R tests/strip_worker.py <out_dir> <mode> <flags> <keys,keys,...> W H"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+torch.cuda.set_device(0)
+from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi  # noqa: E402
+from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app  # noqa: E402
+
+out_dir, mode, flags, keys, W, H = sys.argv[1], sys.argv[2], int(sys.argv[3], 0), sys.argv[4].split(","), int(sys.argv[5]), int(sys.argv[6])
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+app = make_app(W, H, max_segments=3, iterations=3, rank=rank, world=world, mode=mode, flags=flags, torch_planes=world > 1)
+frames, sent = [], 0
+for k in keys:
+    app.drawScene(tuple(k))
+    o0, o1 = app.plan.own
+    frames.append(app.backend.readback_rows(abi.PLANE_PREVIOUS, o0, o1).copy())
+    sent += app.history_bytes_sent
+np.savez(os.path.join(out_dir, f"w{world}_r{rank}.npz"), *frames, rays=np.array([app.backend.ctx.raycount()]), sent=np.array([sent]))
+app.backend.close()
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()

@@ -50,3 +50,33 @@ def test_two_rank_rehearsal_counts_the_same_rays(hip_lib, halo):
     assert two["n_gpus"] == 2 and halo in two["config"]["parallelism"]
     # the frame sequence is deterministic (RNG seeded by pixel + frame) and both runs render the same frame numbers
     assert two["rays_per_frame"] == one["rays_per_frame"]
+
+
+@pytest.mark.parametrize("mode,flags", [("redundant", 0), ("exchange", 0), ("redundant", 0x100), ("redundant", 0x81)])
+def test_gloo_ranks_on_one_gpu_reproduce_the_single_context_frames(hip_lib, tmp_path, mode, flags):
+    """the Python host's multi-rank path on DEVICE memory — halo rows, the history bands bounded by the reprojection
+    reach, and (extension flags 0x100 variance, 0x80 disocclusion) the previous frame's id / moment bands — with three
+    ranks on GPU 0 and gloo as the carrier, vertical camera moves in the script: every rank's rows of every frame equal
+    the single-context frames bit for bit, and only bands travelled (not whole frames)"""
+    import numpy as np
+    W, H, keys = 144, 150, ",E,J,QA,,E"
+    args = [str(tmp_path), mode, hex(flags), keys, str(W), str(H)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    worker = os.path.join(ROOT, "tests", "strip_worker.py")
+    out = subprocess.run([sys.executable, worker] + args, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
+                          "127.0.0.1", "--master-port", str(_port()), worker] + args,
+                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ref = np.load(tmp_path / "w1_r0.npz")
+    parts = [np.load(tmp_path / f"w3_r{r}.npz") for r in range(3)]
+    n_frames = len(keys.split(","))
+    for f in range(n_frames):
+        got = np.concatenate([p[f"arr_{f}"] for p in parts], axis=0)
+        assert got.tobytes() == ref[f"arr_{f}"].tobytes(), (mode, hex(flags), f)
+    assert sum(int(p["rays"][0]) for p in parts) == int(ref["rays"][0])
+    sent = sum(int(p["sent"][0]) for p in parts)
+    moved_frames = 3   # E, QA, E
+    planes = 1 + (flags & 0x100 != 0) * 1.25 + (flags & 0x180 != 0 and not flags & 0x100) * 0.25
+    assert 0 < sent < moved_frames * 3 * H * W * 16 * planes, "bands, not a whole frame to every rank"
