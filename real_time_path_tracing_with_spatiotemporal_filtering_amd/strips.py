@@ -121,6 +121,33 @@ class StripPlan:
         return out
 
 
+def _post(sends, recvs, group=None):
+    """point-to-point exchange of [(tensor, peer)] lists.  RCCL ("nccl") takes device tensors and orders the transfers
+    on the current stream.  gloo — the CPU tests, and the rehearsal of several ranks on ONE GPU, where RCCL refuses to
+    run — only moves host memory: handing it a device tensor makes its TCP transport read the allocation through the
+    PCIe aperture with no stream ordering at all (a race that returns stale rows), so device tensors are staged
+    through host copies made and consumed on the current stream."""
+    import torch
+    import torch.distributed as dist
+    if not sends and not recvs:
+        return
+    staged = dist.get_backend(group) == "gloo" and any(t.is_cuda for t, _ in list(sends) + list(recvs))
+    ops, landing = [], []
+    for t, peer in sends:
+        ops.append(dist.P2POp(dist.isend, t.cpu() if staged and t.is_cuda else t, peer, group))  # .cpu() waits for the stream
+    for t, peer in recvs:
+        if staged and t.is_cuda:
+            h = torch.empty(t.shape, dtype=t.dtype, device="cpu")
+            landing.append((t, h))
+            ops.append(dist.P2POp(dist.irecv, h, peer, group))
+        else:
+            ops.append(dist.P2POp(dist.irecv, t, peer, group))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    for t, h in landing:
+        t.copy_(h)
+
+
 def exchange_halo(plan: StripPlan, k: int, rows_view, group=None):
     """Exchange the k-row colour halos for iteration k.
 
@@ -132,14 +159,8 @@ def exchange_halo(plan: StripPlan, k: int, rows_view, group=None):
     todo = plan.exchange_rows(k)
     if not todo:
         return
-    import torch.distributed as dist
-
-    ops = []
-    for peer, send_rows, recv_rows in todo:
-        ops.append(dist.P2POp(dist.isend, rows_view(*send_rows), peer, group))
-        ops.append(dist.P2POp(dist.irecv, rows_view(*recv_rows), peer, group))
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
+    _post([(rows_view(*send_rows), peer) for peer, send_rows, _ in todo],
+          [(rows_view(*recv_rows), peer) for peer, _, recv_rows in todo], group)
 
 
 # ------------------------------------------------------------------------------------------
@@ -215,21 +236,18 @@ def history_exchange_plan(height: int, world: int, needs):
 def exchange_history(plan: StripPlan, needs, prev_rows_view, full, group=None) -> int:
     """Move the previous frame's rows between ranks so that `full` (a [H, W, 4] tensor on every rank) holds rows
     needs[plan.rank] of it; `prev_rows_view(y0, y1)` views rows of this rank's finished strip.  Returns bytes sent."""
-    import torch.distributed as dist
     r = plan.rank
     o0, o1 = plan.own
     a, b = max(o0, needs[r][0]), min(o1, needs[r][1])
     if b > a:
         full[a:b].copy_(prev_rows_view(a, b))
-    ops, sent = [], 0
+    sends, recvs, sent = [], [], 0
     for peer, what, (y0, y1) in history_exchange_plan(plan.height, plan.world, needs)[r]:
         if what == "send":
             t = prev_rows_view(y0, y1)
             sent += t.numel() * t.element_size()
-            ops.append(dist.P2POp(dist.isend, t, peer, group))
+            sends.append((t, peer))
         else:
-            ops.append(dist.P2POp(dist.irecv, full[y0:y1], peer, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+            recvs.append((full[y0:y1], peer))
+    _post(sends, recvs, group)
     return sent
