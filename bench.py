@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # are CHAIN_LEVELS x 40 — the work 8(d) prices — although the intermediate image never reaches HBM.
 CHAIN_LEVELS = 2
 BYTES_PER_PX = {"k_atrous": 40, "k_atrous_final": 72, "k_atrous_chain": 40 * CHAIN_LEVELS, "k_gradient": 36, "k_gbuffer": 24,
-                "k_pathtrace": 16}
+                "k_gbuffer_gradient": 24 + 36, "k_pathtrace": 16}
 # bytes the kernel as built MUST move per pixel (rgbd cells: depth rides in alpha, so 16 + 4 read and 16 written; the
 # chain reads its input once and writes its last level once; the per-pixel-normal variant of large scenes stages 16 more)
 REQUIRED_PER_PX = {"k_atrous": 36, "k_atrous_final": 68, "k_atrous_chain": 36}
@@ -141,7 +141,8 @@ def kernel_report(kern, wl, plan, steps):
     W = wl["width"]
     steps = max(1, kern.get("k_pathtrace", (0.0, steps))[1])  # sampled frames = launches of the once-per-frame kernel
     rows = {
-        "k_gbuffer": plan.gbuffer_rows(), "k_gradient": plan.gradient_rows(), "k_pathtrace": plan.raytrace_rows(),
+        "k_gbuffer": plan.gbuffer_rows(), "k_gbuffer_gradient": plan.gbuffer_rows(), "k_gradient": plan.gradient_rows(),
+        "k_pathtrace": plan.raytrace_rows(),
         "k_atrous_final": plan.filter_rows(wl["iterations"]),
     }
     out = {}

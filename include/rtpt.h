@@ -106,9 +106,10 @@ typedef struct rtpt_visibility_data {
                                              per secondary ray on the Cornell box).  Same image; measured SLOWER than the
                                              default (4K: 566 vs 500 us) — the per-ray queue traffic and bookkeeping cost
                                              more VALU issue than the skipped tests save — so it is opt-in (A/B switch) */
-#define RTPT_FLAG_NO_FILTER_FUSION 0x400u /* K3: launch every rtpt_temporal_filter call at once, one kernel per
-                                             iteration, instead of recording the frame's calls and chaining
-                                             consecutive iterations into one launch (A/B switch; same pixels) */
+#define RTPT_FLAG_NO_FILTER_FUSION 0x400u /* launch every pass when it is called, one kernel per call, instead of
+                                             recording rtpt_temporal_filter's calls of a frame (consecutive iterations
+                                             then run chained in one launch) and rtpt_gbuffer (which runs in one launch
+                                             with the rtpt_temporal_gradient that follows it) (A/B switch; same pixels) */
 
 /* Extension modes — NOT reference behaviour, default off.  They switch on the pieces of the textbook
  * A-SVGF that the reference declares but leaves unused; any of them routes K3 to a
@@ -272,7 +273,9 @@ int rtpt_scene_set_materials(rtpt_ctx* ctx, const uint32_t* tri_material, uint32
  * refit and the tables are rebuilt before the pass runs, and rtpt_raytrace traces the posed scene too.  It must be
  * affine and invertible.  LUT_PREV keeps the previous frame's pose, which is what K1 and the reprojection read. */
 int rtpt_gbuffer(rtpt_ctx* ctx, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1);
-/* computeTemporalGradient (main.cpp:1201-1220; temporalGradient.comp.glsl:104-172) */
+/* computeTemporalGradient (main.cpp:1201-1220; temporalGradient.comp.glsl:104-172).  Called right behind rtpt_gbuffer
+ * (the reference's order, main.cpp:1105-1106) for rows that call covered, the two run as ONE launch: rtpt_gbuffer records
+ * its dispatch, and every entry point other than this one launches it first, alone. */
 int rtpt_temporal_gradient(rtpt_ctx* ctx, const rtpt_push_constants* pc, uint32_t y0, uint32_t y1);
 /* drawSceneToImage (main.cpp:1222-1253; raytrace.comp.glsl:273-344) */
 int rtpt_raytrace(rtpt_ctx* ctx, const rtpt_push_constants* pc, uint32_t y0, uint32_t y1);
@@ -328,7 +331,8 @@ typedef enum rtpt_kernel_id {
   RTPT_K_ATROUS_FINAL = 5,
   RTPT_K_ATROUS_CHAIN = 6,       /* several consecutive iterations k < N in one launch (intermediates in LDS) */
   RTPT_K_ATROUS_CHAIN_FINAL = 7, /* ... ending in the final pass */
-  RTPT_K_COUNT = 8
+  RTPT_K_GBUFFER_GRADIENT = 8,   /* K0 and K1 in one launch (rtpt_temporal_gradient right behind rtpt_gbuffer) */
+  RTPT_K_COUNT = 9
 } rtpt_kernel_id;
 int rtpt_timing_enable(rtpt_ctx* ctx, int enable);
 int rtpt_timing_collect(rtpt_ctx* ctx, double ms_sum[RTPT_K_COUNT], uint32_t launches[RTPT_K_COUNT]);

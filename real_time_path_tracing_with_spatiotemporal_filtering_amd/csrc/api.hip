@@ -117,6 +117,9 @@ struct rtpt_ctx {
   int ext_hist_y0 = 0, ext_hist_y1 = 0;
   int count_y0 = 0, count_y1 = 0;  // rows counted into RAYCOUNT
 
+  // K0 recorded by rtpt_gbuffer: launched together with K1 when rtpt_temporal_gradient follows at once, alone otherwise
+  rt::GbufferArgs pending_gb{};
+  bool pending_gb_valid = false;
   // K3 iterations recorded by rtpt_temporal_filter and not launched yet (see filter_flush)
   std::vector<FilterCall> pending;
   int chain_max = 2;        // iterations per chained launch (1 = never chain)
@@ -142,10 +145,12 @@ namespace {
 
 // K3 iterations recorded by rtpt_temporal_filter are launched before anything else looks at or changes the planes
 int filter_flush(rtpt_ctx* c, bool fuse);
-#define FLUSH_FILTER(c)                          \
-  do {                                           \
-    int rcf_ = filter_flush((c), false);         \
-    if (rcf_) return rcf_;                       \
+int gbuffer_flush(rtpt_ctx* c);
+#define FLUSH_FILTER(c)                              \
+  do {                                               \
+    int rcf_ = gbuffer_flush(c);                     \
+    if (rcf_ == RTPT_OK) rcf_ = filter_flush((c), false); \
+    if (rcf_) return rcf_;                           \
   } while (0)
 
 int alloc_buf(Buf& b, size_t bytes) {
@@ -993,12 +998,38 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
     }
     c->normals_frame = c->frames_ended;
   }
+  a.grad_on = 0;
+  a.grad_y0 = a.grad_y1 = 0;
+  a.lut = a.lut_prev = nullptr;
+  a.grad = nullptr;
+  for (int i = 0; i < 3; i++) a.g_cam[i] = a.g_light[i] = a.g_light_prev[i] = a.g_color[i] = a.g_color_prev[i] = 0.0f;
+  if (!(c->cfg.flags & RTPT_FLAG_NO_FILTER_FUSION)) {
+    // recorded: rtpt_temporal_gradient normally follows at once (main.cpp:1105-1106) and the two run as one launch;
+    // any other entry point launches it first
+    c->pending_gb = a;
+    c->pending_gb_valid = true;
+    return RTPT_OK;
+  }
   {
     Timer tm(c, RTPT_K_GBUFFER);
     rt::launch_gbuffer(a, c->stream);
   }
   return launch_check("gbuffer");
 }
+
+namespace {
+int gbuffer_flush(rtpt_ctx* c) {
+  if (!c->pending_gb_valid) return RTPT_OK;
+  c->pending_gb_valid = false;
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail(RTPT_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  {
+    Timer tm(c, RTPT_K_GBUFFER);
+    rt::launch_gbuffer(c->pending_gb, c->stream);
+  }
+  return launch_check("gbuffer");
+}
+}  // namespace
 
 // ------------------------------------------------------------------------------------------ K1
 int rtpt_temporal_gradient(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint32_t y1) {
@@ -1007,6 +1038,31 @@ int rtpt_temporal_gradient(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t 
   int rc = check_rows(c, y0, y1);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
+  if (c->pending_gb_valid && static_cast<int32_t>(y0) >= c->pending_gb.g.y0 && static_cast<int32_t>(y1) <= c->pending_gb.g.y1) {
+    // K0 + K1 in one launch: K1's inputs (id, world position) are K0's outputs for the same pixel
+    rt::GbufferArgs& g = c->pending_gb;
+    g.grad_on = 1;
+    g.grad_y0 = static_cast<int32_t>(y0);
+    g.grad_y1 = static_cast<int32_t>(y1);
+    for (int i = 0; i < 3; i++) {
+      g.g_cam[i] = pc->cameraPos[i];
+      g.g_light[i] = pc->lightPos[i];
+      g.g_light_prev[i] = pc->lightPosPrev[i];
+      g.g_color[i] = pc->currentCameraColor[i];
+      g.g_color_prev[i] = pc->previousCameraColor[i];
+    }
+    g.lut = static_cast<const float4*>(c->lut[c->lut_cur].ptr);
+    g.lut_prev = static_cast<const float4*>(c->lut[c->lut_cur ^ 1].ptr);
+    g.grad = static_cast<float4*>(c->gradient.ptr);
+    c->pending_gb_valid = false;
+    int rcq = filter_flush(c, false);
+    if (rcq) return rcq;
+    {
+      Timer tm(c, RTPT_K_GBUFFER_GRADIENT);
+      rt::launch_gbuffer(g, c->stream);
+    }
+    return launch_check("gbuffer + temporal_gradient");
+  }
   FLUSH_FILTER(c);
   rt::GradientArgs a;
   a.g = geom(c, y0, y1);
@@ -1557,6 +1613,7 @@ const char* rtpt_kernel_name(rtpt_kernel_id k) {
     case RTPT_K_ATROUS_FINAL: return "k_atrous_final";
     case RTPT_K_ATROUS_CHAIN: return "k_atrous_chain";
     case RTPT_K_ATROUS_CHAIN_FINAL: return "k_atrous_chain_final";
+    case RTPT_K_GBUFFER_GRADIENT: return "k_gbuffer_gradient";
     default: return "?";
   }
 }

@@ -369,8 +369,15 @@ constexpr int kShThreads = 64 * kShWaves;
 // 2^(k-1), passed as a.stride) run in this kernel too — the same comb staging with 2R halo rows per workgroup and 2R*s
 // halo columns per segment, and the arithmetic of k_atrous_ext (h kept per tap, correctly-rounded final division), so
 // the two are bit-identical.  25 taps are 25 LDS reads here instead of 75 global loads per pixel.
+#ifndef RTPT_COMB_MIN_WAVES
+#define RTPT_COMB_MIN_WAVES 0
+#endif
 template <int CWp, bool FINAL, bool EXACT, bool NRM = false, int R = 1, bool EXTA = false>
-__global__ __launch_bounds__(kShThreads) void k_atrous_comb_sh(AtrousArgs a) {
+__global__ __launch_bounds__(kShThreads)
+#if RTPT_COMB_MIN_WAVES
+__attribute__((amdgpu_waves_per_eu(RTPT_COMB_MIN_WAVES)))
+#endif
+void k_atrous_comb_sh(AtrousArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int W = a.g.W, H = a.g.H, k = a.stride;  // a.stride == a.k (main.cpp:1259-1260, :135) unless POW2_STRIDE
   constexpr int rows = kShWaves * kCombM + 2 * R, cells = rows * CWp;  // block-shared rows

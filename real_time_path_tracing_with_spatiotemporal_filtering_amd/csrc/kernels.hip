@@ -335,6 +335,53 @@ __global__ void k_pair_weights(LutArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K1 temporal gradient
+// ------------------------------------------------------------------------------------------
+// temporalGradient.comp.glsl:71-101
+__device__ __forceinline__ f3 phong(f3 p, f3 n, f3 cam, f3 lpos, f3 lcol) {
+  f3 ldir = exact::normalize(lpos - p);
+  f3 ambient = lcol * 0.1f;
+  float diff = glsl_max(exact::dot(n, ldir), 0.0f);
+  f3 diffuse = lcol * diff;
+  f3 vdir = exact::normalize(cam - p);
+  f3 I = -ldir;
+  float two_ndi = 2.0f * exact::dot(n, I);
+  f3 rdir{fmaf_(-two_ndi, n.x, I.x), fmaf_(-two_ndi, n.y, I.y), fmaf_(-two_ndi, n.z, I.z)};
+  float spec = exact::powi(glsl_max(exact::dot(vdir, rdir), 0.0f), 128);
+  f3 specular = lcol * (0.5f * spec);
+  return ((ambient + diffuse) + specular) * 0.7f;
+}
+
+// temporalGradient.comp.glsl:128-167 for one pixel: relative change of the Phong shade of the visible surface point between
+// the previous and the current light (and pose)
+__device__ __forceinline__ float gradient_lambda(uint32_t id, f3 wp, const float4* lut, const float4* lut_prev, f3 cam, f3 light,
+                                                 f3 light_prev, f3 color, f3 color_prev) {
+  if (id == 0) return 0.0f;  // :128-131
+  f3 va = xyz(lut[3 * id]), vb = xyz(lut[3 * id + 1]), vc = xyz(lut[3 * id + 2]);
+  f3 nrm = exact::normalize(exact::cross(vb - va, vc - va));  // :142
+  f3 bc = bary_coords(wp, va, vb, vc);                        // :143
+  f3 pa = xyz(lut_prev[3 * id]), pb = xyz(lut_prev[3 * id + 1]), pc = xyz(lut_prev[3 * id + 2]);
+  f3 wpp = bary_mix(bc, pa, pb, pc);                          // :153
+  f3 cur = phong(wp, nrm, cam, light, color);                 // :158
+  f3 prv = phong(wpp, nrm, cam, light_prev, color_prev);      // :161 (current normal!)
+  f3 tg = cur - prv;
+  float delta = glsl_max(exact::length(cur), exact::length(prv));  // :166
+  return glsl_min(1.0f, exact::length(tg) / delta);                // :167
+}
+
+__device__ __forceinline__ void store_gradient(float4* grad, size_t i, float lam) {
+#if RTPT_GRAD_NT_STORE
+  // nothing on the reference's path reads the gradient again (its consumer is commented out,
+  // temporalFiltering.comp.glsl:247-248): keep the 133 MB out of the caches the filter passes need
+  typedef float v4f_ __attribute__((ext_vector_type(4)));
+  v4f_ g4 = {lam, lam, lam, 0.0f};
+  __builtin_nontemporal_store(g4, reinterpret_cast<v4f_*>(grad + i));
+#else
+  grad[i] = make_float4(lam, lam, lam, 0.0f);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
 // K0 G-buffer
 // ------------------------------------------------------------------------------------------
 template <bool BVH>
@@ -374,24 +421,18 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
     a.worldpos[i] = make_float4(0.f, 0.f, 0.f, 1.0f);  // clear colour main.cpp:1420
     a.depth[i] = 1.0f;                                  // clear depth  main.cpp:1421
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// K1 temporal gradient
-// ------------------------------------------------------------------------------------------
-// temporalGradient.comp.glsl:71-101
-__device__ __forceinline__ f3 phong(f3 p, f3 n, f3 cam, f3 lpos, f3 lcol) {
-  f3 ldir = exact::normalize(lpos - p);
-  f3 ambient = lcol * 0.1f;
-  float diff = glsl_max(exact::dot(n, ldir), 0.0f);
-  f3 diffuse = lcol * diff;
-  f3 vdir = exact::normalize(cam - p);
-  f3 I = -ldir;
-  float two_ndi = 2.0f * exact::dot(n, I);
-  f3 rdir{fmaf_(-two_ndi, n.x, I.x), fmaf_(-two_ndi, n.y, I.y), fmaf_(-two_ndi, n.z, I.z)};
-  float spec = exact::powi(glsl_max(exact::dot(vdir, rdir), 0.0f), 128);
-  f3 specular = lcol * (0.5f * spec);
-  return ((ambient + diffuse) + specular) * 0.7f;
+  if (a.grad_on && y >= a.grad_y0 && y < a.grad_y1) {
+    // K1 (temporalGradient.comp.glsl:104-172) on the values K0 just stored — the same bits it would load back
+    f3 wp{0.f, 0.f, 0.f};
+    if (h.id1) {
+      float b1 = h.u / h.ad, b2 = h.v / h.ad;
+      float b0 = 1.0f - b1 - b2;
+      const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
+      wp = bary_point(xyz(s[0]), xyz(s[1]), xyz(s[2]), b0, b1, b2);
+    }
+    store_gradient(a.grad, i, gradient_lambda(h.id1, wp, a.lut, a.lut_prev, ld3(a.g_cam), ld3(a.g_light), ld3(a.g_light_prev),
+                                              ld3(a.g_color), ld3(a.g_color_prev)));
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void k_gradient(GradientArgs a) {
@@ -400,31 +441,9 @@ __global__ __launch_bounds__(kThreads) void k_gradient(GradientArgs a) {
   if (x >= a.g.W || y >= a.g.y1) return;  // D10: bounds check first
   const size_t i = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
   const uint32_t id = a.vis[i];
-  float lam = 0.0f;
-  if (id != 0) {
-    f3 wp = xyz(a.worldpos[i]);
-    f3 va = xyz(a.lut[3 * id]), vb = xyz(a.lut[3 * id + 1]), vc = xyz(a.lut[3 * id + 2]);
-    f3 nrm = exact::normalize(exact::cross(vb - va, vc - va));
-    f3 bc = bary_coords(wp, va, vb, vc);
-    f3 pa = xyz(a.lut_prev[3 * id]), pb = xyz(a.lut_prev[3 * id + 1]), pc = xyz(a.lut_prev[3 * id + 2]);
-    f3 wpp = bary_mix(bc, pa, pb, pc);
-    f3 cur = phong(wp, nrm, ld3(a.cam), ld3(a.light), ld3(a.color));
-    f3 prv = phong(wpp, nrm, ld3(a.cam), ld3(a.light_prev), ld3(a.color_prev));
-    f3 tg = cur - prv;
-    float delta = glsl_max(exact::length(cur), exact::length(prv));
-    lam = glsl_min(1.0f, exact::length(tg) / delta);
-  }
-#if RTPT_GRAD_NT_STORE
-  {
-    // nothing on the reference's path reads the gradient again (its consumer is commented out,
-    // temporalFiltering.comp.glsl:247-248): keep the 133 MB out of the caches the filter passes need
-    typedef float v4f_ __attribute__((ext_vector_type(4)));
-    v4f_ g4 = {lam, lam, lam, 0.0f};
-    __builtin_nontemporal_store(g4, reinterpret_cast<v4f_*>(a.grad + i));
-  }
-#else
-  a.grad[i] = make_float4(lam, lam, lam, 0.0f);
-#endif
+  const f3 wp = id ? xyz(a.worldpos[i]) : f3{0.f, 0.f, 0.f};
+  store_gradient(a.grad, i, gradient_lambda(id, wp, a.lut, a.lut_prev, ld3(a.cam), ld3(a.light), ld3(a.light_prev), ld3(a.color),
+                                            ld3(a.color_prev)));
 }
 
 // ------------------------------------------------------------------------------------------

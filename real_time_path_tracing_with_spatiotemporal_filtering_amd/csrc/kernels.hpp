@@ -57,6 +57,14 @@ struct GbufferArgs {
   float4* normals;            // nullable: per-pixel normal_tab[id] for the LDS-staged filter of large scenes
   const float4* normal_tab;   // per-id (n.xyz, self weight), built by k_lut
   int32_t cull;                      // 1: bounds[] is valid
+  // K1 in the same launch (rtpt_temporal_gradient arrived right behind rtpt_gbuffer): the pixel's id and world position
+  // are still in registers, so the gradient costs its 16 B/px store and none of its 20 B/px of loads
+  int32_t grad_on;
+  int32_t grad_y0, grad_y1;          // rows the gradient was asked for
+  float g_cam[3], g_light[3], g_light_prev[3], g_color[3], g_color_prev[3];
+  const float4* lut;
+  const float4* lut_prev;
+  float4* grad;
   TriBounds bounds[kCullMaxTris];
 };
 

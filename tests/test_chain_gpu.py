@@ -71,7 +71,43 @@ def test_chain_is_what_runs_by_default_on_large_frames(hip_lib):
             app.drawScene()
         tm = ctx.timing_collect()
         assert (tm["k_atrous_chain"][1], tm["k_atrous"][1], tm["k_atrous_final"][1]) == want, (w, h, flags, tm)
+        # K0 and K1: one launch unless every pass is launched when called
+        fused = not (flags & hip_lib.FLAG_NO_FILTER_FUSION)
+        assert (tm["k_gbuffer_gradient"][1], tm["k_gbuffer"][1], tm["k_gradient"][1]) == ((3, 0, 0) if fused else (0, 3, 3)), tm
         app.backend.close()
+
+
+def test_gbuffer_gradient_fusion_and_observation(hip_lib):
+    """rtpt_gbuffer records; rtpt_temporal_gradient right behind it runs both in one launch; a readback in between (or a
+    gradient over rows the G-buffer call did not cover) launches K0 alone first.  Same planes either way."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    outs = []
+    for mode in ("fused", "observed", "unfused"):
+        app = make_app(200, 90, max_segments=2, iterations=1, flags=hip_lib.FLAG_NO_FILTER_FUSION if mode == "unfused" else 0)
+        ctx = app.backend.ctx
+        ctx.timing_enable(1)
+        planes = []
+        for f in range(3):
+            app.updateScene(("J",) if f == 1 else (("D",) if f == 2 else ()))
+            app.drawVisbilityBuffer()
+            if mode == "observed":
+                planes.append(ctx.readback(hip_lib.PLANE_VIS_ID))
+            app.computeTemporalGradient()
+            planes += [ctx.readback(p) for p in (hip_lib.PLANE_VIS_ID, hip_lib.PLANE_WORLDPOS, hip_lib.PLANE_DEPTH, hip_lib.PLANE_GRADIENT)]
+            if mode == "observed":
+                planes.pop(-5)
+            app.drawSceneToImage()
+            app.applyTemporalFiltering()
+            app.copyImageToSwapChainsCurrentImage()
+            app.frameCount += 1
+        tm = ctx.timing_collect()
+        assert tm["k_gbuffer_gradient"][1] == (3 if mode == "fused" else 0) and tm["k_gradient"][1] == (0 if mode == "fused" else 3)
+        outs.append(planes)
+        app.backend.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(bits(a), bits(b))
+    assert (outs[0][-1][..., 0] > 0).any(), "the light / camera moves did produce a gradient"
 
 
 def test_observation_between_iterations_sees_the_separate_pass_state(hip_lib, oracle, cornell):
