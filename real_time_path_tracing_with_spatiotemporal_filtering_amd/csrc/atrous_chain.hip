@@ -31,9 +31,10 @@ namespace rt {
 namespace {
 
 #ifndef RTPT_CHAIN_G
-#define RTPT_CHAIN_G 2
+#define RTPT_CHAIN_G 3
 #endif
-constexpr int kChG = RTPT_CHAIN_G;  // rows per level per step
+constexpr int kChG = RTPT_CHAIN_G;  // rows per level per step = waves per level / 2.  4K pair launches: 1: 107.9 us, 2: 100.4,
+                                    // 3: 97.7, 4: 103.1 (more waves per workgroup hide more latency until the rings cost a workgroup per CU)
 #ifndef RTPT_CHAIN_P
 #define RTPT_CHAIN_P 1
 #endif
