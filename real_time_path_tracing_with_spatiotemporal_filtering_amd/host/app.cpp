@@ -363,6 +363,51 @@ void PathTracingApplication::freeRessources() {
   ctx_ = last_ = nullptr;
 }
 
+std::string PathTracingApplication::planJson(int frames, const std::vector<std::string>& script) {
+  loadMesh();
+  for (int a = 0; a < 3; a++) {
+    sceneMin_[a] = 1e30f;
+    sceneMax_[a] = -1e30f;
+  }
+  for (uint32_t i : objIndices)
+    for (int a = 0; a < 3; a++) {
+      sceneMin_[a] = std::min(sceneMin_[a], objVertices[3 * static_cast<size_t>(i) + a]);
+      sceneMax_[a] = std::max(sceneMax_[a], objVertices[3 * static_cast<size_t>(i) + a]);
+    }
+  // uploadBuffers (main.cpp:481-489) + initializeSceneConstants, as in initVulkan, without any device work
+  identity(ubo.model);
+  const float center[3] = {0.0f, 1.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
+  rtpt_util_look_at(cameraOrigin, center, up, ubo.view);
+  rtpt_util_perspective(kFov * 2, static_cast<float>(opt_.width) / static_cast<float>(opt_.height), 0.1f, 10.0f, ubo.proj);
+  ubo.proj[5] *= -1;
+  std::memcpy(ubo.modelPrev, ubo.model, sizeof ubo.model);
+  std::memcpy(ubo.viewPrev, ubo.view, sizeof ubo.view);
+  std::memcpy(ubo.projPrev, ubo.proj, sizeof ubo.proj);
+  initializeSceneConstants();
+  const int H = static_cast<int>(opt_.height), R = opt_.ranks, N = opt_.maxWaveletIteration;
+  std::string out = "{\"ranks\": [";
+  auto rows = [](Rows r) { return "[" + std::to_string(r.first) + ", " + std::to_string(r.second) + "]"; };
+  for (int r = 0; r < R; r++) {
+    StripPlan p;
+    p.height = H; p.world = R; p.rank = r; p.iterations = N; p.exchange = opt_.exchange_halo;
+    out += std::string(r ? ", " : "") + "{\"own\": " + rows(p.own()) + ", \"stored\": " + rows(p.stored()) + ", \"raytrace\": " +
+           rows(p.raytrace_rows()) + ", \"filter\": [";
+    for (int k = 1; k <= N; k++) out += std::string(k > 1 ? ", " : "") + rows(p.filter_rows(k));
+    out += "]}";
+  }
+  out += "], \"frames\": [";
+  for (int f = 0; f < frames; f++) {
+    updateScene(static_cast<size_t>(f) < script.size() ? script[static_cast<size_t>(f)] : std::string());
+    out += std::string(f ? ", " : "") + "{\"moved\": " + (frameCount > 0 && !cameraStatic() ? "true" : "false") + ", \"needs\": [";
+    for (int r = 0; r < R; r++)
+      out += std::string(r ? ", " : "") + rows(reprojection_rows(ubo, static_cast<int>(opt_.width), H, StripPlan::bounds(H, R, r), sceneMin_, sceneMax_, 0.1f));
+    out += "]}";
+    frameCount++;
+  }
+  out += "]}";
+  return out;
+}
+
 uint64_t PathTracingApplication::bytesSent() const { return transport_ ? transport_->bytes_sent() : 0; }
 
 void PathTracingApplication::sync() {

@@ -60,6 +60,9 @@ class PathTracingApplication {
   std::vector<float> readImage();              // RGBA32F, width*height*4
   uint64_t rayCount();
   uint64_t bytesSent() const;                  // strips: bytes this process sent (halo rows + history bands)
+  // host-only (no GPU, no context): the strip plan of every rank and, per scripted frame, the previous-frame rows each
+  // rank's final pass can reach — as one JSON object; what the CPU tests compare with the Python mirror
+  std::string planJson(int frames, const std::vector<std::string>& script);
   void writePFM(const std::string& path);      // linear RGB, bottom-up rows as PFM prescribes
   void sync();
 

@@ -17,6 +17,7 @@ static void usage(const char* argv0) {
       "          [--scene file.obj] [--script \"keys0,keys1,...\"] [--dump out.pfm] [--exact-filter]\n"
       "          [--frames-in-flight 1|2]\n"
       "          [--ranks R [--rank r --rccl-id-file F] [--halo redundant|exchange] [--device D]]\n"
+      "          [--plan-only   (print the strip plan and the history bands of the scripted frames as JSON; needs no GPU)]\n"
       "  --ranks R splits the frame into R row strips: with --rank r this process is rank r on its own GPU and talks RCCL\n"
       "  (start R processes; rank 0 publishes the ncclUniqueId in F); without --rank all R strips run in this process\n"
       "          [--flags N   (RTPT_FLAG_* bits of include/rtpt.h, e.g. 0xF0 = all extension modes)]\n"
@@ -28,6 +29,7 @@ static void usage(const char* argv0) {
 int main(int argc, char** argv) {
   rtpt_host::Options opt;
   int frames = 3;
+  bool plan_only = false;
   std::string dump, script_arg;
   // scene path relative to this binary: <pkg>/scenes/...
   std::string self(argv[0]);
@@ -56,6 +58,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--halo")) opt.exchange_halo = !std::strcmp(need("--halo"), "exchange");
     else if (!std::strcmp(argv[i], "--rccl-id-file")) opt.rccl_id_file = need("--rccl-id-file");
     else if (!std::strcmp(argv[i], "--device")) opt.device = std::atoi(need("--device"));
+    else if (!std::strcmp(argv[i], "--plan-only")) plan_only = true;
     else if (!std::strcmp(argv[i], "--flags") && i + 1 < argc) opt.flags |= static_cast<uint32_t>(std::strtoul(argv[++i], nullptr, 0));
     else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) { usage(argv[0]); return 0; }
     else { std::fprintf(stderr, "unknown option %s\n", argv[i]); usage(argv[0]); return 2; }
@@ -68,6 +71,10 @@ int main(int argc, char** argv) {
   }
   try {
     rtpt_host::PathTracingApplication app(opt);
+    if (plan_only) {  // host-only: no GPU is touched
+      std::printf("%s\n", app.planJson(frames, script).c_str());
+      return 0;
+    }
     app.initVulkan();
     app.sync();
     auto t0 = std::chrono::steady_clock::now();
