@@ -498,6 +498,26 @@ void k_atrous_comb_sh(AtrousArgs a) {
 #if RTPT_COMB_PRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
+  // final pass: world positions fetched with the staging DMA and the history ahead of the taps.  Measured at 4K: it pays
+  // in the per-pixel-normal variant (1.15M triangles: 155.8 -> 144.1 us; its taps compute x^128 per tap and leave time to
+  // hide the fetch) and costs in the id-pair variant (110.5 -> 125.6 us: the 2 KiB of world positions per wave lengthen the
+  // wait in front of the workgroup barrier, which the other workgroups' taps no longer cover)
+#ifndef RTPT_FINAL_EARLY
+#define RTPT_FINAL_EARLY NRM
+#endif
+  // FINAL: the world positions of this wave's output pixels depend on nothing staged — fetch them now, in flight together
+  // with the DMA and waited for by the same vmcnt(0)
+  f3 wp_pre[kCombM * kShHalves];
+  if (FINAL && RTPT_FINAL_EARLY) {
+#pragma unroll
+    for (int mh = 0; mh < kCombM * kShHalves; mh++) {
+      const int m = mh / kShHalves, hf = mh % kShHalves;
+      const int x = x0 + hf * 64 + lane;
+      const int y = yg + (wave * kCombM + m) * k;
+      wp_pre[mh] = f3{0.f, 0.f, 0.f};
+      if (x < W && y < a.g.y1) wp_pre[mh] = xyz(a.worldpos[static_cast<size_t>(y - a.g.row_base) * W + x]);
+    }
+  }
   // own DMA landed, then the barrier publishes every wave's rows to the block
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -518,6 +538,25 @@ void k_atrous_comb_sh(AtrousArgs a) {
     const uint32_t idp = NRM ? (FINAL ? a.vis[ip] : 0u) : ids[cc];  // NRM: the id is only needed for the reprojection
     const float* prow = pairw + idp * NP;
     const float wself = NRM ? np4.w : prow[idp];
+    // FINAL: reproject first (:213-239 — exact arithmetic: the truncated pixel coordinate is an integer observable) so that
+    // the history fetch is in flight under the taps' arithmetic
+    int ppx = x, ppy = y;
+    f3 hc{0.f, 0.f, 0.f};  // D2: out-of-image history fetch returns 0
+    if (FINAL && RTPT_FINAL_EARLY) {
+      if (!(idp < 1)) {
+        const f3 wp = wp_pre[mh];
+        const f3 va = xyz(a.lut_prev[3 * idp]), vb = xyz(a.lut_prev[3 * idp + 1]), vc = xyz(a.lut_prev[3 * idp + 2]);  // :223-233
+        const f3 bc = bary_coords(wp, va, vb, vc);
+        const f3 wpp = bary_mix(bc, va, vb, vc);  // :236
+        const float clx = exact::mat_row_point(a.PVprev, 0, wpp), cly = exact::mat_row_point(a.PVprev, 1, wpp),
+                    clw = exact::mat_row_point(a.PVprev, 3, wpp);
+        const float ndx = clx / clw, ndy = cly / clw;                      // :183
+        ppx = exact::f2i(fmaf_(ndx, 0.5f, 0.5f) * static_cast<float>(W));  // :186,:238
+        ppy = exact::f2i(fmaf_(ndy, 0.5f, 0.5f) * static_cast<float>(H));
+      }
+      if (a.frame > 0 && ppx >= 0 && ppx < W && ppy >= a.hist_y0 && ppy < a.hist_y1)  // :251,:253
+        hc = xyz(a.history[static_cast<size_t>(ppy - a.hist_row_base) * W + ppx]);
+    }
     f3 num{0.f, 0.f, 0.f};
     float den = 0.f;
 #pragma unroll
@@ -588,25 +627,25 @@ void k_atrous_comb_sh(AtrousArgs a) {
 #endif
       continue;
     }
-    // :213-239 reprojection — exact arithmetic: the truncated pixel coordinate is an integer observable
-    int ppx = x, ppy = y;
-    if (!(idp < 1)) {
-      const f3 wp = xyz(a.worldpos[ip]);
-      const f3 va = xyz(a.lut_prev[3 * idp]), vb = xyz(a.lut_prev[3 * idp + 1]), vc = xyz(a.lut_prev[3 * idp + 2]);  // :223-233
-      const f3 bc = bary_coords(wp, va, vb, vc);
-      const f3 wpp = bary_mix(bc, va, vb, vc);  // :236
-      const float clx = exact::mat_row_point(a.PVprev, 0, wpp), cly = exact::mat_row_point(a.PVprev, 1, wpp),
-                  clw = exact::mat_row_point(a.PVprev, 3, wpp);
-      const float ndx = clx / clw, ndy = cly / clw;                      // :183
-      ppx = exact::f2i(fmaf_(ndx, 0.5f, 0.5f) * static_cast<float>(W));  // :186,:238
-      ppy = exact::f2i(fmaf_(ndy, 0.5f, 0.5f) * static_cast<float>(H));
+    if (!RTPT_FINAL_EARLY) {
+      // :213-239 reprojection — exact arithmetic: the truncated pixel coordinate is an integer observable
+      if (!(idp < 1)) {
+        const f3 wp = xyz(a.worldpos[ip]);
+        const f3 va = xyz(a.lut_prev[3 * idp]), vb = xyz(a.lut_prev[3 * idp + 1]), vc = xyz(a.lut_prev[3 * idp + 2]);  // :223-233
+        const f3 bc = bary_coords(wp, va, vb, vc);
+        const f3 wpp = bary_mix(bc, va, vb, vc);  // :236
+        const float clx = exact::mat_row_point(a.PVprev, 0, wpp), cly = exact::mat_row_point(a.PVprev, 1, wpp),
+                    clw = exact::mat_row_point(a.PVprev, 3, wpp);
+        const float ndx = clx / clw, ndy = cly / clw;                      // :183
+        ppx = exact::f2i(fmaf_(ndx, 0.5f, 0.5f) * static_cast<float>(W));  // :186,:238
+        ppy = exact::f2i(fmaf_(ndy, 0.5f, 0.5f) * static_cast<float>(H));
+      }
+      if (a.frame > 0 && ppx >= 0 && ppx < W && ppy >= a.hist_y0 && ppy < a.hist_y1)
+        hc = xyz(a.history[static_cast<size_t>(ppy - a.hist_row_base) * W + ppx]);
     }
     if (a.prev_pixel) a.prev_pixel[ip] = make_int2(ppx, ppy);
     f3 blend = filtered;  // :258
     if (a.frame > 0) {    // :251
-      f3 hc{0.f, 0.f, 0.f};  // D2: out-of-image history fetch returns 0
-      if (ppx >= 0 && ppx < W && ppy >= a.hist_y0 && ppy < a.hist_y1)
-        hc = xyz(a.history[static_cast<size_t>(ppy - a.hist_row_base) * W + ppx]);
       const float oma = 1.0f - a.alpha;
       blend = f3{fmaf_(filtered.x, a.alpha, hc.x * oma), fmaf_(filtered.y, a.alpha, hc.y * oma),
                  fmaf_(filtered.z, a.alpha, hc.z * oma)};  // :254

@@ -328,6 +328,7 @@ hipError_t prepare_device_atrous_chain() {
 // true when `levels` consecutive iterations from stride k0 can run as one chain on this scene
 bool atrous_chain_supported(int k0, int levels, uint32_t n_tris) {
   if (levels < 2 || levels > 3 || k0 < 1) return false;
+  if (128 * levels * kChG > 1024) return false;  // two waves per row and level: the workgroup must fit 1024 threads
   if (n_tris + 1 > 64) return false;  // id-pair table in LDS (the per-pixel-normal variant is not chained)
   if (atrous_chain_strip_width(k0, levels) < 64) return false;
   return atrous_chain_lds(k0, levels, n_tris) <= 160 * 1024;
