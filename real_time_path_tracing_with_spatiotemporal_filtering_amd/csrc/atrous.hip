@@ -385,11 +385,7 @@ void k_atrous_comb_sh(AtrousArgs a) {
   const int lane = static_cast<int>(threadIdx.x);
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   float* pairw = reinterpret_cast<float*>(lds_raw);  // [NP][NP]
-  // FINAL, id-pair variant: the previous LUT (48 B per id, <= 64 ids) sits behind the pair table, so the reprojection's three
-  // vertex fetches per pixel are LDS reads — the pass's epilogue issues 3 vector-memory instructions per pixel instead of 6
-  constexpr bool kLutLds = FINAL && !NRM;
-  const int pair_bytes = ((NP * NP * 4 + 15) & ~15) + (kLutLds ? NP * 48 : 0);
-  const float4* lutp = kLutLds ? reinterpret_cast<const float4*>(lds_raw + ((NP * NP * 4 + 15) & ~15)) : a.lut_prev;
+  const int pair_bytes = (NP * NP * 4 + 15) & ~15;
   unsigned char* mine = lds_raw + pair_bytes;  // one region per block
   const float4* col = reinterpret_cast<const float4*>(mine);                // (r, g, b, depth)
   const uint32_t* ids = reinterpret_cast<const uint32_t*>(mine + 16 * cells);
@@ -399,9 +395,6 @@ void k_atrous_comb_sh(AtrousArgs a) {
 
   // id-pair weight table -> LDS (plain loads; no DMA is in flight yet)
   for (int i = wave * 64 + lane; i < NP * NP; i += kShThreads) pairw[i] = a.pair_tab[i];
-  if (kLutLds)
-    for (int i = wave * 64 + lane; i < NP * 3; i += kShThreads)
-      reinterpret_cast<float4*>(lds_raw + ((NP * NP * 4 + 15) & ~15))[i] = a.lut_prev[i];
   __syncthreads();
 
   // Work list.  A logical block = four CONSECUTIVE chunks (one per wave) of one residue and one
@@ -552,7 +545,7 @@ void k_atrous_comb_sh(AtrousArgs a) {
     if (FINAL && RTPT_FINAL_EARLY) {
       if (!(idp < 1)) {
         const f3 wp = wp_pre[mh];
-        const f3 va = xyz(lutp[3 * idp]), vb = xyz(lutp[3 * idp + 1]), vc = xyz(lutp[3 * idp + 2]);  // :223-233
+        const f3 va = xyz(a.lut_prev[3 * idp]), vb = xyz(a.lut_prev[3 * idp + 1]), vc = xyz(a.lut_prev[3 * idp + 2]);  // :223-233
         const f3 bc = bary_coords(wp, va, vb, vc);
         const f3 wpp = bary_mix(bc, va, vb, vc);  // :236
         const float clx = exact::mat_row_point(a.PVprev, 0, wpp), cly = exact::mat_row_point(a.PVprev, 1, wpp),
@@ -638,7 +631,7 @@ void k_atrous_comb_sh(AtrousArgs a) {
       // :213-239 reprojection — exact arithmetic: the truncated pixel coordinate is an integer observable
       if (!(idp < 1)) {
         const f3 wp = xyz(a.worldpos[ip]);
-        const f3 va = xyz(lutp[3 * idp]), vb = xyz(lutp[3 * idp + 1]), vc = xyz(lutp[3 * idp + 2]);  // :223-233
+        const f3 va = xyz(a.lut_prev[3 * idp]), vb = xyz(a.lut_prev[3 * idp + 1]), vc = xyz(a.lut_prev[3 * idp + 2]);  // :223-233
         const f3 bc = bary_coords(wp, va, vb, vc);
         const f3 wpp = bary_mix(bc, va, vb, vc);  // :236
         const float clx = exact::mat_row_point(a.PVprev, 0, wpp), cly = exact::mat_row_point(a.PVprev, 1, wpp),
@@ -819,8 +812,7 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
     const int base_w = seg_w;
     const int cw = need <= base_w + 8 ? base_w + 8 : (need <= base_w + 16 ? base_w + 16 : base_w + 32);
     const size_t lds = nrm_mode ? static_cast<size_t>(kShWaves * kCombM + 2) * cw * 32
-                                : static_cast<size_t>((np * np * 4 + 15) & ~15) + (final_pass ? static_cast<size_t>(np) * 48 : 0) +
-                                      static_cast<size_t>(kShWaves * kCombM + 2) * cw * 20;
+                                : static_cast<size_t>((np * np * 4 + 15) & ~15) + static_cast<size_t>(kShWaves * kCombM + 2) * cw * 20;
     // persistent grid: as many blocks per CU as 160 KiB of LDS and 32 waves admit
     uint32_t per_cu = static_cast<uint32_t>((160u * 1024u) / lds);
     if (per_cu > 32u / kShWaves) per_cu = 32u / kShWaves;
