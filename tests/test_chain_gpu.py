@@ -175,9 +175,10 @@ def test_lds_staged_extension_taps_equal_the_direct_kernel(hip_lib, ext, exact):
 
 @pytest.mark.parametrize("exact", [0, 1])
 def test_three_level_and_final_chains(hip_lib, monkeypatch, exact):
-    """the chain kernel's other instances — three iterations per launch, and a chain that ends in the FINAL pass
-    (reprojection + blend in the last level's epilogue) — selected through the tuning knobs rtpt_create reads; N = 5 then
-    runs as (1,2,3) + (4,5 final), N = 4 as (1,2,3) + 4, N = 3 as (1,2,3 final).  Same bits as one kernel per iteration."""
+    """the chain kernel's other instances — a chain that ends in the FINAL pass (reprojection + blend in the last level's
+    epilogue) and, where the workgroup size admits it (two waves per row and level, so only with G = 2 rows per step), three
+    iterations per launch — selected through the tuning knobs rtpt_create reads.  Same bits as one kernel per iteration,
+    whatever the grouping."""
     monkeypatch.setenv("RTPT_CHAIN_MAX", "3")
     monkeypatch.setenv("RTPT_CHAIN_FINAL", "1")
     keys = [(), ("J",), ("D", "E"), ()]
