@@ -103,9 +103,11 @@ typedef struct rtpt_visibility_data {
 #define RTPT_FLAG_BINNED_PATHS 0x800u     /* path tracer, small scenes with separate objects, <= 8 segments: one launch per
                                              segment, the paths handed on through queues binned by which objects' bounds the
                                              next ray enters, so a wave tests only its class's triangles (16.5 instead of 32
-                                             per secondary ray on the Cornell box).  Same image; measured SLOWER than the
-                                             default (4K: 566 vs 500 us) — the per-ray queue traffic and bookkeeping cost
-                                             more VALU issue than the skipped tests save — so it is opt-in (A/B switch) */
+                                             per secondary ray on the Cornell box).  Same image.  It is what runs by default
+                                             for launches of >= 4 M pixels (4K: 449 vs 474 us) and loses below that (1080p:
+                                             153 vs 141 us: four launches of little work each); this bit forces it on at any
+                                             size, RTPT_FLAG_NO_BINNED_PATHS off (A/B switches) */
+#define RTPT_FLAG_NO_BINNED_PATHS 0x1000u
 #define RTPT_FLAG_NO_FILTER_FUSION 0x400u /* launch every pass when it is called, one kernel per call, instead of
                                              recording rtpt_temporal_filter's calls of a frame (consecutive iterations
                                              then run chained in one launch) and rtpt_gbuffer (which runs in one launch

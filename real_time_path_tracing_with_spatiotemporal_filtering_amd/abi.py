@@ -25,6 +25,7 @@ FLAG_EXT_VARIANCE = 0x100
 FLAG_SINGLE_LAUNCH_PATHS = 0x200
 FLAG_NO_FILTER_FUSION = 0x400
 FLAG_BINNED_PATHS = 0x800
+FLAG_NO_BINNED_PATHS = 0x1000
 FLAG_EXT_MASK = 0x1F0
 DEBUG_HIT_ID, DEBUG_PREV_PIXEL = 0x1, 0x2
 

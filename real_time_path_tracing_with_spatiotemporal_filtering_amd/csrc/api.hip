@@ -128,6 +128,9 @@ struct rtpt_ctx {
   // fewer pixels than this per launch the segments that fill the GPU are too short for that to pay (measured: 1080p
   // 39.2 us chained vs 2 x 18.6 us separate; 4K 100.7 vs 2 x 63.8), so smaller launches run one kernel per iteration
   int64_t chain_min_pixels = 4000000;
+  // the class-binned path hand-over (one launch per segment) has the same break-even: 4K 449 vs 474 us, a 1 095-row strip
+  // 250 vs 258, 1080p 153 vs 141, a 300-row strip 109 vs 91
+  int64_t binned_min_pixels = 4000000;
 
   // timing
   int timing_period = 0;          // 0 off, n: kernels of every n-th frame are bracketed by events
@@ -472,6 +475,7 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   if (const char* v = std::getenv("RTPT_CHAIN_MAX")) c->chain_max = std::max(1, std::min(3, std::atoi(v)));
   if (const char* v = std::getenv("RTPT_CHAIN_FINAL")) c->chain_final = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_CHAIN_MIN_PIXELS")) c->chain_min_pixels = std::atoll(v);
+  if (const char* v = std::getenv("RTPT_BINNED_MIN_PIXELS")) c->binned_min_pixels = std::atoll(v);
   int rc = alloc_planes(c);
   if (rc != RTPT_OK) {
     rtpt_destroy(c);
@@ -1149,8 +1153,9 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   a.class_ids = nullptr;
   for (uint32_t i = 0; i < rt::kPathClasses; i++) a.class_off[i] = a.class_cnt[i] = 0;
   if (c->clusters.n > 0 && !c->use_bvh && a.compact && a.spp == 1 && a.max_segments >= 2 && a.max_segments <= rt::kBinnedMaxSegments &&
-      (c->cfg.flags & RTPT_FLAG_BINNED_PATHS) && !(c->cfg.flags & RTPT_FLAG_SINGLE_LAUNCH_PATHS) && c->cfg.width < 65536 &&
-      c->cfg.height < 65536) {
+      !(c->cfg.flags & (RTPT_FLAG_SINGLE_LAUNCH_PATHS | RTPT_FLAG_NO_BINNED_PATHS)) &&
+      ((c->cfg.flags & RTPT_FLAG_BINNED_PATHS) || static_cast<int64_t>(y1 - y0) * c->cfg.width >= c->binned_min_pixels) &&
+      c->cfg.width < 65536 && c->cfg.height < 65536) {
     // class-binned hand-over (kernels.hpp): a region holds at most the survivors of the workgroups mapped to it —
     // ceil(tiles / regions) tiles of 256 paths from the tile kernel; from a queue launch, (grid / regions) workgroups
     // of at most ceil(chunks / grid) chunks each, chunks <= paths / 256 + one partial chunk per list

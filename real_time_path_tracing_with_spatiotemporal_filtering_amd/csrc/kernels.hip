@@ -585,21 +585,20 @@ __device__ __forceinline__ uint32_t ray_class(const ClusterInfo& ci, f3 o, f3 d,
 // Records are stored as three float4 planes (structure of arrays) so that a wave's 64 records are three 1 KiB stores.
 __device__ __forceinline__ void enqueue_binned(const PathtraceArgs& a, uint32_t region, bool alive, uint32_t cls, uint32_t pixg, uint32_t rng,
                                                f3 o, f3 d, f3 acc) {
+  // lane c reserves the slots of class c: the (up to) four atomics are ONE instruction and one round trip — issued one
+  // after the other, each waited for before the next, they were 4 x ~3 us of pure latency per 64 paths
+  const uint32_t lane = threadIdx.x & 63u;
   unsigned long long mine = 0;
-  uint32_t base = 0;
+  uint32_t cnt = 0;
 #pragma unroll
   for (uint32_t c = 0; c < kPathClasses; c++) {
     const unsigned long long m = __ballot(alive && cls == c);
-    if (m == 0ull) continue;  // wave-uniform
-    uint32_t b = 0;
-    if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(m)))
-      b = atomicAdd(a.bq_out_count + region * kPathClasses + c, static_cast<uint32_t>(__builtin_popcountll(m)));
-    b = __shfl(b, __builtin_ctzll(m), 64);
-    if (cls == c) {
-      mine = m;
-      base = b;
-    }
+    if (lane == c) cnt = static_cast<uint32_t>(__builtin_popcountll(m));
+    if (cls == c) mine = m;
   }
+  uint32_t b = 0;
+  if (lane < kPathClasses && cnt) b = atomicAdd(a.bq_out_count + region * kPathClasses + lane, cnt);
+  const uint32_t base = __shfl(b, static_cast<int>(cls), 64);
   if (alive) {
     const uint32_t off = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mine >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mine), 0u));
     const size_t rbase = static_cast<size_t>(region) * a.bq_region_cap;
@@ -808,7 +807,12 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
       const uint32_t blk = blockIdx.y * gridDim.x + blockIdx.x;
       if (!BVH && a.bq_out_count) {
         const uint32_t cls = alive ? ray_class(a.clusters, o, d, a.tmax) : 0u;
+#if defined(RTPT_TILE_WAVE_ENQ) && RTPT_TILE_WAVE_ENQ
+        (void)bin_cnt; (void)bin_bases;
+        enqueue_binned(a, (blk * kPtRows + static_cast<uint32_t>(wave)) % kBinRegions, alive, cls, pixg, rng, o, d, acc);
+#else
         enqueue_binned_block(a, blk % kBinRegions, bin_cnt, bin_bases, alive, cls, wave, lane, pixg, rng, o, d, acc);
+#endif
       } else
         enqueue_paths(a, blk % kPathQueues, wave_cnt, &q_base, alive, wave, lane, pixg, rng, o, d, acc);
     }
@@ -854,7 +858,11 @@ void k_pathtrace_small(PathtraceArgs a) {
 // (equal-t ties keep the lower id, D4 — the triangles left out cannot be hit: the ray misses their cluster's padded
 // bounds).  Survivors are classified by their new ray and appended to the out queues; a path that ends writes its pixel.
 // Waves are independent after the prologue: no workgroup barrier in the loop.
-__global__ __launch_bounds__(kPtThreads) void k_pathtrace_binned(PathtraceArgs a) {
+__global__ __launch_bounds__(kPtThreads)
+#if RTPT_PT_WAVES
+__attribute__((amdgpu_waves_per_eu(RTPT_PT_WAVES, RTPT_PT_WAVES)))
+#endif
+void k_pathtrace_binned(PathtraceArgs a) {
   constexpr uint32_t kLists = kBinRegions * kPathClasses;
   constexpr uint32_t kPer = (kLists + kPtThreads - 1) / kPtThreads;  // lists per thread in the prefix scan
   __shared__ uint32_t prefix[kLists + 1];   // 64-record pieces before list l
@@ -977,7 +985,7 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace_binned(PathtraceArgs a
         alive = false;
         const size_t gi = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
         a.image[gi] = make_float4(acc.x, acc.y, acc.z, a.depth[gi]);  // :328,:343 (+ depth in alpha)
-      } else {
+      } else if (more) {
         cls_out = ray_class(a.clusters, o, d, a.tmax);
       }
     }
@@ -1180,7 +1188,7 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
     // one resident generation of waves (the kernel's registers admit 7 waves per SIMD = 7 workgroups of 4 per CU) —
     // a grid of 8 per CU ran its last workgroups as a second round behind the first
     const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
-    const dim3 qgrid(static_cast<uint32_t>(n_cu) * 7u);
+    const dim3 qgrid(static_cast<uint32_t>(n_cu) * (RTPT_PT_WAVES ? RTPT_PT_WAVES : 7u));
     for (uint32_t seg = 1; seg < a.max_segments; seg++) {
       const uint32_t in = (seg - 1) & 1u, out = seg & 1u;
       const bool more = seg + 1 < a.max_segments;

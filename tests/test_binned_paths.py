@@ -1,7 +1,7 @@
 """K2 on small scenes, RTPT_FLAG_BINNED_PATHS: paths handed from segment to segment through queues binned by which
 objects' bounds the next ray enters (kernels.hpp ClusterInfo), against the default segment-window path — the triangles a
-class leaves out cannot be hit, so image, first-hit ids and ray count must not change by a bit.  (The mode is opt-in: it
-measured slower than the default; it stays as an A/B switch with its parity pinned here.)"""
+class leaves out cannot be hit, so image, first-hit ids and ray count must not change by a bit.  (By default the mode
+runs for launches of >= 4 M pixels, where it is faster; the flags force it on / off at any size.)"""
 import numpy as np
 import pytest
 
@@ -33,7 +33,7 @@ def test_binned_paths_equal_segment_windows(hip_lib, size, seg):
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
     w, h = size
     outs = []
-    for flags in (hip_lib.FLAG_BINNED_PATHS, 0):
+    for flags in (hip_lib.FLAG_BINNED_PATHS, hip_lib.FLAG_NO_BINNED_PATHS):
         app = make_app(w, h, max_segments=seg, iterations=3, flags=flags | hip_lib.FLAG_EXACT_FILTER, debug_mask=hip_lib.DEBUG_HIT_ID)
         ctx = app.backend.ctx
         for f in range(3):
