@@ -807,12 +807,8 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
       const uint32_t blk = blockIdx.y * gridDim.x + blockIdx.x;
       if (!BVH && a.bq_out_count) {
         const uint32_t cls = alive ? ray_class(a.clusters, o, d, a.tmax) : 0u;
-#if defined(RTPT_TILE_WAVE_ENQ) && RTPT_TILE_WAVE_ENQ
-        (void)bin_cnt; (void)bin_bases;
-        enqueue_binned(a, (blk * kPtRows + static_cast<uint32_t>(wave)) % kBinRegions, alive, cls, pixg, rng, o, d, acc);
-#else
+        // (the per-wave append measures the same here: 117-120 us either way)
         enqueue_binned_block(a, blk % kBinRegions, bin_cnt, bin_bases, alive, cls, wave, lane, pixg, rng, o, d, acc);
-#endif
       } else
         enqueue_paths(a, blk % kPathQueues, wave_cnt, &q_base, alive, wave, lane, pixg, rng, o, d, acc);
     }
