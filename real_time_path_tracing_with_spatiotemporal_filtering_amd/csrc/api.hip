@@ -127,7 +127,7 @@ struct rtpt_ctx {
   // A chain slides down column strips in row segments and pays sum(s) + lag rows of pipeline fill per segment: with
   // fewer pixels than this per launch the segments that fill the GPU are too short for that to pay (measured: 1080p
   // 39.2 us chained vs 2 x 18.6 us separate; 4K 100.7 vs 2 x 63.8), so smaller launches run one kernel per iteration
-  int64_t chain_min_pixels = 4000000;
+  int64_t chain_min_pixels = 1000000;
   // the class-binned path hand-over (one launch per segment) has the same break-even: 4K 449 vs 474 us, a 1 095-row strip
   // 250 vs 258, 1080p 153 vs 141, a 300-row strip 109 vs 91
   int64_t binned_min_pixels = 4000000;

@@ -584,7 +584,7 @@ __device__ __forceinline__ uint32_t ray_class(const ClusterInfo& ci, f3 o, f3 d,
 // cost the persistent queue kernel 100 of its 260 us: every wave of the workgroup idled through the atomic's round trip).
 // Records are stored as three float4 planes (structure of arrays) so that a wave's 64 records are three 1 KiB stores.
 __device__ __forceinline__ void enqueue_binned(const PathtraceArgs& a, uint32_t region, bool alive, uint32_t cls, uint32_t pixg, uint32_t rng,
-                                               f3 o, f3 d, f3 acc) {
+                                               f3 o, f3 d, f3 acc, float depth) {
   // lane c reserves the slots of class c: the (up to) four atomics are ONE instruction and one round trip — issued one
   // after the other, each waited for before the next, they were 4 x ~3 us of pure latency per 64 paths
   const uint32_t lane = threadIdx.x & 63u;
@@ -607,7 +607,7 @@ __device__ __forceinline__ void enqueue_binned(const PathtraceArgs& a, uint32_t 
     float4* q = reinterpret_cast<float4*>(a.bq_out[cls >> 1]);
     q[slot] = make_float4(__uint_as_float(pixg), __uint_as_float(rng), o.x, o.y);
     q[plane + slot] = make_float4(o.z, d.x, d.y, d.z);
-    q[2 * plane + slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    q[2 * plane + slot] = make_float4(acc.x, acc.y, acc.z, depth);
   }
 }
 
@@ -615,7 +615,7 @@ __device__ __forceinline__ void enqueue_binned(const PathtraceArgs& a, uint32_t 
 // atomic per class present serves the workgroup — a third of the returning atomics of the per-wave form
 __device__ __forceinline__ void enqueue_binned_block(const PathtraceArgs& a, uint32_t region, uint32_t (*wave_cnt)[kPathClasses],
                                                      uint32_t* bases, bool alive, uint32_t cls, int wave, uint32_t lane, uint32_t pixg,
-                                                     uint32_t rng, f3 o, f3 d, f3 acc) {
+                                                     uint32_t rng, f3 o, f3 d, f3 acc, float depth) {
   unsigned long long mine = 0;
 #pragma unroll
   for (uint32_t c = 0; c < kPathClasses; c++) {
@@ -643,7 +643,7 @@ __device__ __forceinline__ void enqueue_binned_block(const PathtraceArgs& a, uin
     float4* q = reinterpret_cast<float4*>(a.bq_out[cls >> 1]);
     q[slot] = make_float4(__uint_as_float(pixg), __uint_as_float(rng), o.x, o.y);
     q[plane + slot] = make_float4(o.z, d.x, d.y, d.z);
-    q[2 * plane + slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    q[2 * plane + slot] = make_float4(acc.x, acc.y, acc.z, depth);
   }
 }
 
@@ -678,6 +678,9 @@ struct PathState {  // SoA in LDS, one slot per thread
 #ifndef RTPT_PT_WAVES
 #define RTPT_PT_WAVES 8
 #endif
+#ifndef RTPT_PT_CENTER_OUT
+#define RTPT_PT_CENTER_OUT 1
+#endif
 template <bool BVH, bool COMPACT>
 __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
   // dynamic LDS, two tenants that are never live together: the BVH node stack (stack_depth x 256 entries, only
@@ -701,7 +704,16 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   const uint32_t lane = threadIdx.x;
   if (tid == 0) block_rays = 0;
-  const int tile_x0 = blockIdx.x * kBlockX, tile_y0 = a.g.y0 + blockIdx.y * kPtRows;
+#if RTPT_PT_CENTER_OUT
+  // workgroups are dispatched in the order of their linear index; tiles are taken column by column from the middle of
+  // the frame outwards, so the last ones dispatched — the tail of the launch — are the outermost columns, where (camera
+  // facing the scene) the paths are short.  A frame of a few thousand tiles is only ~2 generations of workgroups.
+  const uint32_t lin_ = blockIdx.y * gridDim.x + blockIdx.x, col_ = lin_ / gridDim.y;
+  const uint32_t bx_ = (col_ & 1u) ? (gridDim.x - 1u) / 2u + (col_ + 1u) / 2u : (gridDim.x - 1u) / 2u - col_ / 2u, by_ = lin_ % gridDim.y;
+#else
+  const uint32_t bx_ = blockIdx.x, by_ = blockIdx.y;
+#endif
+  const int tile_x0 = static_cast<int>(bx_) * kBlockX, tile_y0 = a.g.y0 + static_cast<int>(by_) * kPtRows;
   const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
   const f3 light_c = ld3(a.light_c);
   unsigned int rays = 0;
@@ -808,7 +820,9 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
       if (!BVH && a.bq_out_count) {
         const uint32_t cls = alive ? ray_class(a.clusters, o, d, a.tmax) : 0u;
         // (the per-wave append measures the same here: 117-120 us either way)
-        enqueue_binned_block(a, blk % kBinRegions, bin_cnt, bin_bases, alive, cls, wave, lane, pixg, rng, o, d, acc);
+        float dpt = 0.0f;  // the pixel's G-buffer depth rides in the record's spare component (the path's final store needs it)
+        if (alive) dpt = a.depth[static_cast<size_t>(tile_y0 + static_cast<int>(pix >> 6) - a.g.row_base) * a.g.W + tile_x0 + static_cast<int>(pix & 63u)];
+        enqueue_binned_block(a, blk % kBinRegions, bin_cnt, bin_bases, alive, cls, wave, lane, pixg, rng, o, d, acc, dpt);
       } else
         enqueue_paths(a, blk % kPathQueues, wave_cnt, &q_base, alive, wave, lane, pixg, rng, o, d, acc);
     }
@@ -980,12 +994,14 @@ void k_pathtrace_binned(PathtraceArgs a) {
       if (shade_segment(a, h, seg, light_c, o, d, acc, rng)) {
         alive = false;
         const size_t gi = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
-        a.image[gi] = make_float4(acc.x, acc.y, acc.z, a.depth[gi]);  // :328,:343 (+ depth in alpha)
+        // :328,:343 (+ depth in alpha: the record carries it — a gather from the depth plane here cost 1 % of K2; a
+        // non-temporal store of these scattered 16 bytes cost 5 %)
+        a.image[gi] = make_float4(acc.x, acc.y, acc.z, cur.q2.w);
       } else if (more) {
         cls_out = ray_class(a.clusters, o, d, a.tmax);
       }
     }
-    if (more) enqueue_binned(a, my_wave % kBinRegions, alive, cls_out, pix, rng, o, d, acc);
+    if (more) enqueue_binned(a, my_wave % kBinRegions, alive, cls_out, pix, rng, o, d, acc, cur.q2.w);
   }
   for (int off2 = 32; off2 > 0; off2 >>= 1) rays += __shfl_down(rays, off2, 64);
   if ((tid & 63) == 0 && rays) atomicAdd(&block_rays, rays);
