@@ -100,14 +100,6 @@ typedef struct rtpt_visibility_data {
                                               handing the paths that survive 4 / 8 / 16 segments to follow-up launches
                                               through a queue (A/B switch; the image is the same) */
 
-#define RTPT_FLAG_BINNED_PATHS 0x800u     /* path tracer, small scenes with separate objects, <= 8 segments: one launch per
-                                             segment, the paths handed on through queues binned by which objects' bounds the
-                                             next ray enters, so a wave tests only its class's triangles (16.5 instead of 32
-                                             per secondary ray on the Cornell box).  Same image.  It is what runs by default
-                                             for launches of >= 4 M pixels (4K: 449 vs 474 us) and loses below that (1080p:
-                                             153 vs 141 us: four launches of little work each); this bit forces it on at any
-                                             size, RTPT_FLAG_NO_BINNED_PATHS off (A/B switches) */
-#define RTPT_FLAG_NO_BINNED_PATHS 0x1000u
 #define RTPT_FLAG_NO_FILTER_FUSION 0x400u /* launch every pass when it is called, one kernel per call, instead of
                                              recording rtpt_temporal_filter's calls of a frame (consecutive iterations
                                              then run chained in one launch) and rtpt_gbuffer (which runs in one launch
@@ -363,10 +355,6 @@ int rtpt_util_load_obj(const char* path, float* xyz, uint32_t* n_verts, uint32_t
  * OBJ names one that does not exist (scenes/CornellBox-Original-Merged.obj:3) — *n_materials comes back 0. */
 int rtpt_util_load_obj_materials(const char* path, uint32_t* tri_material, uint32_t* n_tris, rtpt_material* materials,
                                  uint32_t* n_materials);
-/* Host-only view of the object clusters a small scene (<= 64 triangles, 9 floats each) is split into for the path
- * tracer's class-binned hand-over (RTPT_FLAG_NO_BINNED_PATHS): masks[0] = triangles tested for every ray, masks[1..2] =
- * the cull clusters, bounds = their padded min xyz / max xyz.  Returns the number of clusters (0..2) or a negative code. */
-int rtpt_util_clusters(const float* tris, uint32_t n_tris, uint64_t masks[3], float bounds[12]);
 /* Host-only self check of the acceleration-structure builder that stands in for the driver's BLAS/TLAS build
  * (buildAccelerationStructure, main.cpp:687-742): builds the BVH over `n_tris` world-space triangles (9 floats
  * each), packs the device nodes and verifies the invariants the traversal relies on.  Needs no GPU.

@@ -24,8 +24,6 @@ FLAG_EXT_ADAPTIVE_ALPHA, FLAG_EXT_GAUSS5, FLAG_EXT_POW2_STRIDE, FLAG_EXT_DISOCCL
 FLAG_EXT_VARIANCE = 0x100
 FLAG_SINGLE_LAUNCH_PATHS = 0x200
 FLAG_NO_FILTER_FUSION = 0x400
-FLAG_BINNED_PATHS = 0x800
-FLAG_NO_BINNED_PATHS = 0x1000
 FLAG_EXT_MASK = 0x1F0
 DEBUG_HIT_ID, DEBUG_PREV_PIXEL = 0x1, 0x2
 
@@ -96,7 +94,7 @@ SYMBOLS = [
     "rtpt_raytrace", "rtpt_temporal_filter", "rtpt_end_frame", "rtpt_sync", "rtpt_readback", "rtpt_set_plane",
     "rtpt_reset_counters", "rtpt_set_count_rows", "rtpt_enable_debug", "rtpt_timing_enable", "rtpt_timing_collect", "rtpt_kernel_name",
     "rtpt_selftest_math", "rtpt_selftest_trace", "rtpt_util_look_at", "rtpt_util_perspective", "rtpt_util_load_obj", "rtpt_util_bvh_check",
-    "rtpt_scene_set_materials", "rtpt_util_load_obj_materials", "rtpt_util_bvh_refit_check", "rtpt_util_clusters", "rtpt_set_external_guides",
+    "rtpt_scene_set_materials", "rtpt_util_load_obj_materials", "rtpt_util_bvh_refit_check", "rtpt_set_external_guides",
 ]
 
 _lib = None
@@ -149,7 +147,6 @@ def load() -> C.CDLL:
         "rtpt_util_bvh_check": [vp, u32, C.POINTER(C.c_uint64 * 8)],
         "rtpt_scene_set_materials": [vp, vp, u32, vp, u32],
         "rtpt_util_bvh_refit_check": [vp, vp, u32, C.POINTER(C.c_uint64 * 8)],
-        "rtpt_util_clusters": [vp, u32, C.POINTER(C.c_uint64 * 3), C.POINTER(C.c_float * 12)],
         "rtpt_util_load_obj_materials": [C.c_char_p, vp, C.POINTER(u32), vp, C.POINTER(u32)],
     }
     for name, args in sigs.items():
@@ -389,18 +386,6 @@ class Context:
         ts = np.zeros(len(rays), np.float32)
         _check(self._lib.rtpt_selftest_trace(self._h, _ptr(rays), len(rays), _ptr(ids), _ptr(ts)))
         return ids, ts
-
-
-def clusters(tris: np.ndarray):
-    """(always mask, [cluster masks], [(lo xyz, hi xyz)]) of a small scene: see rtpt_util_clusters (needs no GPU)"""
-    tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
-    masks = (C.c_uint64 * 3)()
-    bounds = (C.c_float * 12)()
-    n = load().rtpt_util_clusters(_ptr(tris), len(tris), C.byref(masks), C.byref(bounds))
-    if n < 0:
-        _check(n)
-    b = np.array(bounds, np.float32).reshape(2, 2, 3)
-    return int(masks[0]), [int(masks[1 + g]) for g in range(n)], [(b[g, 0], b[g, 1]) for g in range(n)]
 
 
 def bvh_check(tris: np.ndarray, built_for: np.ndarray | None = None) -> dict:

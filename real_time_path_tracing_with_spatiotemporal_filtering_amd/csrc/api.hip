@@ -92,11 +92,6 @@ struct rtpt_ctx {
   float model[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   uint64_t model_version = 0;          // bumped whenever the posed geometry changes
   uint64_t lut_version[2] = {~0ull, ~0ull};  // model_version each LUT buffer was built for
-  rt::ClusterInfo clusters{};          // small scenes: cull clusters of the class-binned path hand-over (kernels.hpp)
-  Buf bin_queue[2][2], bin_count;      // its record buffers [direction][buffer] and counters
-  Buf class_recs, class_ids;           // per class: the isect records / ids of its triangle set, contiguous
-  uint32_t class_off[rt::kPathClasses] = {0, 0, 0, 0}, class_cnt[rt::kPathClasses] = {0, 0, 0, 0};
-  uint32_t bin_region_cap = 0;
   Buf materials;                       // optional per-base-triangle (Kd, Ke) records, rtpt_scene_set_materials
   uint32_t n_base_tris = 0;
 
@@ -125,12 +120,10 @@ struct rtpt_ctx {
   int chain_max = 2;        // iterations per chained launch (1 = never chain)
   bool chain_final = false; // may a chain end in the FINAL pass
   // A chain slides down column strips in row segments and pays sum(s) + lag rows of pipeline fill per segment: with
-  // fewer pixels than this per launch the segments that fill the GPU are too short for that to pay (measured: 1080p
-  // 39.2 us chained vs 2 x 18.6 us separate; 4K 100.7 vs 2 x 63.8), so smaller launches run one kernel per iteration
+  // fewer pixels than this per launch the segments that fill the GPU are too short for that to pay, so smaller launches
+  // run one kernel per iteration (measured, pair vs 2 separate: 4K 98 vs 128 us, 1080p 38.2 vs 40.3, a 300-row strip of
+  // 3840 columns 27.1 vs 28.9 — the kernel itself no longer wins there, the launch it saves does: frame 0.171 vs 0.173 ms)
   int64_t chain_min_pixels = 1000000;
-  // the class-binned path hand-over (one launch per segment) has the same break-even: 4K 449 vs 474 us, a 1 095-row strip
-  // 250 vs 258, 1080p 153 vs 141, a 300-row strip 109 vs 91
-  int64_t binned_min_pixels = 4000000;
 
   // timing
   int timing_period = 0;          // 0 off, n: kernels of every n-th frame are bracketed by events
@@ -380,9 +373,6 @@ static int alloc_planes(rtpt_ctx* c) {
   if (rc == RTPT_OK) rc = alloc_buf(c->depth, px * 4);
   if (rc == RTPT_OK && !c->raycount.ptr) rc = alloc_buf(c->raycount, 8 * rt::kRayCounters);
   for (auto& b : c->path_queue) free_buf(b);  // sized per frame: re-created by the next rtpt_raytrace
-  for (auto& d : c->bin_queue)
-    for (auto& b : d) free_buf(b);
-  c->bin_region_cap = 0;
   free_buf(c->normals);  // sized per frame: re-created by the next rtpt_gbuffer
   c->normals_y0 = c->normals_y1 = 0;
   if (c->cfg.flags & RTPT_FLAG_EXT_VARIANCE) {
@@ -475,7 +465,6 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   if (const char* v = std::getenv("RTPT_CHAIN_MAX")) c->chain_max = std::max(1, std::min(3, std::atoi(v)));
   if (const char* v = std::getenv("RTPT_CHAIN_FINAL")) c->chain_final = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_CHAIN_MIN_PIXELS")) c->chain_min_pixels = std::atoll(v);
-  if (const char* v = std::getenv("RTPT_BINNED_MIN_PIXELS")) c->binned_min_pixels = std::atoll(v);
   int rc = alloc_planes(c);
   if (rc != RTPT_OK) {
     rtpt_destroy(c);
@@ -499,11 +488,6 @@ int rtpt_destroy(rtpt_ctx* c) {
   for (auto& b : c->vis) free_buf(b);
   free_buf(c->normals);
   free_buf(c->path_queue_count);
-  free_buf(c->bin_count);
-  free_buf(c->class_recs);
-  free_buf(c->class_ids);
-  for (auto& d : c->bin_queue)
-    for (auto& b : d) free_buf(b);
   for (auto& b : c->path_queue) free_buf(b);
   for (auto& b : c->moments) free_buf(b);
   for (auto& b : c->variance) free_buf(b);
@@ -645,7 +629,6 @@ int rtpt_enable_debug(rtpt_ctx* c, uint32_t mask) {
 }
 
 // ------------------------------------------------------------------------------------------ scene
-static int compute_clusters(rtpt_ctx* c);
 
 int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uint32_t* idx, uint32_t n_tris,
                       const float* xf, uint32_t n_instances) {
@@ -721,7 +704,6 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   for (int i = 0; i < 16; i++) c->model[i] = (i % 5 == 0) ? 1.0f : 0.0f;
   c->model_version++;
   c->use_bvh = (total > 64) || (c->cfg.flags & RTPT_FLAG_FORCE_BVH);
-  if ((rc = compute_clusters(c))) return rc;
   c->use_bvh = (total > 64) || (c->cfg.flags & RTPT_FLAG_FORCE_BVH);
   c->bvh_depth = bvh.max_depth;
   c->lut_prev_valid = false;
@@ -731,112 +713,6 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   return RTPT_OK;
 }
 
-// Cull clusters of a small scene (kernels.hpp ClusterInfo): connected components of the posed triangle soup (two
-// triangles are connected when they share a vertex position), of which up to kMaxClusters become clusters — those that
-// save the most tests: triangles x (1 - bounds area / scene bounds area) — and everything else is always tested.  The
-// bounds are padded like the BVH's boxes so the slab test never rejects a ray the triangle routine would accept (D4).
-static rt::ClusterInfo find_clusters(const float* T, uint32_t n) {
-  rt::ClusterInfo ci{};
-  ci.n = 0;
-  if (n == 0 || n > static_cast<uint32_t>(rt::kCullMaxTris)) return ci;
-  std::vector<uint32_t> parent(n);
-  for (uint32_t i = 0; i < n; i++) parent[i] = i;
-  auto find = [&](uint32_t x) {
-    while (parent[x] != x) x = parent[x] = parent[parent[x]];
-    return x;
-  };
-  for (uint32_t i = 0; i < n; i++)
-    for (uint32_t j = i + 1; j < n; j++) {
-      bool touch = false;
-      for (int a = 0; a < 3 && !touch; a++)
-        for (int b = 0; b < 3 && !touch; b++) touch = std::memcmp(T + 9 * i + 3 * a, T + 9 * j + 3 * b, 3 * sizeof(float)) == 0;
-      if (touch) parent[find(i)] = find(j);
-    }
-  struct Comp {
-    unsigned long long mask = 0;
-    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    int tris = 0;
-    double score = 0;
-  };
-  std::vector<Comp> comps;
-  std::vector<int> comp_of(n, -1);
-  float slo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, shi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (uint32_t i = 0; i < n; i++) {
-    const uint32_t r = find(i);
-    if (comp_of[r] < 0) {
-      comp_of[r] = static_cast<int>(comps.size());
-      comps.emplace_back();
-    }
-    Comp& cp = comps[static_cast<size_t>(comp_of[r])];
-    cp.mask |= 1ull << i;
-    cp.tris++;
-    for (int v = 0; v < 3; v++)
-      for (int a = 0; a < 3; a++) {
-        const float x = T[9 * i + 3 * v + a];
-        cp.lo[a] = std::min(cp.lo[a], x); cp.hi[a] = std::max(cp.hi[a], x);
-        slo[a] = std::min(slo[a], x); shi[a] = std::max(shi[a], x);
-      }
-  }
-  auto area = [](const float* lo, const float* hi) {
-    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-    return dx * dy + dy * dz + dz * dx;
-  };
-  const double scene_area = std::max(area(slo, shi), 1e-30);
-  for (auto& cp : comps) cp.score = cp.tris * (1.0 - std::min(1.0, area(cp.lo, cp.hi) / scene_area));
-  std::vector<size_t> order(comps.size());
-  for (size_t i = 0; i < order.size(); i++) order[i] = i;
-  std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return comps[x].score > comps[y].score || (comps[x].score == comps[y].score && x < y); });
-  float diag = 0.f, mag = 0.f;
-  for (int a = 0; a < 3; a++) {
-    diag += (shi[a] - slo[a]) * (shi[a] - slo[a]);
-    mag = std::max(mag, std::max(std::fabs(slo[a]), std::fabs(shi[a])));
-  }
-  const float pad = 1e-5f * std::max(std::sqrt(diag), mag);
-  unsigned long long used = 0;
-  for (size_t oi = 0; oi < order.size() && ci.n < rt::kMaxClusters; oi++) {
-    const Comp& cp = comps[order[oi]];
-    if (cp.score < 2.0) break;  // saves fewer than two triangle tests per ray: not worth a class bit
-    ci.mask[ci.n] = cp.mask;
-    for (int a = 0; a < 3; a++) {
-      ci.lo[ci.n][a] = cp.lo[a] - pad;
-      ci.hi[ci.n][a] = cp.hi[a] + pad;
-    }
-    used |= cp.mask;
-    ci.n++;
-  }
-  const unsigned long long all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-  ci.always = all & ~used;
-  return ci;
-}
-
-// (re)derive the clusters of the posed scene and the per-class record runs; enqueued on the context's stream behind
-// k_scene_prepare, whose isect records the gather reads
-static int compute_clusters(rtpt_ctx* c) {
-  c->clusters = rt::ClusterInfo{};
-  if (c->host_tris.empty() || c->use_bvh) return RTPT_OK;
-  const rt::ClusterInfo ci = find_clusters(c->host_tris.data(), c->n_tris);
-  if (ci.n == 0) return RTPT_OK;
-  std::vector<uint32_t> ids;
-  for (uint32_t cls = 0; cls < rt::kPathClasses; cls++) {
-    unsigned long long set = ci.always;
-    for (int g = 0; g < rt::kMaxClusters; g++)
-      if ((cls & (1u << g)) && g < ci.n) set |= ci.mask[g];
-    c->class_off[cls] = static_cast<uint32_t>(ids.size());
-    for (uint32_t t = 0; t < c->n_tris; t++)
-      if (set >> t & 1ull) ids.push_back(t);  // ascending id: equal-t ties keep the lower id (D4)
-    c->class_cnt[cls] = static_cast<uint32_t>(ids.size()) - c->class_off[cls];
-  }
-  int rc;
-  if ((rc = alloc_buf(c->class_ids, ids.size() * sizeof(uint32_t)))) return rc;
-  if ((rc = alloc_buf(c->class_recs, ids.size() * 48))) return rc;
-  HIP_TRY(hipMemcpyAsync(c->class_ids.ptr, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  rt::launch_class_records(static_cast<const float4*>(c->isect_id.ptr), static_cast<const uint32_t*>(c->class_ids.ptr),
-                           static_cast<uint32_t>(ids.size()), static_cast<float4*>(c->class_recs.ptr), c->stream);
-  if ((rc = launch_check("class_records"))) return rc;
-  HIP_TRY(hipStreamSynchronize(c->stream));  // `ids` dies at return
-  c->clusters = ci;
-  return RTPT_OK;
-}
 
 // Pose the scene with a new model matrix (visibility.vert.glsl:24 `model * position`; the reference recomputes
 // ubo.model every frame, main.cpp:1469, as the identity): world triangle = model * uploaded triangle, in the same
@@ -876,7 +752,6 @@ static int apply_model(rtpt_ctx* c, const float* model) {
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));  // host staging vectors die at return
   if (total <= static_cast<uint32_t>(rt::kCullMaxTris)) c->host_tris.swap(tris);
-  if ((rc = compute_clusters(c))) return rc;
   std::memcpy(c->model, model, sizeof c->model);
   c->model_version++;
   c->tables_valid = false;  // per-id normals and pair weights follow the posed triangles
@@ -1140,54 +1015,6 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
     a.queue[1] = c->path_queue[1].ptr;
     a.queue_count = static_cast<uint32_t*>(c->path_queue_count.ptr);
     a.queue_region = static_cast<uint32_t>(region);
-  }
-  a.clusters = rt::ClusterInfo{};
-  a.bq[0][0] = a.bq[0][1] = a.bq[1][0] = a.bq[1][1] = nullptr;
-  a.bq_count = nullptr;
-  a.bq_out[0] = a.bq_out[1] = nullptr;
-  a.bq_in[0] = a.bq_in[1] = nullptr;
-  a.bq_out_count = nullptr;
-  a.bq_in_count = nullptr;
-  a.bq_region_cap = 0;
-  a.class_recs = nullptr;
-  a.class_ids = nullptr;
-  for (uint32_t i = 0; i < rt::kPathClasses; i++) a.class_off[i] = a.class_cnt[i] = 0;
-  if (c->clusters.n > 0 && !c->use_bvh && a.compact && a.spp == 1 && a.max_segments >= 2 && a.max_segments <= rt::kBinnedMaxSegments &&
-      !(c->cfg.flags & (RTPT_FLAG_SINGLE_LAUNCH_PATHS | RTPT_FLAG_NO_BINNED_PATHS)) &&
-      ((c->cfg.flags & RTPT_FLAG_BINNED_PATHS) || static_cast<int64_t>(y1 - y0) * c->cfg.width >= c->binned_min_pixels) &&
-      c->cfg.width < 65536 && c->cfg.height < 65536) {
-    // class-binned hand-over (kernels.hpp): a region holds at most the survivors of the workgroups mapped to it —
-    // ceil(tiles / regions) tiles of 256 paths from the tile kernel; from a queue launch, (grid / regions) workgroups
-    // of at most ceil(chunks / grid) chunks each, chunks <= paths / 256 + one partial chunk per list
-    const size_t tiles = ((static_cast<size_t>(c->cfg.width) + 63) / 64) * ((c->rows() + 3) / 4);
-    const size_t grid = static_cast<size_t>(c->n_cu) * 8;  // >= the queue launches' grid
-    const size_t lists = rt::kBinRegions * rt::kPathClasses;
-    const size_t chunks = tiles + lists;
-    const size_t per_region = std::max((tiles + rt::kBinRegions - 1) / rt::kBinRegions,
-                                       ((grid + rt::kBinRegions - 1) / rt::kBinRegions) * ((chunks + grid - 1) / grid));
-    const uint32_t cap = static_cast<uint32_t>(per_region * 256);
-    if (c->bin_region_cap != cap) {
-      for (auto& d : c->bin_queue)
-        for (auto& b : d) free_buf(b);
-      c->bin_region_cap = 0;
-    }
-    if (!c->bin_count.ptr && (rc = alloc_buf(c->bin_count, 2 * lists * sizeof(uint32_t)))) return rc;
-    const int dirs = a.max_segments > 2 ? 2 : 1;
-    for (int d = 0; d < dirs; d++)
-      for (int b = 0; b < 2; b++)
-        if (!c->bin_queue[d][b].ptr && (rc = alloc_buf(c->bin_queue[d][b], static_cast<size_t>(cap) * rt::kBinRegions * 48))) return rc;
-    c->bin_region_cap = cap;
-    a.clusters = c->clusters;
-    for (int d = 0; d < 2; d++)
-      for (int b = 0; b < 2; b++) a.bq[d][b] = c->bin_queue[d][b].ptr;
-    a.bq_count = static_cast<uint32_t*>(c->bin_count.ptr);
-    a.bq_region_cap = cap;
-    a.class_recs = static_cast<const float4*>(c->class_recs.ptr);
-    a.class_ids = static_cast<const uint32_t*>(c->class_ids.ptr);
-    for (uint32_t i = 0; i < rt::kPathClasses; i++) {
-      a.class_off[i] = c->class_off[i];
-      a.class_cnt[i] = c->class_cnt[i];
-    }
   }
   a.cull = 0;
   if (!c->use_bvh && c->width_fits_i16()) {
@@ -1794,21 +1621,6 @@ static int bvh_check_impl(const float* build_tris, const float* tris, uint32_t n
     done[ni] = 1;
   }
   return RTPT_OK;
-}
-
-int rtpt_util_clusters(const float* tris, uint32_t n, uint64_t masks[3], float bounds[12]) {
-  if (!tris || !masks || !bounds) return fail(RTPT_E_INVALID, "NULL argument");
-  if (n == 0 || n > static_cast<uint32_t>(rt::kCullMaxTris)) return fail(RTPT_E_INVALID, "1..64 triangles");
-  const rt::ClusterInfo ci = find_clusters(tris, n);
-  masks[0] = ci.always;
-  for (int g = 0; g < rt::kMaxClusters; g++) {
-    masks[1 + g] = g < ci.n ? ci.mask[g] : 0;
-    for (int a = 0; a < 3; a++) {
-      bounds[6 * g + a] = g < ci.n ? ci.lo[g][a] : 0.f;
-      bounds[6 * g + 3 + a] = g < ci.n ? ci.hi[g][a] : 0.f;
-    }
-  }
-  return ci.n;
 }
 
 int rtpt_util_bvh_check(const float* tris, uint32_t n, uint64_t stats[8]) { return bvh_check_impl(nullptr, tris, n, stats); }

@@ -553,100 +553,6 @@ __device__ __forceinline__ void enqueue_paths(const PathtraceArgs& a, uint32_t r
   __syncthreads();  // wave_cnt / bcast may be reused right away
 }
 
-// ------------------------------------------------------------------------------------------
-// class-binned paths (ClusterInfo, kernels.hpp)
-// which cull clusters' bounds does the ray enter?  Conservative slab test: the bounds are padded like the BVH's boxes, a
-// direction component that is exactly 0 is clamped (inf - inf would drop the axis), NaN rays enter nothing (they cannot
-// hit, D7).
-__device__ __forceinline__ uint32_t ray_class(const ClusterInfo& ci, f3 o, f3 d, float tmax) {
-  auto nz = [](float v) { return __builtin_fabsf(v) < 1e-20f ? __builtin_copysignf(1e-20f, v) : v; };
-  const f3 rd{fast::rcp_(nz(d.x)), fast::rcp_(nz(d.y)), fast::rcp_(nz(d.z))};
-  uint32_t cls = 0;
-#pragma unroll
-  for (int g = 0; g < kMaxClusters; g++) {
-    if (g >= ci.n) break;
-    const float t0x = (ci.lo[g][0] - o.x) * rd.x, t1x = (ci.hi[g][0] - o.x) * rd.x;
-    const float t0y = (ci.lo[g][1] - o.y) * rd.y, t1y = (ci.hi[g][1] - o.y) * rd.y;
-    const float t0z = (ci.lo[g][2] - o.z) * rd.z, t1z = (ci.hi[g][2] - o.z) * rd.z;
-    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
-                                     __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
-    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
-                                     __builtin_fminf(__builtin_fmaxf(t0z, t1z), tmax));
-    // "not (tn > tf)": a NaN anywhere keeps the cluster (conservative); rays with NaN components are caught below
-    if (!(tn > tf)) cls |= 1u << g;
-  }
-  if (__builtin_isunordered(o.x, d.x) || __builtin_isunordered(o.y, d.y) || __builtin_isunordered(o.z, d.z)) cls = 0;
-  return cls;
-}
-
-// append a wave's surviving paths to the class-binned queues: one atomic per class present, all issued before the first
-// is waited for, no workgroup barrier (a workgroup-wide append — one atomic per class per workgroup behind two barriers —
-// cost the persistent queue kernel 100 of its 260 us: every wave of the workgroup idled through the atomic's round trip).
-// Records are stored as three float4 planes (structure of arrays) so that a wave's 64 records are three 1 KiB stores.
-__device__ __forceinline__ void enqueue_binned(const PathtraceArgs& a, uint32_t region, bool alive, uint32_t cls, uint32_t pixg, uint32_t rng,
-                                               f3 o, f3 d, f3 acc, float depth) {
-  // lane c reserves the slots of class c: the (up to) four atomics are ONE instruction and one round trip — issued one
-  // after the other, each waited for before the next, they were 4 x ~3 us of pure latency per 64 paths
-  const uint32_t lane = threadIdx.x & 63u;
-  unsigned long long mine = 0;
-  uint32_t cnt = 0;
-#pragma unroll
-  for (uint32_t c = 0; c < kPathClasses; c++) {
-    const unsigned long long m = __ballot(alive && cls == c);
-    if (lane == c) cnt = static_cast<uint32_t>(__builtin_popcountll(m));
-    if (cls == c) mine = m;
-  }
-  uint32_t b = 0;
-  if (lane < kPathClasses && cnt) b = atomicAdd(a.bq_out_count + region * kPathClasses + lane, cnt);
-  const uint32_t base = __shfl(b, static_cast<int>(cls), 64);
-  if (alive) {
-    const uint32_t off = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mine >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mine), 0u));
-    const size_t rbase = static_cast<size_t>(region) * a.bq_region_cap;
-    const size_t slot = (cls & 1u) ? rbase + a.bq_region_cap - 1u - off : rbase + off;  // odd classes grow down
-    const size_t plane = static_cast<size_t>(kBinRegions) * a.bq_region_cap;
-    float4* q = reinterpret_cast<float4*>(a.bq_out[cls >> 1]);
-    q[slot] = make_float4(__uint_as_float(pixg), __uint_as_float(rng), o.x, o.y);
-    q[plane + slot] = make_float4(o.z, d.x, d.y, d.z);
-    q[2 * plane + slot] = make_float4(acc.x, acc.y, acc.z, depth);
-  }
-}
-
-// the same append for a whole workgroup that is about to retire (the tile kernel): per-wave counts meet in LDS and ONE
-// atomic per class present serves the workgroup — a third of the returning atomics of the per-wave form
-__device__ __forceinline__ void enqueue_binned_block(const PathtraceArgs& a, uint32_t region, uint32_t (*wave_cnt)[kPathClasses],
-                                                     uint32_t* bases, bool alive, uint32_t cls, int wave, uint32_t lane, uint32_t pixg,
-                                                     uint32_t rng, f3 o, f3 d, f3 acc, float depth) {
-  unsigned long long mine = 0;
-#pragma unroll
-  for (uint32_t c = 0; c < kPathClasses; c++) {
-    const unsigned long long m = __ballot(alive && cls == c);
-    if (lane == 0) wave_cnt[wave][c] = static_cast<uint32_t>(__builtin_popcountll(m));
-    if (cls == c) mine = m;
-  }
-  __syncthreads();
-  const uint32_t tid = static_cast<uint32_t>(wave) * 64u + lane;
-  if (tid < kPathClasses) {
-    uint32_t total = 0;
-#pragma unroll
-    for (int w = 0; w < kPtRows; w++) total += wave_cnt[w][tid];
-    bases[tid] = total ? atomicAdd(a.bq_out_count + region * kPathClasses + tid, total) : 0u;
-  }
-  __syncthreads();
-  if (alive) {
-    uint32_t before = 0;
-    for (int w = 0; w < wave; w++) before += wave_cnt[w][cls];
-    const uint32_t off = bases[cls] + before +
-                         __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mine >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mine), 0u));
-    const size_t rbase = static_cast<size_t>(region) * a.bq_region_cap;
-    const size_t slot = (cls & 1u) ? rbase + a.bq_region_cap - 1u - off : rbase + off;  // odd classes grow down
-    const size_t plane = static_cast<size_t>(kBinRegions) * a.bq_region_cap;
-    float4* q = reinterpret_cast<float4*>(a.bq_out[cls >> 1]);
-    q[slot] = make_float4(__uint_as_float(pixg), __uint_as_float(rng), o.x, o.y);
-    q[plane + slot] = make_float4(o.z, d.x, d.y, d.z);
-    q[2 * plane + slot] = make_float4(acc.x, acc.y, acc.z, depth);
-  }
-}
-
 // K2 tile kernel with optional per-segment compaction (PathtraceArgs::compact).
 //
 // A 256-thread block owns a 64x4 pixel tile and advances all of its paths one segment at a time
@@ -697,8 +603,6 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
   uint32_t* const rng_pix = reinterpret_cast<uint32_t*>(sum_b + kPtThreads);
   __shared__ uint32_t wave_cnt[kPtRows];
   __shared__ uint32_t q_base;
-  __shared__ uint32_t bin_cnt[kPtRows][kPathClasses];
-  __shared__ uint32_t bin_bases[kPathClasses];
   __shared__ unsigned int block_rays;
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
@@ -817,14 +721,7 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
       const uint32_t pixg = (static_cast<uint32_t>(tile_y0 + static_cast<int>(pix >> 6)) << 16) |
                             static_cast<uint32_t>(tile_x0 + static_cast<int>(pix & 63u));
       const uint32_t blk = blockIdx.y * gridDim.x + blockIdx.x;
-      if (!BVH && a.bq_out_count) {
-        const uint32_t cls = alive ? ray_class(a.clusters, o, d, a.tmax) : 0u;
-        // (the per-wave append measures the same here: 117-120 us either way)
-        float dpt = 0.0f;  // the pixel's G-buffer depth rides in the record's spare component (the path's final store needs it)
-        if (alive) dpt = a.depth[static_cast<size_t>(tile_y0 + static_cast<int>(pix >> 6) - a.g.row_base) * a.g.W + tile_x0 + static_cast<int>(pix & 63u)];
-        enqueue_binned_block(a, blk % kBinRegions, bin_cnt, bin_bases, alive, cls, wave, lane, pixg, rng, o, d, acc, dpt);
-      } else
-        enqueue_paths(a, blk % kPathQueues, wave_cnt, &q_base, alive, wave, lane, pixg, rng, o, d, acc);
+      enqueue_paths(a, blk % kPathQueues, wave_cnt, &q_base, alive, wave, lane, pixg, rng, o, d, acc);
     }
   }
   __syncthreads();
@@ -861,172 +758,6 @@ void k_pathtrace_small(PathtraceArgs a) {
   pathtrace_tile<false, COMPACT>(a);
 }
 
-// ------------------------------------------------------------------------------------------
-// class-binned paths: the queue kernel
-// One segment (a.seg_begin) of every queued path.  A WAVE takes 64-record pieces of one list = (region, class), so it
-// tests one triangle set: always | the class's clusters, stored as a contiguous run of records in ascending id order
-// (equal-t ties keep the lower id, D4 — the triangles left out cannot be hit: the ray misses their cluster's padded
-// bounds).  Survivors are classified by their new ray and appended to the out queues; a path that ends writes its pixel.
-// Waves are independent after the prologue: no workgroup barrier in the loop.
-__global__ __launch_bounds__(kPtThreads)
-#if RTPT_PT_WAVES
-__attribute__((amdgpu_waves_per_eu(RTPT_PT_WAVES, RTPT_PT_WAVES)))
-#endif
-void k_pathtrace_binned(PathtraceArgs a) {
-  constexpr uint32_t kLists = kBinRegions * kPathClasses;
-  constexpr uint32_t kPer = (kLists + kPtThreads - 1) / kPtThreads;  // lists per thread in the prefix scan
-  __shared__ uint32_t prefix[kLists + 1];   // 64-record pieces before list l
-  __shared__ uint32_t counts[kLists];
-  __shared__ uint32_t part[kPtThreads + 1];
-  __shared__ unsigned int block_rays;
-  const int tid = threadIdx.y * kBlockX + threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
-  const uint32_t lane = threadIdx.x;
-  if (tid == 0) block_rays = 0;
-  {
-    uint32_t mine = 0;
-    for (uint32_t i = 0; i < kPer; i++) {
-      const uint32_t l = static_cast<uint32_t>(tid) * kPer + i;
-      if (l >= kLists) break;
-      const uint32_t cnt = a.bq_in_count[l];
-      counts[l] = cnt;
-      mine += (cnt + 63u) / 64u;
-    }
-    part[tid + 1] = mine;
-    if (tid == 0) part[0] = 0;
-    __syncthreads();
-    for (uint32_t step = 1; step < kPtThreads; step <<= 1) {  // inclusive scan of part[1..]
-      const uint32_t v = (static_cast<uint32_t>(tid) >= step) ? part[tid + 1 - step] : 0u;
-      __syncthreads();
-      part[tid + 1] += v;
-      __syncthreads();
-    }
-    uint32_t run = part[tid];
-    for (uint32_t i = 0; i < kPer; i++) {
-      const uint32_t l = static_cast<uint32_t>(tid) * kPer + i;
-      if (l >= kLists) break;
-      prefix[l] = run;
-      run += (counts[l] + 63u) / 64u;
-    }
-    if (tid == kPtThreads - 1) prefix[kLists] = part[kPtThreads];
-    __syncthreads();
-  }
-  const uint32_t total_pieces = prefix[kLists];
-  const f3 light_c = ld3(a.light_c);
-  const uint32_t seg = a.seg_begin;
-  const bool more = seg + 1 < a.max_segments;  // survivors are handed on (otherwise shade_segment ends every path)
-  const uint32_t n_waves = gridDim.x * kPtRows, my_wave = blockIdx.x * kPtRows + static_cast<uint32_t>(wave);
-  const size_t plane = static_cast<size_t>(kBinRegions) * a.bq_region_cap;
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  using cv4f = const __attribute__((address_space(4))) v4f;
-  using cu32 = const __attribute__((address_space(4))) uint32_t;
-  unsigned int rays = 0;
-  // this wave's pieces are j = my_wave + i * n_waves.  Which list holds piece j — the largest l with prefix[l] <= j — is
-  // found for 64 pieces at a time, lane i searching for piece i, so the ten dependent LDS reads of the binary search are
-  // paid once per 64 pieces instead of once per piece; the loop below fetches lane i's answer with a readlane.
-  const uint32_t my_pieces = my_wave < total_pieces ? (total_pieces - 1u - my_wave) / n_waves + 1u : 0u;
-  auto locate = [&](uint32_t i0) -> uint32_t {
-    const uint32_t j = my_wave + (i0 + lane) * n_waves;
-    uint32_t lo = 0, hi = kLists;
-    if (j < total_pieces)
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (prefix[mid] <= j) lo = mid; else hi = mid;
-      }
-    return lo;
-  };
-  // one piece of 64 records, read ahead of its use: the loads of piece i + 1 are in flight while piece i is traced
-  struct Piece {
-    float4 q0, q1, q2;
-    uint32_t list;
-    bool alive;
-  };
-  auto fetch = [&](uint32_t list, uint32_t j) -> Piece {
-    Piece p;
-    p.list = list;
-    const uint32_t region = list / kPathClasses, cls = list % kPathClasses;
-    const uint32_t off = (j - prefix[list]) * 64u + lane;
-    p.alive = off < counts[list];
-    p.q0 = p.q1 = p.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.alive) {
-      const size_t rbase = static_cast<size_t>(region) * a.bq_region_cap;
-      const size_t slot = (cls & 1u) ? rbase + a.bq_region_cap - 1u - off : rbase + off;
-      const float4* q = reinterpret_cast<const float4*>(a.bq_in[cls >> 1]);
-      p.q0 = q[slot];
-      p.q1 = q[plane + slot];
-      p.q2 = q[2 * plane + slot];
-    }
-    return p;
-  };
-  uint32_t tbl = my_pieces ? locate(0) : 0u;
-  Piece nxt{};
-  if (my_pieces) nxt = fetch(__builtin_amdgcn_readlane(tbl, 0), my_wave);
-#pragma unroll 1
-  for (uint32_t i = 0; i < my_pieces; i++) {  // wave-uniform
-    const Piece cur = nxt;
-    if (i + 1 < my_pieces) {
-      if (((i + 1) & 63u) == 0u) tbl = locate(i + 1);
-      const uint32_t nl = __builtin_amdgcn_readfirstlane(__shfl(tbl, static_cast<int>((i + 1) & 63u), 64));
-      nxt = fetch(nl, my_wave + (i + 1) * n_waves);
-    }
-    const uint32_t cls_in = cur.list % kPathClasses;
-    bool alive = cur.alive;
-    uint32_t pix = __float_as_uint(cur.q0.x), rng = __float_as_uint(cur.q0.y);
-    f3 o{cur.q0.z, cur.q0.w, cur.q1.x}, d{cur.q1.y, cur.q1.z, cur.q1.w}, acc{cur.q2.x, cur.q2.y, cur.q2.z};
-    uint32_t cls_out = 0;
-    if (alive) {
-      HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
-      {
-        // :208-222 over the class's triangle run; the records are read through the constant address space (scalar
-        // loads into SGPR operands, like closest_hit_brute)
-        cv4f* rec = (cv4f*)(a.class_recs + 3 * static_cast<size_t>(a.class_off[cls_in]));
-        cu32* ids = (cu32*)(a.class_ids + a.class_off[cls_in]);
-        const uint32_t n = a.class_cnt[cls_in];
-#pragma unroll 4
-        for (uint32_t t = 0; t < n; t++) {
-          const v4f a0 = rec[3 * t], a1 = rec[3 * t + 1], a2 = rec[3 * t + 2];
-          tri_test<false>(o, d, make_float4(a0.x, a0.y, a0.z, a0.w), make_float4(a1.x, a1.y, a1.z, a1.w),
-                          make_float4(a2.x, a2.y, a2.z, a2.w), ids[t] + 1, h);
-        }
-      }
-      const int x = static_cast<int>(pix & 0xFFFFu), y = static_cast<int>(pix >> 16);
-      if (y >= a.count_y0 && y < a.count_y1) rays++;
-      if (shade_segment(a, h, seg, light_c, o, d, acc, rng)) {
-        alive = false;
-        const size_t gi = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
-        // :328,:343 (+ depth in alpha: the record carries it — a gather from the depth plane here cost 1 % of K2; a
-        // non-temporal store of these scattered 16 bytes cost 5 %)
-        a.image[gi] = make_float4(acc.x, acc.y, acc.z, cur.q2.w);
-      } else if (more) {
-        cls_out = ray_class(a.clusters, o, d, a.tmax);
-      }
-    }
-    if (more) enqueue_binned(a, my_wave % kBinRegions, alive, cls_out, pix, rng, o, d, acc, cur.q2.w);
-  }
-  for (int off2 = 32; off2 > 0; off2 >>= 1) rays += __shfl_down(rays, off2, 64);
-  if ((tid & 63) == 0 && rays) atomicAdd(&block_rays, rays);
-  __syncthreads();
-  if (tid == 0 && block_rays) atomicAdd(a.raycount + (blockIdx.x & (kRayCounters - 1u)), static_cast<unsigned long long>(block_rays));
-}
-
-__global__ void k_class_records(const float4* isect_id, const uint32_t* ids, uint32_t n, float4* out) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const uint32_t id = ids[t];
-  out[3 * t] = isect_id[3 * id];
-  out[3 * t + 1] = isect_id[3 * id + 1];
-  out[3 * t + 2] = isect_id[3 * id + 2];
-}
-
-// ------------------------------------------------------------------------------------------
-// self tests
-// Later segments of long paths.  By segment 8 a quarter of the Cornell box's paths is still alive, by segment 16 a
-// tenth: a 64x4 tile is then one partly filled wave in a workgroup that still holds its LDS and wave slots, and the
-// kernel — which needs its occupancy — runs a handful of waves per CU.  So a launch covers a window of segments
-// [seg_begin, seg_end) only and hands its survivors to the next one through a queue in global memory (48-byte records,
-// one atomic per wave), where they are dense again: this kernel takes 256 queued paths per workgroup, runs the same
-// segment body with the same per-segment compaction, and queues what is left for the window after it.  Each path
-// still executes the reference's loop with its own RNG stream, so the image does not change.
 template <bool BVH>
 __global__ __launch_bounds__(kPtThreads) void k_pathtrace_queue(PathtraceArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t stack[];
@@ -1149,10 +880,6 @@ void launch_scene_prepare(const ScenePrepArgs& a, hipStream_t s) {
   if (!a.n_tris) return;
   hipLaunchKernelGGL(k_scene_prepare, dim3((a.n_tris + 255) / 256), dim3(256), 0, s, a);
 }
-void launch_class_records(const float4* isect_id, const uint32_t* ids, uint32_t n, float4* out, hipStream_t s) {
-  if (!n) return;
-  hipLaunchKernelGGL(k_class_records, dim3((n + 255) / 256), dim3(256), 0, s, isect_id, ids, n, out);
-}
 void launch_lut(const LutArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_lut, dim3((a.n_tris + 256) / 256), dim3(256), 0, s, a);
   if (a.pair_tab) {
@@ -1181,45 +908,6 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
   b.multi_off = static_cast<uint32_t>(dyn / 4);
   const size_t dyn_queue = dyn;
   if (a.spp > 1) dyn += 4 * kPtThreads * 4;  // sum_r, sum_g, sum_b, rng_pix
-  if (a.clusters.n > 0 && !a.scene.use_bvh && a.spp == 1 && a.compact && a.bq[0][0] && a.bq_count && a.max_segments >= 2 &&
-      a.max_segments <= kBinnedMaxSegments) {
-    // class-binned wavefront: the tile kernel traces the (coherent, screen-culled) primary segment and bins the
-    // survivors by the class of their next ray; one launch per later segment consumes the bins
-    const size_t cbytes = kBinRegions * kPathClasses * sizeof(uint32_t);
-    (void)hipMemsetAsync(a.bq_count, 0, 2 * cbytes, s);
-    b.seg_begin = 0;
-    b.seg_end = 1;
-    b.q_in = b.q_out = nullptr;
-    b.q_in_count = b.q_out_count = nullptr;
-    b.bq_in[0] = b.bq_in[1] = nullptr;
-    b.bq_in_count = nullptr;
-    b.bq_out[0] = a.bq[0][0];
-    b.bq_out[1] = a.bq[0][1];
-    b.bq_out_count = a.bq_count;
-    hipLaunchKernelGGL((k_pathtrace_small<true>), grid, block, dyn, s, b);
-    // one resident generation of waves (the kernel's registers admit 7 waves per SIMD = 7 workgroups of 4 per CU) —
-    // a grid of 8 per CU ran its last workgroups as a second round behind the first
-    const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
-    const dim3 qgrid(static_cast<uint32_t>(n_cu) * (RTPT_PT_WAVES ? RTPT_PT_WAVES : 7u));
-    for (uint32_t seg = 1; seg < a.max_segments; seg++) {
-      const uint32_t in = (seg - 1) & 1u, out = seg & 1u;
-      const bool more = seg + 1 < a.max_segments;
-      PathtraceArgs c = b;
-      c.seg_begin = seg;
-      c.seg_end = seg + 1;
-      c.bq_in[0] = a.bq[in][0];
-      c.bq_in[1] = a.bq[in][1];
-      c.bq_in_count = a.bq_count + in * kBinRegions * kPathClasses;
-      c.bq_out[0] = more ? a.bq[out][0] : nullptr;
-      c.bq_out[1] = more ? a.bq[out][1] : nullptr;
-      c.bq_out_count = more ? a.bq_count + out * kBinRegions * kPathClasses : nullptr;
-      if (more && seg >= 2) (void)hipMemsetAsync(a.bq_count + out * kBinRegions * kPathClasses, 0, cbytes, s);
-      hipLaunchKernelGGL(k_pathtrace_binned, qgrid, block, 0, s, c);
-    }
-    return;
-  }
-  b.bq_out_count = nullptr;  // the windowed paths below hand over through the plain queue
-  b.bq_in_count = nullptr;
   const uint32_t phase0 = pt_first_window(a.scene.use_bvh != 0);
   const bool split = a.spp == 1 && a.compact && a.queue[0] && a.queue_count && a.max_segments > phase0 &&
                      (a.max_segments <= 2 * phase0 || a.queue[1]);

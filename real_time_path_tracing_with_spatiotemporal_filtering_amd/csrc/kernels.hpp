@@ -88,25 +88,6 @@ struct GradientArgs {
   float4* grad;
 };
 
-// Small scenes (<= 64 triangles, wave-uniform brute force): secondary rays are incoherent, so no wave can skip a
-// triangle on its own — but most rays miss most OBJECTS.  At scene upload the triangles are grouped into connected
-// components; up to kMaxClusters of them (the ones whose bounds are small against the scene's) become CULL CLUSTERS, the
-// rest is the always-tested set.  A ray's class = which cluster bounds it enters (kMaxClusters bits); paths are handed
-// from one segment to the next through queues binned by class, so the waves of the next segment are class-homogeneous
-// and test always_mask | the masks of the class's clusters — on the Cornell box 12 + 10 P(short box) + 10 P(tall box)
-// = 16.5 of 32 triangles per secondary ray on average (60 % of them enter neither box's bounds).
-constexpr int kMaxClusters = 2;
-constexpr uint32_t kPathClasses = 1u << kMaxClusters;
-constexpr uint32_t kBinRegions = 256;  // per-class queues are split into regions with their own counters: an append is
-                                       // an atomic WITH return, and those serialise at ~90 ns per address on this part
-                                       // (measured: 390 k of them over 256 counters added 135 us to a 129 us launch)
-struct ClusterInfo {
-  int32_t n;                    // cull clusters in use (0: no binning)
-  unsigned long long always;    // triangles tested for every ray
-  unsigned long long mask[kMaxClusters];
-  float lo[kMaxClusters][3], hi[kMaxClusters][3];  // padded bounds
-};
-
 struct PathtraceArgs {
   FrameGeom g;
   SceneView scene;
@@ -138,23 +119,6 @@ struct PathtraceArgs {
   void* queue[2];
   uint32_t* queue_count;       // [2][kPathQueues]
   uint32_t queue_region;       // records per region (a queue buffer holds kPathQueues regions)
-  // class-binned hand-over (ClusterInfo above): two record buffers per direction — buffer 0 holds class 0 growing up
-  // and class 1 growing down inside each region, buffer 1 classes 2 and 3 — so a region can never overflow (it holds
-  // the survivors of the workgroups mapped to it, whatever their classes)
-  ClusterInfo clusters;
-  void* bq[2][2];               // context storage: [direction][buffer] (set by the ABI layer; NULL = no binning)
-  uint32_t* bq_count;           // [2][kBinRegions][kPathClasses]
-  void* bq_out[2];
-  uint32_t* bq_out_count;       // [kBinRegions][kPathClasses]
-  const void* bq_in[2];
-  const uint32_t* bq_in_count;
-  uint32_t bq_region_cap;       // records per region
-  // per class: the isect records of its triangle set (always | the class's clusters, ascending id) as one contiguous
-  // run, so the closest-hit loop is the unrolled scalar-load loop of the full scene — walking a bit mask instead costs
-  // three times as much per test (measured: 32 tests unrolled 203 us, 16.5 tests by mask 262 us for the same launch)
-  const float4* class_recs;     // [class_off[c] .. + class_cnt[c]) x 3 float4
-  const uint32_t* class_ids;    // triangle id of each entry
-  uint32_t class_off[kPathClasses], class_cnt[kPathClasses];
   TriBounds bounds[kCullMaxTris];
 };
 
@@ -234,9 +198,6 @@ constexpr uint32_t kPathQueues = RTPT_PATH_QUEUES;  // regions (and counters) pe
 #ifndef RTPT_PT_BVH_MULT
 #define RTPT_PT_BVH_MULT 2
 #endif
-// class-binned hand-over after EVERY segment pays while a launch per segment is affordable: up to this many segments
-// (the BASELINE configs use 2 / 4 / 8); longer paths (the reference's own bound is 32) keep the segment windows above
-constexpr uint32_t kBinnedMaxSegments = 8;
 inline uint32_t pt_first_window(bool use_bvh) { return use_bvh ? RTPT_PT_BVH_MULT * RTPT_PT_PHASE0 : RTPT_PT_PHASE0; }
 
 constexpr uint32_t kRayCounters = 256;  // RAYCOUNT is kept as this many partial sums (power of two), added up at readback
@@ -256,7 +217,6 @@ struct ScenePrepArgs {
 
 void launch_scene_prepare(const ScenePrepArgs& a, hipStream_t s);
 // gather isect records into class order: out[t] = isect_id[ids[t]] (3 float4 each), n entries
-void launch_class_records(const float4* isect_id, const uint32_t* ids, uint32_t n, float4* out, hipStream_t s);
 void launch_lut(const LutArgs& a, hipStream_t s);
 void launch_gbuffer(const GbufferArgs& a, hipStream_t s);
 void launch_gradient(const GradientArgs& a, hipStream_t s);
