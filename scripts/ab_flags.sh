@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench.py per (workload, flags) pair on the GPU box, K2 kernel table only.  usage: scripts/ab_flags.sh <outdir> "4k 0x1000" "1080p 0" ...
+# bench.py per (workload, flags) pair on the GPU box, K2 kernel table only.  usage: scripts/ab_flags.sh <outdir> "4k 0x400" "1080p 0" ...
 OUT=$1; shift
 mkdir -p "$OUT"
 for CFG in "$@"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-launch durations of the K2 kernels of the last traced frame (rocprofv3 --kernel-trace), one library per argument
-# usage: [K2_ARGS="--flags 0x800"] scripts/k2_launches.sh <outdir> default|lib.so ...
+# usage: [K2_ARGS="--flags 0x200"] scripts/k2_launches.sh <outdir> default|lib.so ...
 OUT=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
