@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def chain_every_size(monkeypatch, request):
-    """by default only launches of >= 4 M pixels are chained (shorter row segments do not pay for the pipeline fill);
+    """by default only launches of >= 1 M pixels are chained (shorter row segments do not pay for the pipeline fill);
     these tests want the chain at every size — the knob is read by rtpt_create"""
     if "default_policy" not in request.keywords:
         monkeypatch.setenv("RTPT_CHAIN_MIN_PIXELS", "0")
@@ -62,7 +62,7 @@ def test_chain_is_what_runs_by_default_on_large_frames(hip_lib):
     """the timing hooks name the launches: at 4K N = 5 is two chained pairs + the final pass, not four k_atrous
     launches; a small frame, and RTPT_FLAG_NO_FILTER_FUSION at any size, run one kernel per iteration"""
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
-    for (w, h, flags, want) in ((3840, 2160, 0, (6, 0, 3)), (320, 200, 0, (0, 12, 3)),
+    for (w, h, flags, want) in ((3840, 2160, 0, (6, 0, 3)), (1920, 1080, 0, (6, 0, 3)), (320, 200, 0, (0, 12, 3)),
                                 (3840, 2160, hip_lib.FLAG_NO_FILTER_FUSION, (0, 12, 3))):
         app = make_app(w, h, max_segments=1, iterations=5, flags=flags)
         ctx = app.backend.ctx
