@@ -126,6 +126,12 @@ struct rtpt_ctx {
   int64_t chain_min_pixels = 1000000;
 
   // timing
+  // BVH traversal: stack entries per lane kept in LDS (kernels.hpp SceneView::stack_lds) and the global-memory home of
+  // the deeper ones, sized for the largest grid that traverses (ensure_stack_spill)
+  int bvh_stack_lds = 16;
+  Buf stack_spill;
+  size_t stack_spill_blocks = 0;
+
   int timing_period = 0;          // 0 off, n: kernels of every n-th frame are bracketed by events
   uint64_t frames_ended = 0;
   bool timing_now() const { return timing_period > 0 && (frames_ended % static_cast<uint64_t>(timing_period)) == 0; }
@@ -148,6 +154,33 @@ int gbuffer_flush(rtpt_ctx* c);
     if (rcf_ == RTPT_OK) rcf_ = filter_flush((c), false); \
     if (rcf_) return rcf_;                           \
   } while (0)
+
+int alloc_buf(Buf& b, size_t bytes);
+void free_buf(Buf& b);
+// workgroups of the largest per-frame launch that traverses the BVH: the 64 x 4-pixel tiles of the stored rows
+// (k_gbuffer, the tile kernel) or the persistent queue kernel's grid
+size_t frame_blocks(const rtpt_ctx* c) {
+  const size_t tiles = ((static_cast<size_t>(c->cfg.width) + 63) / 64) * ((static_cast<size_t>(c->cfg.row_end - c->cfg.row_begin) + 3) / 4);
+  return std::max(tiles, static_cast<size_t>(c->n_cu > 0 ? c->n_cu : 256) * 8);
+}
+// the spill area of the BVH traversal stack holds (stack depth - LDS entries) x workgroups x 256 entries: grown (never
+// shrunk) before a launch whose grid is larger than any before it
+int ensure_stack_spill(rtpt_ctx* c, size_t blocks) {
+  if (!c->use_bvh) return RTPT_OK;
+  const size_t depth = static_cast<size_t>(c->bvh_depth + 2 < 8 ? 8 : c->bvh_depth + 2);
+  const size_t lds = std::min<size_t>(depth, static_cast<size_t>(c->bvh_stack_lds));
+  if (depth <= lds || blocks <= c->stack_spill_blocks) return RTPT_OK;
+  if (c->stack_spill.ptr) {
+    hipError_t e = hipStreamSynchronize(c->stream);  // launches that spill into the old area
+    if (e != hipSuccess) return fail(RTPT_E_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    free_buf(c->stack_spill);
+  }
+  c->stack_spill_blocks = 0;
+  int rc = alloc_buf(c->stack_spill, (depth - lds) * blocks * 256 * sizeof(uint32_t));
+  if (rc) return rc;
+  c->stack_spill_blocks = blocks;
+  return RTPT_OK;
+}
 
 int alloc_buf(Buf& b, size_t bytes) {
   if (b.owned && b.ptr) (void)hipFree(b.ptr);
@@ -272,6 +305,8 @@ rt::SceneView scene_view(const rtpt_ctx* c) {
   s.n_tris = c->n_tris;
   s.use_bvh = c->use_bvh ? 1u : 0u;
   s.stack_depth = static_cast<uint32_t>(c->bvh_depth + 2 < 8 ? 8 : c->bvh_depth + 2);
+  s.stack_lds = std::min<uint32_t>(s.stack_depth, static_cast<uint32_t>(c->bvh_stack_lds));
+  s.stack_spill = static_cast<uint32_t*>(c->stack_spill.ptr);
   s.materials = static_cast<const float4*>(c->materials.ptr);
   s.n_base_tris = c->n_base_tris ? c->n_base_tris : 1u;
   return s;
@@ -464,6 +499,7 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   // tuning knobs for A/B runs on the box (never needed for correctness: every setting computes the same pixels)
   if (const char* v = std::getenv("RTPT_CHAIN_MAX")) c->chain_max = std::max(1, std::min(3, std::atoi(v)));
   if (const char* v = std::getenv("RTPT_CHAIN_FINAL")) c->chain_final = std::atoi(v) != 0;
+  if (const char* v = std::getenv("RTPT_BVH_STACK_LDS")) c->bvh_stack_lds = std::max(1, std::atoi(v));
   if (const char* v = std::getenv("RTPT_CHAIN_MIN_PIXELS")) c->chain_min_pixels = std::atoll(v);
   int rc = alloc_planes(c);
   if (rc != RTPT_OK) {
@@ -696,6 +732,8 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   c->n_tris = total;
   c->n_base_tris = n_tris;
   free_buf(c->materials);  // materials belong to the mesh that was replaced
+  free_buf(c->stack_spill);  // sized by the depth of the tree that was replaced
+  c->stack_spill_blocks = 0;
   if (total <= static_cast<uint32_t>(rt::kCullMaxTris))
     c->host_tris = tris;
   else
@@ -834,6 +872,7 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
   }
   rt::GbufferArgs a;
   a.g = geom(c, y0, y1);
+  if ((rc = ensure_stack_spill(c, frame_blocks(c)))) return rc;
   a.scene = scene_view(c);
   const float* V = ubo->view;
   rt::f3 tcol{V[12], V[13], V[14]};
@@ -974,6 +1013,7 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   FLUSH_FILTER(c);
   rt::PathtraceArgs a;
   a.g = geom(c, y0, y1);
+  if ((rc = ensure_stack_spill(c, frame_blocks(c)))) return rc;
   a.scene = scene_view(c);
   a.frame = pc->frameNumber;
   a.batch = pc->sample_batch;
@@ -1486,6 +1526,12 @@ int rtpt_selftest_trace(rtpt_ctx* c, const float* rays, size_t n, uint32_t* out_
   if (e == hipSuccess) e = hipMalloc(&dt, n * 4);
   if (e == hipSuccess) e = hipMemcpyAsync(drays, rays, n * 24, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
+    if (int rcs = ensure_stack_spill(c, std::max(frame_blocks(c), (n + 255) / 256))) {
+      (void)hipFree(drays);
+      (void)hipFree(did);
+      (void)hipFree(dt);
+      return rcs;
+    }
     rt::launch_selftest_trace(scene_view(c), drays, n, c->cfg.ray_tmax, did, dt, c->stream);
     e = hipGetLastError();
   }

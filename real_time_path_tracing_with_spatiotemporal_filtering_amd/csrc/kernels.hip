@@ -162,10 +162,21 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
   const f3 oi{(sc.bvh_origin[0] - o.x) * rd.x, (sc.bvh_origin[1] - o.y) * rd.y, (sc.bvh_origin[2] - o.z) * rd.z};
   int sp = 0;
   uint32_t cur = 0;  // root pair
+  // entries [0, stack_lds) in LDS, the rest in global memory (SceneView::stack_spill)
+  const int lds_levels = static_cast<int>(sc.stack_lds);
+  const size_t spill_stride = static_cast<size_t>(gridDim.x) * gridDim.y * nt;
+  uint32_t* const spill = sc.stack_spill + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * nt + tid;
+  auto push = [&](uint32_t v) {
+    if (sp < lds_levels)
+      stack[sp * nt + tid] = v;
+    else
+      spill[static_cast<size_t>(sp - lds_levels) * spill_stride] = v;
+    sp++;
+  };
   auto pop = [&]() -> uint32_t {
     if (sp > 0) {
       sp--;
-      return stack[sp * nt + tid];
+      return sp < lds_levels ? stack[sp * nt + tid] : spill[static_cast<size_t>(sp - lds_levels) * spill_stride];
     }
     return kSentinel;
   };
@@ -212,8 +223,7 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
     const bool hl = sl & (cl != kBvhEmpty), hr = sr & (cr != kBvhEmpty);
     if (hl && hr) {
       const bool left_first = tl <= tr;
-      stack[sp * nt + tid] = left_first ? cr : cl;
-      sp++;
+      push(left_first ? cr : cl);
       cur = left_first ? cl : cr;
     } else if (hl) {
       cur = cl;
@@ -745,8 +755,19 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
 
 // the two kernels of the tile body: the wave-uniform brute-force one is pinned at 8 waves per SIMD (above), the BVH one
 // is LDS-limited anyway and loses 4 % to the scalar spills the pin costs (1.15M-triangle trace 3.69 -> 3.85 ms)
+// The BVH variant waits on memory for most of its wave-cycles and is that sensitive to occupancy (kernels.hpp
+// SceneView::stack_lds); with the stack's LDS share cut to 16 entries the registers set the limit.  1.15M-triangle trace,
+// 5 waves per SIMD (the compiler's 79 VGPRs and the old 30 KB stack) 3.69 ms; pinned at 6 / 7 / 8: 3.93 / 3.55 / 3.36 ms
+// (at 8: 64 VGPRs and 8 dwords of scratch per lane).
+#ifndef RTPT_PT_BVH_WAVES
+#define RTPT_PT_BVH_WAVES 8
+#endif
 template <bool BVH, bool COMPACT>
-__global__ __launch_bounds__(kPtThreads) void k_pathtrace(PathtraceArgs a) {
+__global__ __launch_bounds__(kPtThreads)
+#if RTPT_PT_BVH_WAVES
+__attribute__((amdgpu_waves_per_eu(RTPT_PT_BVH_WAVES, RTPT_PT_BVH_WAVES)))
+#endif
+void k_pathtrace(PathtraceArgs a) {
   pathtrace_tile<BVH, COMPACT>(a);
 }
 template <bool COMPACT>
@@ -890,7 +911,7 @@ void launch_lut(const LutArgs& a, hipStream_t s) {
 void launch_gbuffer(const GbufferArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;
   if (a.scene.use_bvh)
-    hipLaunchKernelGGL(k_gbuffer<true>, grid_for(a.g), dim3(kBlockX, kBlockY), a.scene.stack_depth * kThreads * 4, s, a);
+    hipLaunchKernelGGL(k_gbuffer<true>, grid_for(a.g), dim3(kBlockX, kBlockY), a.scene.stack_lds * kThreads * 4, s, a);
   else
     hipLaunchKernelGGL(k_gbuffer<false>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
 }
@@ -902,7 +923,7 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;
   dim3 block(kBlockX, kPtRows);
   const dim3 grid((a.g.W + kBlockX - 1) / kBlockX, (a.g.y1 - a.g.y0 + kPtRows - 1) / kPtRows, 1);
-  const size_t stack_bytes = a.scene.use_bvh ? static_cast<size_t>(a.scene.stack_depth) * kPtThreads * 4 : 0;
+  const size_t stack_bytes = a.scene.use_bvh ? static_cast<size_t>(a.scene.stack_lds) * kPtThreads * 4 : 0;
   size_t dyn = stack_bytes > sizeof(PathState) ? stack_bytes : sizeof(PathState);  // shared by both tenants
   PathtraceArgs b = a;
   b.multi_off = static_cast<uint32_t>(dyn / 4);
@@ -960,7 +981,7 @@ void launch_selftest_trace(const SceneView& scene, const float* rays, size_t n, 
   if (!n) return;
   dim3 grid((n + kThreads - 1) / kThreads), block(kThreads);
   if (scene.use_bvh)
-    hipLaunchKernelGGL(k_selftest_trace<true>, grid, block, scene.stack_depth * kThreads * 4, s, scene, rays, n, tmax, out_id, out_t);
+    hipLaunchKernelGGL(k_selftest_trace<true>, grid, block, scene.stack_lds * kThreads * 4, s, scene, rays, n, tmax, out_id, out_t);
   else
     hipLaunchKernelGGL(k_selftest_trace<false>, grid, block, 0, s, scene, rays, n, tmax, out_id, out_t);
 }

@@ -22,6 +22,12 @@ struct SceneView {
   uint32_t n_tris;
   uint32_t use_bvh;  // 0: brute force over isect_id, 1: BVH traversal
   uint32_t stack_depth;  // BVH traversal stack entries per lane (tree depth + 2)
+  // The first stack_lds entries of a lane's stack live in LDS (what sets the workgroups per CU: the 1.15M-triangle
+  // tree is 28 deep, 30 KB per workgroup = 5 per CU, and its trace is that sensitive to occupancy: 2 / 3 / 4 / 5
+  // workgroups per CU 5.75 / 4.74 / 4.07 / 3.62 ms); deeper entries, which few rays ever reach, go to stack_spill in
+  // global memory: [entry - stack_lds][workgroup of the launch][thread]
+  uint32_t stack_lds;
+  uint32_t* stack_spill;
   // optional per-triangle materials of the BASE mesh (.mtl Kd / Ke; instance i, triangle t reads record t):
   //   m0 = (Kd.rgb, 0)  m1 = (Ke.rgb, 1 if emissive else 0).  NULL: the reference's normal-keyed colours
   const float4* materials;
