@@ -1519,6 +1519,7 @@ int rtpt_selftest_trace(rtpt_ctx* c, const float* rays, size_t n, uint32_t* out_
   if (!c->n_tris) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");
   if (n == 0) return RTPT_OK;
   HIP_TRY(hipSetDevice(c->device));
+  FLUSH_FILTER(c);  // a recorded G-buffer call holds the scene view, and with it the stack's spill area, which may move below
   float *drays = nullptr, *dt = nullptr;
   uint32_t* did = nullptr;
   hipError_t e = hipMalloc(&drays, n * 24);
