@@ -96,7 +96,11 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
         ctx.timing_enable(timing_period if collect_kernels else 0)
         t_wake = time.perf_counter()
         n_wake = 0
-        while time.perf_counter() - t_wake < args.prewarm_seconds or (n_wake < steps and time.perf_counter() - t_wake < 3.0):
+        # with several ranks the number of wake-up frames is fixed, not timed: ranks that exchange rows every frame
+        # (a moving camera, --halo exchange) must all draw the same frames
+        fixed = None if dist is None else max(steps, 16 * int(args.prewarm_seconds * 1e3 / (16 * 0.2)))
+        while (n_wake < fixed) if fixed is not None else (
+                time.perf_counter() - t_wake < args.prewarm_seconds or (n_wake < steps and time.perf_counter() - t_wake < 3.0)):
             for _ in range(16):
                 draw()
             n_wake += 16
