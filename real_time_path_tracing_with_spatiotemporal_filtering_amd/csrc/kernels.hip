@@ -27,6 +27,9 @@ struct HitRec {
 // division deferred until a candidate passes the inside tests:
 //   det = -d.n,  tt = (o-v0).n,  c = (o-v0) x d,  u = e2.c,  v = -e1.c        (21 flops instead of 27)
 // record: r0 = (v0.xyz, e1.x)  r1 = (e1.yz, e2.xy)  r2 = (e2.z, n.xyz)
+#ifndef RTPT_TRI_DET_CHECK
+#define RTPT_TRI_DET_CHECK 0
+#endif
 template <bool TIE_BREAK>
 __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float4 r2, uint32_t id1, HitRec& h) {
   f3 v0{r0.x, r0.y, r0.z}, e1{r0.w, r1.x, r1.y}, e2{r1.z, r1.w, r2.x}, n{r2.y, r2.z, r2.w};
@@ -42,7 +45,12 @@ __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float
     v = -v;
     tt = -tt;
   }
+#if RTPT_TRI_DET_CHECK
   bool ok = (ad > 0.0f) && (u >= 0.0f) && (v >= 0.0f) && (u + v <= ad) && (tt > 0.0f);
+#else
+  // no "ad > 0" term: with ad == 0 only u == v == 0 passes, th is then +inf (tt > 0), and +inf never beats h.t
+  bool ok = (u >= 0.0f) && (v >= 0.0f) && (u + v <= ad) && (tt > 0.0f);
+#endif
   if (ok) {
     float th = tt / ad;
     bool better = th < h.t;
