@@ -995,6 +995,7 @@ int rtpt_temporal_gradient(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t 
   a.worldpos = static_cast<const float4*>(c->worldpos.ptr);
   a.lut = static_cast<const float4*>(c->lut[c->lut_cur].ptr);
   a.lut_prev = static_cast<const float4*>(c->lut[c->lut_cur ^ 1].ptr);
+  a.normal_tab = static_cast<const float4*>(c->normal_tab.ptr);
   a.grad = static_cast<float4*>(c->gradient.ptr);
   {
     Timer tm(c, RTPT_K_GRADIENT);

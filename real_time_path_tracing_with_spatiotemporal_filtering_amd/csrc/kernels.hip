@@ -372,11 +372,13 @@ __device__ __forceinline__ f3 phong(f3 p, f3 n, f3 cam, f3 lpos, f3 lcol) {
 
 // temporalGradient.comp.glsl:128-167 for one pixel: relative change of the Phong shade of the visible surface point between
 // the previous and the current light (and pose)
-__device__ __forceinline__ float gradient_lambda(uint32_t id, f3 wp, const float4* lut, const float4* lut_prev, f3 cam, f3 light,
-                                                 f3 light_prev, f3 color, f3 color_prev) {
+__device__ __forceinline__ float gradient_lambda(uint32_t id, f3 wp, const float4* lut, const float4* lut_prev, const float4* normal_tab,
+                                                 f3 cam, f3 light, f3 light_prev, f3 color, f3 color_prev) {
   if (id == 0) return 0.0f;  // :128-131
   f3 va = xyz(lut[3 * id]), vb = xyz(lut[3 * id + 1]), vc = xyz(lut[3 * id + 2]);
-  f3 nrm = exact::normalize(exact::cross(vb - va, vc - va));  // :142
+  // :142 normalize(cross(vb - va, vc - va)) — k_lut computed exactly that from exactly these vertices, once per triangle
+  // (normal_tab[id]); per pixel it is 36 VALU of a VALU-bound kernel
+  f3 nrm = xyz(normal_tab[id]);
   f3 bc = bary_coords(wp, va, vb, vc);                        // :143
   f3 pa = xyz(lut_prev[3 * id]), pb = xyz(lut_prev[3 * id + 1]), pc = xyz(lut_prev[3 * id + 2]);
   f3 wpp = bary_mix(bc, pa, pb, pc);                          // :153
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
       const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
       wp = bary_point(xyz(s[0]), xyz(s[1]), xyz(s[2]), b0, b1, b2);
     }
-    store_gradient(a.grad, i, gradient_lambda(h.id1, wp, a.lut, a.lut_prev, ld3(a.g_cam), ld3(a.g_light), ld3(a.g_light_prev),
+    store_gradient(a.grad, i, gradient_lambda(h.id1, wp, a.lut, a.lut_prev, a.normal_tab, ld3(a.g_cam), ld3(a.g_light), ld3(a.g_light_prev),
                                               ld3(a.g_color), ld3(a.g_color_prev)));
   }
 }
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(kThreads) void k_gradient(GradientArgs a) {
   const size_t i = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
   const uint32_t id = a.vis[i];
   const f3 wp = id ? xyz(a.worldpos[i]) : f3{0.f, 0.f, 0.f};
-  store_gradient(a.grad, i, gradient_lambda(id, wp, a.lut, a.lut_prev, ld3(a.cam), ld3(a.light), ld3(a.light_prev), ld3(a.color),
+  store_gradient(a.grad, i, gradient_lambda(id, wp, a.lut, a.lut_prev, a.normal_tab, ld3(a.cam), ld3(a.light), ld3(a.light_prev), ld3(a.color),
                                             ld3(a.color_prev)));
 }
 

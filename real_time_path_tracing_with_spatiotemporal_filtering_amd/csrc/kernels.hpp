@@ -91,6 +91,7 @@ struct GradientArgs {
   const float4* worldpos;
   const float4* lut;
   const float4* lut_prev;
+  const float4* normal_tab;  // per-id normals of the current LUT (k_lut)
   float4* grad;
 };
 
