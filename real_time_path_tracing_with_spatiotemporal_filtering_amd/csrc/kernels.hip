@@ -20,20 +20,38 @@ namespace {
 struct HitRec {
   float t;       // best t so far (initialised to tmax)
   uint32_t id1;  // primitive id + 1, 0 = none
-  float u, v, ad;  // scaled barycentrics of the best hit: b1 = u/ad, b2 = v/ad
+  float u, v, ad;  // scaled barycentrics of the best hit, u NEGATED: b1 = -u/ad, b2 = v/ad (tri_test)
 };
 
 // Scalar-triple-product form of Moller-Trumbore, plane normal n = e1 x e2 precomputed per triangle,
 // division deferred until a candidate passes the inside tests:
 //   det = -d.n,  tt = (o-v0).n,  c = (o-v0) x d,  u = e2.c,  v = -e1.c        (21 flops instead of 27)
 // record: r0 = (v0.xyz, e1.x)  r1 = (e1.yz, e2.xy)  r2 = (e2.z, n.xyz)
-#ifndef RTPT_TRI_DET_CHECK
-#define RTPT_TRI_DET_CHECK 0
+#ifndef RTPT_TRI_XOR_SIGN
+#define RTPT_TRI_XOR_SIGN 1
 #endif
 template <bool TIE_BREAK>
 __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float4 r2, uint32_t id1, HitRec& h) {
   f3 v0{r0.x, r0.y, r0.z}, e1{r0.w, r1.x, r1.y}, e2{r1.z, r1.w, r2.x}, n{r2.y, r2.z, r2.w};
   f3 tv = o - v0;
+#if RTPT_TRI_XOR_SIGN
+  // The signs of u, v, tt follow the sign of det = -d.n.  Instead of comparing det with 0 and selecting three negations
+  // (a v_cmp whose result three VOP3 selects must wait two cycles for), the sign bit of d.n is XORed into e2.c, e1.c and
+  // tt: that yields -u, +v and -tt of the oriented triangle (v = -e1.c takes the other sign), so two of the tests read
+  // the other way round and HitRec keeps -u (HitRec::u: negated).  Same decisions bit for bit: x <= 0 iff -x >= 0,
+  // x < 0 iff -x > 0, v - (-u) is u + v.
+  const float dn = exact::dot(d, n);
+  const uint32_t sm = f2u(dn) & 0x80000000u;
+  const float tt = u2f(f2u(exact::dot(tv, n)) ^ sm);
+  const f3 c = exact::cross(tv, d);
+  const float u = u2f(f2u(exact::dot(e2, c)) ^ sm);
+  const float v = u2f(f2u(exact::dot(e1, c)) ^ sm);
+  const float ad = __builtin_fabsf(dn);
+  // no "ad > 0" term: with ad == 0 only u == v == 0 passes, th is then +inf (tt > 0), and +inf never beats h.t
+  const bool ok = (u <= 0.0f) && (v >= 0.0f) && (v - u <= ad) && (tt < 0.0f);
+  if (ok) {
+    const float th = (-tt) / ad;
+#else
   float det = -exact::dot(d, n);
   float tt = exact::dot(tv, n);
   f3 c = exact::cross(tv, d);
@@ -45,14 +63,12 @@ __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float
     v = -v;
     tt = -tt;
   }
-#if RTPT_TRI_DET_CHECK
-  bool ok = (ad > 0.0f) && (u >= 0.0f) && (v >= 0.0f) && (u + v <= ad) && (tt > 0.0f);
-#else
   // no "ad > 0" term: with ad == 0 only u == v == 0 passes, th is then +inf (tt > 0), and +inf never beats h.t
   bool ok = (u >= 0.0f) && (v >= 0.0f) && (u + v <= ad) && (tt > 0.0f);
-#endif
   if (ok) {
     float th = tt / ad;
+    u = -u;  // HitRec keeps -u
+#endif
     bool better = th < h.t;
     if (TIE_BREAK) better = better || (th == h.t && h.id1 != 0 && id1 < h.id1);
     if (better) {
@@ -430,7 +446,7 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
   a.vis[i] = h.id1;  // visibility.frag.glsl:23
   if (a.normals) a.normals[i] = a.normal_tab[h.id1];
   if (h.id1) {
-    float b1 = h.u / h.ad, b2 = h.v / h.ad;
+    float b1 = -h.u / h.ad, b2 = h.v / h.ad;
     float b0 = 1.0f - b1 - b2;
     const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
     f3 wp = bary_point(xyz(s[0]), xyz(s[1]), xyz(s[2]), b0, b1, b2);
@@ -445,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
     // K1 (temporalGradient.comp.glsl:104-172) on the values K0 just stored — the same bits it would load back
     f3 wp{0.f, 0.f, 0.f};
     if (h.id1) {
-      float b1 = h.u / h.ad, b2 = h.v / h.ad;
+      float b1 = -h.u / h.ad, b2 = h.v / h.ad;
       float b0 = 1.0f - b1 - b2;
       const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
       wp = bary_point(xyz(s[0]), xyz(s[1]), xyz(s[2]), b0, b1, b2);
@@ -515,7 +531,7 @@ __device__ __forceinline__ bool shade_segment(const PathtraceArgs& a, const HitR
   }
   const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
   float4 s0 = s[0], s1 = s[1], s2 = s[2];
-  float b1 = h.u / h.ad, b2 = h.v / h.ad;
+  float b1 = -h.u / h.ad, b2 = h.v / h.ad;
   float b0 = 1.0f - b1 - b2;                                       // :134
   f3 pos = bary_point(xyz(s0), xyz(s1), xyz(s2), b0, b1, b2);      // :137
   f3 n{s0.w, s1.w, s2.w};                                          // :150 (precomputed per triangle)
