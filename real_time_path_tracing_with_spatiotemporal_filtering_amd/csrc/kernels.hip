@@ -495,9 +495,12 @@ __device__ __forceinline__ bool ray_hits_light(f3 o, f3 d, f3 c, float r2) {
   float disc = fmaf_(b, b, -((4.0f * a) * cc));
   if (disc < 0.0f) return false;
   float sq = exact::sqrt_(disc);
-  float t1 = (-b - sq) / (2.0f * a);
+  // :190-197 "t1 > 0 || t2 > 0" with t1 = (-b - sq) / 2a, t2 = (-b + sq) / 2a.  sq >= 0 and 2a >= 0, and both the
+  // addition and the correctly-rounded division are monotonic, so t1 <= t2 whenever neither is NaN: t1 > 0 implies
+  // t2 > 0, and the disjunction IS "t2 > 0" (NaN operands make both comparisons false either way; 2a == 0 gives +-inf /
+  // NaN with the same signs).  One division less per path segment.
   float t2 = (-b + sq) / (2.0f * a);
-  return (t1 > 0.0f) || (t2 > 0.0f);
+  return t2 > 0.0f;
 }
 
 __device__ __forceinline__ f3 sky_color(f3 d) {  // raytrace.comp.glsl:95-107
