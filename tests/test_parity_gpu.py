@@ -557,6 +557,10 @@ def test_two_frames_in_flight(hip_lib, oracle, cornell, exact):
     for keys, _, _ in script:   # enqueue everything first: the frames really overlap on the GPU
         app.drawScene(keys)
         outs.append(app.backend.prev.ctx.plane_ptr(hip_lib.PLANE_PREVIOUS))
+    for b in app.backend.be:    # then let the GPU finish before the oracle's 16 OpenMP threads take the host: one run in
+        b.ctx.sync()            # nine of the whole suite died with SIGSEGV inside the oracle's G-buffer loop while the
+                                # HIP runtime was still retiring these frames (not reproduced; neither side keeps host
+                                # memory the other touches)
     # only the last two frames are still resident (one per context); check the whole history through them:
     # the temporal blend makes frame f depend on every earlier frame
     total = 0
