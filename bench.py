@@ -175,7 +175,16 @@ def kernel_report(kern, wl, plan, steps):
     return out
 
 
-def cpu_baseline(wl, budget_s=12.0):
+def cpu_baseline(workload: str, budget_s=12.0):
+    """the CPU oracle in a CHILD process (a fresh interpreter: no torch, no HIP runtime, none of their threads): the
+    checker's worker threads never share a process with the GPU legs that ran before it"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", workload, str(budget_s)],
+                         stdout=subprocess.PIPE, stderr=sys.stderr, timeout=600, check=True)
+    return json.loads(out.stdout.decode().strip().splitlines()[-1])
+
+
+def _cpu_baseline_child(wl, budget_s=12.0):
     """the CPU oracle (oracle/rtpt_oracle.c, "port") on a bounded row band of the same workload"""
     from oracle import oracle as O
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE
@@ -237,7 +246,7 @@ def cpu_baseline(wl, budget_s=12.0):
         "value": round(rays / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
         "one_thread": {"value": round(r1 / d1 / 1e6, 3), "unit": "Mray/s", "sample": f"{rows1} centre rows, {d1:.1f} s"},
         "sample": f"{reps} x {rows} centre rows of the {W}x{H} frame (+{N * (N + 1) // 2} halo rows per side when banded), "
-                  f"all passes, {dt:.1f} s of oracle/rtpt_oracle.c with {cores} OpenMP threads",
+                  f"all passes, {dt:.1f} s of oracle/rtpt_oracle.c with {cores} threads",
         "ms_per_frame_extrapolated": round(dt / reps / rows * H * 1e3, 1),
     }
 
@@ -400,7 +409,7 @@ def main():
         result["also"]["cornell-1080p-1spp-4seg-5atrous"]["two_frames_in_flight"] = {
             "value": round(r4 / e4 / 1e6, 2), "ms_per_step": round(e4 / args.steps * 1e3, 4)}
     if world == 1 and rank == 0 and not args.no_cpu_baseline and not wl.get("instanced"):
-        result["cpu_baseline"] = cpu_baseline(wl)
+        result["cpu_baseline"] = cpu_baseline(args.workload)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -427,4 +436,7 @@ def _main_with_clean_stdout():
 _RESULT_LINE = []
 
 if __name__ == "__main__":
-    _main_with_clean_stdout()
+    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-baseline-child":
+        print(json.dumps(_cpu_baseline_child(WORKLOADS[sys.argv[2]], float(sys.argv[3]) if len(sys.argv) > 3 else 12.0)))
+    else:
+        _main_with_clean_stdout()

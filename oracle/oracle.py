@@ -17,7 +17,8 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# RTPT_ORACLE_LIB: a sanitizer build of the same source (oracle/Makefile targets asan / tsan), CPU only
+_LIB_PATH = os.environ.get("RTPT_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 
 
 class OracleConfig(C.Structure):
@@ -61,6 +62,8 @@ _lib = None
 
 def build(force: bool = False) -> str:
     """compile liboracle.so with gcc (building the checker is not using it)."""
+    if os.environ.get("RTPT_ORACLE_LIB"):
+        return _LIB_PATH
     srcs = [os.path.join(_HERE, f) for f in ("rtpt_oracle.c", "rtpt_oracle.h", "det_math.h", "Makefile")]
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):

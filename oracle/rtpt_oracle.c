@@ -3,6 +3,7 @@
  * Plain C scalar restatement of the reference's compute chain; citations are file:line
  * relative to the reference tree (shaders/ prefix omitted for *.glsl).
  */
+#define _GNU_SOURCE /* gettid, backtrace */
 #include "rtpt_oracle.h"
 
 #include <math.h>
@@ -12,13 +13,96 @@
 
 #include "det_math.h"
 
-#ifdef _OPENMP
-#include <omp.h>
-#endif
+#include <execinfo.h>
+#include <pthread.h>
+#include <signal.h>
+#include <sys/prctl.h>
+#include <unistd.h>
 
+/* Row-parallel driver.  Plain pthreads, created and joined inside every call: no OpenMP runtime, no pool that outlives
+ * a call or is resized between calls, nothing shared with the process the checker is loaded into (pytest/bench.py
+ * processes also hold torch's own libgomp image and the HIP runtime's threads; DESIGN.md 2, "The round-2 abort").
+ * Work is handed out in chunks from one atomic counter; every chunk runs the SAME serial row function the one-thread
+ * path runs, so the thread count cannot change a result. */
 static int g_threads = 1;
-void oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+void oracle_set_threads(int n) { g_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
 int oracle_get_threads(void) { return g_threads; }
+
+/* Crash attribution for the test processes (tests/conftest.py installs it for -m gpu runs): Python's faulthandler
+ * prints Python frames only, and round 2's abort was in a thread that had none.  On SIGSEGV / SIGBUS /
+ * SIGABRT this prints the faulting thread's name, the faulting address and its NATIVE frames (module + offset) to
+ * stderr, then hands the signal to whatever handler was installed before (faulthandler's). */
+static struct sigaction g_prev_sa[3];
+static const int g_crash_sigs[3] = {SIGSEGV, SIGBUS, SIGABRT};
+
+static void crash_trace_handler(int sig, siginfo_t* si, void* uc) {
+  char name[32] = "?";
+  prctl(PR_GET_NAME, name, 0, 0, 0);
+  char msg[160];
+  int n = snprintf(msg, sizeof msg, "\n[oracle crash trace] signal %d at address %p in native thread '%s' (tid %ld):\n", sig,
+                   si ? si->si_addr : NULL, name, (long)gettid());
+  if (n > 0) (void)!write(2, msg, (size_t)n);
+  void* frames[64];
+  int nf = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, nf, 2);
+  for (int i = 0; i < 3; i++)
+    if (g_crash_sigs[i] == sig) {
+      sigaction(sig, &g_prev_sa[i], NULL); /* restore and re-deliver to the previous handler */
+      raise(sig);
+      return;
+    }
+}
+
+void oracle_install_crash_trace(void) {
+  void* warm[4];
+  (void)backtrace(warm, 4); /* loads libgcc's unwinder now, not inside the handler */
+  struct sigaction sa;
+  memset(&sa, 0, sizeof sa);
+  sa.sa_sigaction = crash_trace_handler;
+  sa.sa_flags = SA_SIGINFO | SA_ONSTACK | SA_NODEFER;
+  sigemptyset(&sa.sa_mask);
+  for (int i = 0; i < 3; i++) sigaction(g_crash_sigs[i], &sa, &g_prev_sa[i]);
+}
+
+typedef void (*range_fn)(void* ctx, int64_t a, int64_t b);
+typedef struct {
+  range_fn fn;
+  void* ctx;
+  int64_t end, chunk;
+  int64_t next; /* atomic */
+} range_job;
+
+static void* range_worker(void* p) {
+  range_job* j = (range_job*)p;
+  for (;;) {
+    int64_t a = __atomic_fetch_add(&j->next, j->chunk, __ATOMIC_RELAXED);
+    if (a >= j->end) break;
+    int64_t b = a + j->chunk < j->end ? a + j->chunk : j->end;
+    j->fn(j->ctx, a, b);
+  }
+  return NULL;
+}
+
+static void run_ranges(int64_t begin, int64_t end, int64_t chunk, range_fn fn, void* ctx) {
+  if (end <= begin) return;
+  int64_t n_chunks = (end - begin + chunk - 1) / chunk;
+  int nt = g_threads < n_chunks ? g_threads : (int)n_chunks;
+  if (nt <= 1) {
+    fn(ctx, begin, end);
+    return;
+  }
+  range_job job = {fn, ctx, end, chunk, begin};
+  pthread_t th[256];
+  pthread_attr_t at;
+  pthread_attr_init(&at);
+  pthread_attr_setstacksize(&at, 1 << 20); /* the row functions keep a few hundred bytes of locals */
+  int started = 0;
+  for (int i = 0; i < nt - 1; i++)
+    if (pthread_create(&th[started], &at, range_worker, &job) == 0) started++; /* a failed create only lowers the width */
+  pthread_attr_destroy(&at);
+  range_worker(&job); /* the calling thread works too */
+  for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+}
 
 void oracle_config_default(oracle_config* c, uint32_t w, uint32_t h) {
   memset(c, 0, sizeof(*c));
@@ -238,14 +322,33 @@ uint32_t oracle_closest_hit(const float* tris, uint32_t n, const float o_[3], co
   return best;
 }
 
-void oracle_trace_rays(const float* tris, uint32_t n, const float* rays, uint64_t n_rays, float tmax,
-                       uint32_t* out_id, float* out_t) {
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 64)
-  for (int64_t i = 0; i < (int64_t)n_rays; i++) {
+typedef struct {
+  const float* tris;
+  uint32_t n;
+  const float* rays;
+  float tmax;
+  uint32_t* out_id;
+  float* out_t;
+} trace_rays_args;
+
+static void trace_rays_range(void* ctx, int64_t i0, int64_t i1) {
+  const trace_rays_args* A = (const trace_rays_args*)ctx;
+  const float *tris = A->tris, *rays = A->rays;
+  const uint32_t n = A->n;
+  const float tmax = A->tmax;
+  uint32_t* out_id = A->out_id;
+  float* out_t = A->out_t;
+  for (int64_t i = i0; i < i1; i++) {
     float t = 0.f;
     out_id[i] = oracle_closest_hit(tris, n, rays + 6 * i, rays + 6 * i + 3, tmax, &t, NULL, NULL);
     if (out_t) out_t[i] = out_id[i] ? t : 0.0f;
   }
+}
+
+void oracle_trace_rays(const float* tris, uint32_t n, const float* rays, uint64_t n_rays, float tmax,
+                       uint32_t* out_id, float* out_t) {
+  trace_rays_args A = {tris, n, rays, tmax, out_id, out_t};
+  run_ranges(0, (int64_t)n_rays, 64, trace_rays_range, &A);
 }
 
 /* v0*b.x + v1*b.y + v2*b.z (raytrace.comp.glsl:137) := fma(v2,b2, fma(v1,b1, v0*b0)) */
@@ -270,7 +373,7 @@ void oracle_lut(const float* tris, uint32_t n, const float model[16], float* lut
     }
 }
 
-void oracle_gbuffer(const oracle_config* cfg, const float* tris, uint32_t n, const oracle_ubo* ubo,
+static void gbuffer_rows(const oracle_config* cfg, const float* tris, uint32_t n, const oracle_ubo* ubo,
                     uint32_t y0, uint32_t y1, uint32_t* vis, float* worldpos, float* depth) {
   const int W = (int)cfg->width, H = (int)cfg->height;
   const float* V = ubo->view;
@@ -282,7 +385,6 @@ void oracle_gbuffer(const oracle_config* cfg, const float* tris, uint32_t n, con
   mat4_mul(ubo->proj, ubo->view, PV); /* visibility.vert.glsl:22 proj * view (* model = I) */
   const float p00 = ubo->proj[0], p11 = ubo->proj[5];
   const float fw = (float)W, fh = (float)H;
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
   for (int y = (int)y0; y < (int)y1; y++)
     for (int x = 0; x < W; x++) {
       /* pixel-centre sample: ndc = (2(x+.5) - W)/W ; view-space direction (ndc.x/P00, ndc.y/P11, -1) */
@@ -306,6 +408,26 @@ void oracle_gbuffer(const oracle_config* cfg, const float* tris, uint32_t n, con
         depth[i] = 1.0f; /* main.cpp:1421 */
       }
     }
+}
+
+typedef struct {
+  const oracle_config* cfg;
+  const float* tris;
+  uint32_t n;
+  const oracle_ubo* ubo;
+  uint32_t* vis;
+  float* worldpos;
+  float* depth;
+} gbuffer_args;
+
+static void gbuffer_range(void* ctx, int64_t a, int64_t b) {
+  const gbuffer_args* A = (const gbuffer_args*)ctx;
+  gbuffer_rows(A->cfg, A->tris, A->n, A->ubo, (uint32_t)a, (uint32_t)b, A->vis, A->worldpos, A->depth);
+}
+
+void oracle_gbuffer(const oracle_config* cfg, const float* tris, uint32_t n, const oracle_ubo* ubo, uint32_t y0, uint32_t y1, uint32_t* vis, float* worldpos, float* depth) {
+  gbuffer_args A = {cfg, tris, n, ubo, vis, worldpos, depth};
+  run_ranges((int64_t)y0, (int64_t)y1, 4, gbuffer_range, &A);
 }
 
 /* ---------------------------------------------------------------- K1 */
@@ -346,7 +468,7 @@ static vec3 phong(vec3 p, vec3 n, vec3 cam, vec3 lpos, vec3 lcol, int shininess)
   return v3_scale(sum, 0.7f); /* attenuation 1.0 (exact), objectColor 0.7 */
 }
 
-void oracle_temporal_gradient(const oracle_config* cfg, const oracle_push_constants* pc,
+static void temporal_gradient_rows(const oracle_config* cfg, const oracle_push_constants* pc,
                               const uint32_t* vis, const float* worldpos, const float* lut,
                               const float* lut_prev, uint32_t y0, uint32_t y1, float* grad) {
   const int W = (int)cfg->width;
@@ -355,7 +477,6 @@ void oracle_temporal_gradient(const oracle_config* cfg, const oracle_push_consta
   vec3 lpp = v3(pc->lightPosPrev[0], pc->lightPosPrev[1], pc->lightPosPrev[2]);
   vec3 lc = v3(pc->currentCameraColor[0], pc->currentCameraColor[1], pc->currentCameraColor[2]);
   vec3 lcp = v3(pc->previousCameraColor[0], pc->previousCameraColor[1], pc->previousCameraColor[2]);
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
   for (int y = (int)y0; y < (int)y1; y++)
     for (int x = 0; x < W; x++) {
       uint64_t i = (uint64_t)y * W + x;
@@ -377,6 +498,26 @@ void oracle_temporal_gradient(const oracle_config* cfg, const oracle_push_consta
       g[0] = g[1] = g[2] = lam;
       g[3] = 0.0f; /* :170 */
     }
+}
+
+typedef struct {
+  const oracle_config* cfg;
+  const oracle_push_constants* pc;
+  const uint32_t* vis;
+  const float* worldpos;
+  const float* lut;
+  const float* lut_prev;
+  float* grad;
+} temporal_gradient_args;
+
+static void temporal_gradient_range(void* ctx, int64_t a, int64_t b) {
+  const temporal_gradient_args* A = (const temporal_gradient_args*)ctx;
+  temporal_gradient_rows(A->cfg, A->pc, A->vis, A->worldpos, A->lut, A->lut_prev, (uint32_t)a, (uint32_t)b, A->grad);
+}
+
+void oracle_temporal_gradient(const oracle_config* cfg, const oracle_push_constants* pc, const uint32_t* vis, const float* worldpos, const float* lut, const float* lut_prev, uint32_t y0, uint32_t y1, float* grad) {
+  temporal_gradient_args A = {cfg, pc, vis, worldpos, lut, lut_prev, grad};
+  run_ranges((int64_t)y0, (int64_t)y1, 4, temporal_gradient_range, &A);
 }
 
 /* ---------------------------------------------------------------- K2 */
@@ -425,7 +566,7 @@ void oracle_raytrace(const oracle_config* cfg, const oracle_push_constants* pc, 
 /* materials (not reference behaviour): tri_mat = n_base x 8 floats (Kd.rgb, 0, Ke.rgb, emissive
  * flag), triangle id reads record id % n_base (instances share the base mesh's materials); NULL = the reference's
  * normal-keyed colours (raytrace.comp.glsl:155-163) */
-void oracle_raytrace_mat(const oracle_config* cfg, const oracle_push_constants* pc, const float* tris,
+static void raytrace_mat_rows(const oracle_config* cfg, const oracle_push_constants* pc, const float* tris,
                          uint32_t n, const float* tri_mat, uint32_t n_base, uint32_t y0, uint32_t y1, float* image,
                          uint64_t* raycount, uint32_t* hit_id) {
   const int W = (int)cfg->width, H = (int)cfg->height;
@@ -436,7 +577,6 @@ void oracle_raytrace_mat(const oracle_config* cfg, const oracle_push_constants* 
   const float slope = cfg->fov_slope;
   const float fw = (float)W, fh = (float)H;
   uint64_t rays_total = 0;
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4) reduction(+ : rays_total)
   for (int y = (int)y0; y < (int)y1; y++)
     for (int x = 0; x < W; x++) {
       uint32_t rng = oracle_rng_seed((uint32_t)x, (uint32_t)y, pc->frameNumber, pc->sample_batch); /* :297 */
@@ -508,7 +648,29 @@ void oracle_raytrace_mat(const oracle_config* cfg, const oracle_push_constants* 
       image[4 * i + 3] = 0.0f; /* :343 */
       if (hit_id) hit_id[i] = first_id;
     }
-  if (raycount) *raycount += rays_total;
+  if (raycount) __atomic_fetch_add(raycount, rays_total, __ATOMIC_RELAXED); /* chunks of one call share it */
+}
+
+typedef struct {
+  const oracle_config* cfg;
+  const oracle_push_constants* pc;
+  const float* tris;
+  uint32_t n;
+  const float* tri_mat;
+  uint32_t n_base;
+  float* image;
+  uint64_t* raycount;
+  uint32_t* hit_id;
+} raytrace_mat_args;
+
+static void raytrace_mat_range(void* ctx, int64_t a, int64_t b) {
+  const raytrace_mat_args* A = (const raytrace_mat_args*)ctx;
+  raytrace_mat_rows(A->cfg, A->pc, A->tris, A->n, A->tri_mat, A->n_base, (uint32_t)a, (uint32_t)b, A->image, A->raycount, A->hit_id);
+}
+
+void oracle_raytrace_mat(const oracle_config* cfg, const oracle_push_constants* pc, const float* tris, uint32_t n, const float* tri_mat, uint32_t n_base, uint32_t y0, uint32_t y1, float* image, uint64_t* raycount, uint32_t* hit_id) {
+  raytrace_mat_args A = {cfg, pc, tris, n, tri_mat, n_base, image, raycount, hit_id};
+  run_ranges((int64_t)y0, (int64_t)y1, 4, raytrace_mat_range, &A);
 }
 
 /* ---------------------------------------------------------------- K3 */
@@ -539,14 +701,13 @@ static void reproject(int W, int H, const float* PVp, uint32_t id, const float* 
 
 static inline float luminance(vec3 c) { return dm_fma(0.0722f, c.z, dm_fma(0.7152f, c.y, 0.2126f * c.x)); }
 
-void oracle_moments(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
+static void moments_rows(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
                     const float* traced, const uint32_t* vis, const float* worldpos, const float* lut_prev,
                     const uint32_t* prev_vis, const float* moments_prev, uint32_t y0, uint32_t y1,
                     float* moments_out, float* var_out) {
   const int W = (int)cfg->width, H = (int)cfg->height;
   float PVp[16];
   mat4_mul(ubo->projPrev, ubo->viewPrev, PVp);
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
   for (int y = (int)y0; y < (int)y1; y++)
     for (int x = 0; x < W; x++) {
       uint64_t ip = (uint64_t)y * W + x;
@@ -573,6 +734,30 @@ void oracle_moments(const oracle_config* cfg, const oracle_push_constants* pc, c
     }
 }
 
+typedef struct {
+  const oracle_config* cfg;
+  const oracle_push_constants* pc;
+  const oracle_ubo* ubo;
+  const float* traced;
+  const uint32_t* vis;
+  const float* worldpos;
+  const float* lut_prev;
+  const uint32_t* prev_vis;
+  const float* moments_prev;
+  float* moments_out;
+  float* var_out;
+} moments_args;
+
+static void moments_range(void* ctx, int64_t a, int64_t b) {
+  const moments_args* A = (const moments_args*)ctx;
+  moments_rows(A->cfg, A->pc, A->ubo, A->traced, A->vis, A->worldpos, A->lut_prev, A->prev_vis, A->moments_prev, (uint32_t)a, (uint32_t)b, A->moments_out, A->var_out);
+}
+
+void oracle_moments(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo, const float* traced, const uint32_t* vis, const float* worldpos, const float* lut_prev, const uint32_t* prev_vis, const float* moments_prev, uint32_t y0, uint32_t y1, float* moments_out, float* var_out) {
+  moments_args A = {cfg, pc, ubo, traced, vis, worldpos, lut_prev, prev_vis, moments_prev, moments_out, var_out};
+  run_ranges((int64_t)y0, (int64_t)y1, 4, moments_range, &A);
+}
+
 /* gaussianKernel2D, temporalFiltering.comp.glsl:93-99 (sum 273) */
 static const float k_gauss5[5][5] = {{1, 4, 7, 4, 1}, {4, 16, 26, 16, 4}, {7, 26, 41, 26, 7}, {4, 16, 26, 16, 4}, {1, 4, 7, 4, 1}};
 
@@ -592,7 +777,7 @@ void oracle_atrous_ext(const oracle_config* cfg, const oracle_push_constants* pc
                     prev_pixel, NULL);
 }
 
-void oracle_atrous_var(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
+static void atrous_var_rows(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
                        const float* in, const float* depth, const uint32_t* vis, const float* lut,
                        const float* lut_prev, const float* worldpos, const float* history,
                        const float* gradient, const uint32_t* prev_vis, const float* var_in,
@@ -611,7 +796,6 @@ void oracle_atrous_var(const oracle_config* cfg, const oracle_push_constants* pc
   if (final_pass) mat4_mul(ubo->projPrev, ubo->viewPrev, PVp); /* :180 projMatrix * viewMatrix */
   const float h = 1.0f / 9.0f;                    /* :145 */
   const float one_minus_alpha = 1.0f - cfg->alpha; /* :254 */
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
   for (int y = (int)y0; y < (int)y1; y++)
     for (int x = 0; x < W; x++) {
       uint64_t ip = (uint64_t)y * W + x;
@@ -677,4 +861,33 @@ void oracle_atrous_var(const oracle_config* cfg, const oracle_push_constants* pc
       }
       o[0] = blend.x; o[1] = blend.y; o[2] = blend.z; o[3] = 0.0f; /* :263 */
     }
+}
+
+typedef struct {
+  const oracle_config* cfg;
+  const oracle_push_constants* pc;
+  const oracle_ubo* ubo;
+  const float* in;
+  const float* depth;
+  const uint32_t* vis;
+  const float* lut;
+  const float* lut_prev;
+  const float* worldpos;
+  const float* history;
+  const float* gradient;
+  const uint32_t* prev_vis;
+  const float* var_in;
+  float* out;
+  int32_t* prev_pixel;
+  float* var_out;
+} atrous_var_args;
+
+static void atrous_var_range(void* ctx, int64_t a, int64_t b) {
+  const atrous_var_args* A = (const atrous_var_args*)ctx;
+  atrous_var_rows(A->cfg, A->pc, A->ubo, A->in, A->depth, A->vis, A->lut, A->lut_prev, A->worldpos, A->history, A->gradient, A->prev_vis, A->var_in, (uint32_t)a, (uint32_t)b, A->out, A->prev_pixel, A->var_out);
+}
+
+void oracle_atrous_var(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo, const float* in, const float* depth, const uint32_t* vis, const float* lut, const float* lut_prev, const float* worldpos, const float* history, const float* gradient, const uint32_t* prev_vis, const float* var_in, uint32_t y0, uint32_t y1, float* out, int32_t* prev_pixel, float* var_out) {
+  atrous_var_args A = {cfg, pc, ubo, in, depth, vis, lut, lut_prev, worldpos, history, gradient, prev_vis, var_in, out, prev_pixel, var_out};
+  run_ranges((int64_t)y0, (int64_t)y1, 4, atrous_var_range, &A);
 }

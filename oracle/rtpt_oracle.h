@@ -62,9 +62,11 @@ typedef struct oracle_ubo {
 } oracle_ubo;
 
 void oracle_config_default(oracle_config* cfg, uint32_t width, uint32_t height);
-/* number of worker threads for the row loops (OpenMP); 1 = scalar */
+/* number of worker threads for the row loops (plain pthreads, created and joined per call); 1 = scalar */
 void oracle_set_threads(int n);
 int oracle_get_threads(void);
+/* test processes only: print the faulting NATIVE thread's frames on SIGSEGV/SIGBUS/SIGABRT, then chain */
+void oracle_install_crash_trace(void);
 
 /* --- numerics contract, exported for bit-exact comparison with the device ---------------- */
 float oracle_log(float x);

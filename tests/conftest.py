@@ -22,6 +22,10 @@ def oracle():
     from oracle import oracle as O
     O.build()
     O.set_threads(min(8, os.cpu_count() or 1))
+    # native frames of the faulting thread on SIGSEGV/SIGBUS/SIGABRT, then pytest's faulthandler (installed at
+    # configure time, i.e. before this fixture) gets the signal: a crash in a thread without Python frames — an
+    # oracle worker, a HIP runtime thread — is attributable from the log ("The round-2 abort")
+    O.lib().oracle_install_crash_trace()
     return O
 
 

@@ -557,10 +557,11 @@ def test_two_frames_in_flight(hip_lib, oracle, cornell, exact):
     for keys, _, _ in script:   # enqueue everything first: the frames really overlap on the GPU
         app.drawScene(keys)
         outs.append(app.backend.prev.ctx.plane_ptr(hip_lib.PLANE_PREVIOUS))
-    for b in app.backend.be:    # then let the GPU finish before the oracle's 16 OpenMP threads take the host: one run in
-        b.ctx.sync()            # nine of the whole suite died with SIGSEGV inside the oracle's G-buffer loop while the
-                                # HIP runtime was still retiring these frames (not reproduced; neither side keeps host
-                                # memory the other touches)
+    # No sync here: the oracle's frames below run on the host while the GPU retires the seven frames queued above.
+    # Round 2 saw one abort at this point (SIGSEGV in a native thread without Python frames while the main thread was
+    # inside oracle_gbuffer); the oracle then ran its rows on a libgomp pool that was resized 8 <-> 16 between tests
+    # beside torch's own libgomp image.  It now runs them on plain pthreads created and joined per call, is clean under
+    # ASan/UBSan/TSan on this script, and conftest's crash tracer prints the native frames of any faulting thread.
     # only the last two frames are still resident (one per context); check the whole history through them:
     # the temporal blend makes frame f depend on every earlier frame
     total = 0
