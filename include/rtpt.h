@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RTPT_ABI_VERSION 2
+#define RTPT_ABI_VERSION 3
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define RTPT_OK 0
@@ -294,6 +294,14 @@ int rtpt_temporal_filter(rtpt_ctx* ctx, const rtpt_push_constants* pc, const rtp
  * done by rotating plane roles (no copy kernels). */
 int rtpt_end_frame(rtpt_ctx* ctx);
 
+/* the swapchain blit of copyImageToSwapChainsCurrentImage (main.cpp:1338-1361: `image`, RGBA32F, blitted to the acquired
+ * swapchain image, VK_FORMAT_B8G8R8A8_UNORM): frame rows [y0,y1) of the finished frame (call after rtpt_end_frame, or
+ * after the last rtpt_temporal_filter) are converted — clamp to [0,1], x*255 + 0.5 truncated, NaN -> 0; bytes B,G,R,A in
+ * memory — and written to `dst_device`, a device buffer whose first byte is pixel (0, y0): 4*W bytes per row.  The
+ * buffer is the caller's "swapchain image"; with several ranks each rank converts its own rows and the presenting rank
+ * gathers them (4 B/px on the wire instead of 16).  Runs on the context's stream. */
+int rtpt_present(rtpt_ctx* ctx, void* dst_device, uint32_t y0, uint32_t y1);
+
 /* ---- synchronisation / data movement ---------------------------------------------------- */
 int rtpt_sync(rtpt_ctx* ctx);
 /* blocking copy of a whole plane (stored rows) to host memory */
@@ -326,7 +334,8 @@ typedef enum rtpt_kernel_id {
   RTPT_K_ATROUS_CHAIN = 6,       /* several consecutive iterations k < N in one launch (intermediates in LDS) */
   RTPT_K_ATROUS_CHAIN_FINAL = 7, /* ... ending in the final pass */
   RTPT_K_GBUFFER_GRADIENT = 8,   /* K0 and K1 in one launch (rtpt_temporal_gradient right behind rtpt_gbuffer) */
-  RTPT_K_COUNT = 9
+  RTPT_K_PRESENT = 9,            /* rtpt_present: RGBA32F -> B8G8R8A8_UNORM */
+  RTPT_K_COUNT = 10
 } rtpt_kernel_id;
 int rtpt_timing_enable(rtpt_ctx* ctx, int enable);
 int rtpt_timing_collect(rtpt_ctx* ctx, double ms_sum[RTPT_K_COUNT], uint32_t launches[RTPT_K_COUNT]);

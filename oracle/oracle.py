@@ -403,3 +403,14 @@ class OracleApp:
         self.prev_vis = vis  # main.cpp:1367
         self.frame += 1
         return FrameOut(vis, wp, depth, grad, traced, hid, cur, pp, rays, lut_)
+
+
+def present_bgra8(image: np.ndarray) -> np.ndarray:
+    """main.cpp:1338-1361: the blit RGBA32F `image` -> B8G8R8A8_UNORM swapchain image, as the build defines the
+    conversion (include/rtpt.h rtpt_present): clamp to [0,1], x*255 + 0.5 (binary32 multiply, then add) truncated,
+    NaN -> 0.  Returns [H, W, 4] uint8 in memory order B,G,R,A."""
+    c = np.asarray(image, np.float32)
+    c = np.where(np.isnan(c), np.float32(0), c)
+    c = np.minimum(np.maximum(c, np.float32(0)), np.float32(1))
+    q = (c * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    return np.ascontiguousarray(q[..., [2, 1, 0, 3]])

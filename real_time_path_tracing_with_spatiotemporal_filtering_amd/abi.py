@@ -33,9 +33,9 @@ DEBUG_HIT_ID, DEBUG_PREV_PIXEL = 0x1, 0x2
  PLANE_VARIANCE, PLANE_MOMENTS_PREV) = range(16)
 # rtpt_kernel_id
 (K_GBUFFER, K_LUT, K_GRADIENT, K_PATHTRACE, K_ATROUS, K_ATROUS_FINAL, K_ATROUS_CHAIN, K_ATROUS_CHAIN_FINAL,
- K_GBUFFER_GRADIENT, K_COUNT) = range(10)
+ K_GBUFFER_GRADIENT, K_PRESENT, K_COUNT) = range(11)
 KERNEL_NAMES = ["k_gbuffer", "k_lut", "k_gradient", "k_pathtrace", "k_atrous", "k_atrous_final", "k_atrous_chain",
-                "k_atrous_chain_final", "k_gbuffer_gradient"]
+                "k_atrous_chain_final", "k_gbuffer_gradient", "k_present"]
 
 
 class RtptLibraryMissing(RuntimeError):
@@ -95,6 +95,7 @@ SYMBOLS = [
     "rtpt_reset_counters", "rtpt_set_count_rows", "rtpt_enable_debug", "rtpt_timing_enable", "rtpt_timing_collect", "rtpt_kernel_name",
     "rtpt_selftest_math", "rtpt_selftest_trace", "rtpt_util_look_at", "rtpt_util_perspective", "rtpt_util_load_obj", "rtpt_util_bvh_check",
     "rtpt_scene_set_materials", "rtpt_util_load_obj_materials", "rtpt_util_bvh_refit_check", "rtpt_set_external_guides",
+    "rtpt_present",
 ]
 
 _lib = None
@@ -133,6 +134,7 @@ def load() -> C.CDLL:
         "rtpt_raytrace": [vp, C.POINTER(PushConstants), u32, u32],
         "rtpt_temporal_filter": [vp, C.POINTER(PushConstants), C.POINTER(Ubo), u32, u32],
         "rtpt_end_frame": [vp],
+        "rtpt_present": [vp, vp, u32, u32],
         "rtpt_sync": [vp],
         "rtpt_readback": [vp, C.c_int, vp, sz],
         "rtpt_set_plane": [vp, C.c_int, vp, sz],
@@ -332,6 +334,10 @@ class Context:
 
     def end_frame(self):
         _check(self._lib.rtpt_end_frame(self._h))
+
+    def present(self, dst_device_ptr: int, y0=0, y1=0):
+        """main.cpp:1338-1361: rows [y0,y1) of the finished frame -> B8G8R8A8_UNORM at the device address"""
+        _check(self._lib.rtpt_present(self._h, C.c_void_p(dst_device_ptr), y0, y1))
 
     def sync(self):
         _check(self._lib.rtpt_sync(self._h))

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 from . import abi
-from .strips import StripPlan, exchange_halo, exchange_history, reprojection_rows
+from .strips import StripPlan, exchange_halo, exchange_history, gather_frame, reprojection_rows
 
 FOV = 0.20                 # common.h:16
 SPEED = np.float32(0.1)    # main.cpp:68
@@ -154,6 +154,21 @@ class HipBackend:
         base = self.ctx.cfg.row_begin
         return self.ctx.readback(plane)[y0 - base:y1 - base]
 
+    # presenting the frame (main.cpp:1338-1361) ---------------------------------------------------
+    on_device = True
+
+    def alloc(self, shape, dtype):
+        import torch
+        return torch.zeros(shape, dtype=getattr(torch, dtype), device=torch.device("cuda", torch.cuda.current_device()))
+
+    def present_rows(self, image8, y0: int, y1: int):
+        """rtpt_present: rows [y0,y1) of the finished frame -> rows [y0,y1) of the [H, W, 4] uint8 swapchain image"""
+        self.ctx.present(image8.data_ptr() + y0 * self.width * 4, y0, y1)
+
+    def final_rows(self, y0: int, y1: int):
+        """torch view of rows of the finished frame (after end_frame: the PREVIOUS plane)"""
+        return self.color_rows(abi.PLANE_PREVIOUS, y0, y1)
+
     # two frames in flight (PipelinedBackend) ------------------------------------------------
     def wait_for(self, other: "HipBackend"):
         self.ctx.stream_wait(other.ctx)
@@ -263,6 +278,21 @@ class PipelinedBackend:
         """rows of the last finished frame"""
         return self.prev.readback_rows(abi.PLANE_PREVIOUS, y0, y1)
 
+    # presenting: called after end_frame, i.e. the finished frame lives in `prev`; no stream-to-stream wait — the
+    # caller is still on the finished frame's stream (drawScene's scope)
+    @property
+    def on_device(self):
+        return getattr(self.be[0], "on_device", False)
+
+    def alloc(self, shape, dtype):
+        return self.be[0].alloc(shape, dtype)
+
+    def present_rows(self, image8, y0, y1):
+        self.prev.present_rows(image8, y0, y1)
+
+    def final_rows(self, y0, y1):
+        return self.prev.final_rows(y0, y1)
+
     def raycount(self):
         return sum(b.ctx.raycount() for b in self.be)
 
@@ -276,8 +306,18 @@ class PathTracingApplication:
 
     def __init__(self, backend, width=1000, height=800, maxWaveletIteration=9, plan: StripPlan | None = None,
                  cameraOrigin=(-0.001, 1.0, 6.0), lightPos=(1.0, 1.0, -0.4), lightColor=(0.5, 0.5, 0.5),
-                 group=None, z_near=0.1, z_far=10.0):
+                 group=None, z_near=0.1, z_far=10.0, present=None, present_root=0):
         self.backend = backend
+        # present: None — the finished frame stays where the final pass left it (strips stay on their ranks);
+        # "rgba8" — every frame is converted to the swapchain format (rtpt_present, B8G8R8A8_UNORM) and, with several
+        # ranks, gathered on rank `present_root`; "f32" — the float strips are gathered as they are (main.cpp:1338-1361)
+        if present not in (None, "rgba8", "f32"):
+            raise ValueError("present must be None, 'rgba8' or 'f32'")
+        self.present, self.present_root = present, present_root
+        self._present_images = None
+        self._present_stream = None
+        self._present_done = {}
+        self.present_bytes_sent = 0
         self.render_width, self.render_height = width, height          # main.cpp:52-53
         self.maxWaveletIteration = maxWaveletIteration                 # main.cpp:55
         self.plan = plan or StripPlan(height, 1, 0, maxWaveletIteration)
@@ -418,8 +458,73 @@ class PathTracingApplication:
             self.backend.temporal_filter(pc, self.ubo, *self.plan.filter_rows(k))
 
     def copyImageToSwapChainsCurrentImage(self):
-        """main.cpp:1308-1406 minus the swapchain: the history hand-over (:1364-1372)."""
+        """main.cpp:1308-1406: the history hand-over (:1364-1372) and, when `present` is set, the blit to the
+        swapchain image (:1338-1361) — with several ranks: assembled on the presenting rank."""
         self.backend.end_frame()
+        if self.present:
+            self._present()
+
+    def presented_image(self, frame: int | None = None):
+        """the swapchain image ("rgba8": [H, W, 4] uint8, bytes B,G,R,A; "f32": [H, W, 4] float) holding frame
+        `frame` (default: the last one drawn) — complete on the presenting rank once its stream has been synchronised"""
+        f = self.frameCount - 1 if frame is None else frame
+        return self._present_images[f & 1]
+
+    def present_sync(self):
+        """host-blocks until every posted gather has landed"""
+        for ev in self._present_done.values():
+            ev.synchronize()
+
+    def _acquire(self, idx: int):
+        """vkAcquireNextImageKHR (main.cpp:1310-1316): image idx may be written again once the gather that read it —
+        two frames ago — is done.  The same wait protects the float strip a 'f32' gather is still sending: its buffer
+        becomes IMAGE again, and is overwritten by the trace, two frames after it was finished."""
+        ev = self._present_done.pop(idx, None)
+        if ev is not None:
+            import torch
+            torch.cuda.current_stream().wait_event(ev)
+
+    def _present(self):
+        be, plan = self.backend, self.plan
+        o0, o1 = plan.own
+        f = self.frameCount            # drawScene increments after this call
+        idx = f & 1
+        H, W = plan.height, self.render_width
+        rgba8 = self.present == "rgba8"
+        if self._present_images is None:
+            if rgba8:
+                self._present_images = [be.alloc((H, W, 4), "uint8") for _ in range(2)]
+            elif plan.world > 1 and plan.rank == self.present_root:
+                self._present_images = [be.alloc((H, W, 4), "float32") for _ in range(2)]
+            else:
+                self._present_images = [None, None]
+        img = self._present_images[idx]
+        if rgba8:
+            be.present_rows(img, o0, o1)
+            mine = img[o0:o1]
+        else:
+            mine = be.final_rows(o0, o1) if plan.world > 1 else None
+            if img is not None:
+                img[o0:o1].copy_(mine)
+        self.present_bytes_sent = 0
+        if plan.world == 1:
+            return
+        if getattr(be, "on_device", False):
+            # the gather runs on its own stream behind the frame's kernels, so the next frame's passes do not wait for
+            # the wire; _acquire() closes the loop two frames later
+            import torch
+            main = torch.cuda.current_stream()
+            if self._present_stream is None:
+                self._present_stream = torch.cuda.Stream()
+            ps = self._present_stream
+            ps.wait_stream(main)
+            with torch.cuda.stream(ps):
+                self.present_bytes_sent = gather_frame(plan, mine, img, self.present_root, self.group)
+                ev = torch.cuda.Event()
+                ev.record(ps)
+            self._present_done[idx] = ev
+        else:
+            self.present_bytes_sent = gather_frame(plan, mine, img, self.present_root, self.group)
 
     def _camera_static(self):
         u = self.ubo
@@ -472,6 +577,8 @@ class PathTracingApplication:
         """main.cpp:1090-1113."""
         scope = getattr(self.backend, "stream_scope", None)
         with (scope() if scope else _null_scope()):
+            if self.present and self._present_done:
+                self._acquire(self.frameCount & 1)
             self.updateScene(keys)
             self.drawVisbilityBuffer()
             self.computeTemporalGradient()

@@ -1364,6 +1364,29 @@ int rtpt_end_frame(rtpt_ctx* c) {
   return RTPT_OK;
 }
 
+// main.cpp:1338-1361: the blit of `image` to the swapchain image
+int rtpt_present(rtpt_ctx* c, void* dst_device, uint32_t y0, uint32_t y1) {
+  if (!c || !dst_device) return fail(RTPT_E_INVALID, "NULL argument");
+  if (reinterpret_cast<uintptr_t>(dst_device) & 3u) return fail(RTPT_E_INVALID, "swapchain image must be 4-byte aligned");
+  FLUSH_FILTER(c);
+  int rc = check_rows(c, y0, y1);
+  if (rc) return rc;
+  // the finished frame: IMAGE until rtpt_end_frame, PREVIOUS after it (the reference blits before it copies, the pixels
+  // are the same); only rows the last final pass wrote hold it
+  Buf* b = plane_buf(c, c->image_alias ? RTPT_PLANE_PREVIOUS : RTPT_PLANE_IMAGE);
+  if (!b || !b->ptr) return fail(RTPT_E_INVALID, "no image plane");
+  const int f0 = c->image_alias ? c->hist_y0 : c->final_y0, f1 = c->image_alias ? c->hist_y1 : c->final_y1;
+  if (static_cast<int>(y0) < f0 || static_cast<int>(y1) > f1)
+    return fail(RTPT_E_INVALID, "rtpt_present: rows [" + std::to_string(y0) + "," + std::to_string(y1) + ") outside the rows of the finished frame [" +
+                                    std::to_string(f0) + "," + std::to_string(f1) + ")");
+  HIP_TRY(hipSetDevice(c->device));
+  {
+    Timer tm(c, RTPT_K_PRESENT);
+    rt::launch_present(geom(c, y0, y1), static_cast<const float4*>(b->ptr), static_cast<uint32_t*>(dst_device), c->stream);
+  }
+  return launch_check("present");
+}
+
 // ------------------------------------------------------------------------------------------ sync / copies
 int rtpt_sync(rtpt_ctx* c) {
   if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
@@ -1487,6 +1510,7 @@ const char* rtpt_kernel_name(rtpt_kernel_id k) {
     case RTPT_K_ATROUS_CHAIN: return "k_atrous_chain";
     case RTPT_K_ATROUS_CHAIN_FINAL: return "k_atrous_chain_final";
     case RTPT_K_GBUFFER_GRADIENT: return "k_gbuffer_gradient";
+    case RTPT_K_PRESENT: return "k_present";
     default: return "?";
   }
 }

@@ -673,7 +673,27 @@ __global__ __launch_bounds__(kThreads) void k_stamp_depth(FrameGeom g, float4* c
   reinterpret_cast<float*>(color + i)[3] = depth[i];
 }
 
+// main.cpp:1338-1361 vkCmdBlitImage image (RGBA32F) -> swapchain image (B8G8R8A8_UNORM): the float -> UNORM
+// conversion clamps to [0,1] and quantises; defined here as trunc(x*255 + 0.5) with separate multiply and add (the
+// file is compiled -ffp-contract=off), NaN -> 0 (max(NaN, 0) = 0), which is what output.to_unorm8 / the oracle compute.
+__device__ __forceinline__ uint32_t unorm8(float x) {
+  const float c = fminf(fmaxf(x, 0.0f), 1.0f);
+  return static_cast<uint32_t>(c * 255.0f + 0.5f);
+}
+__global__ __launch_bounds__(kThreads) void k_present(FrameGeom g, const float4* __restrict__ image, uint32_t* __restrict__ dst) {
+  const int x = blockIdx.x * kBlockX + threadIdx.x;
+  const int y = g.y0 + blockIdx.y * kBlockY + threadIdx.y;
+  if (x >= g.W || y >= g.y1) return;
+  const float4 c = image[static_cast<size_t>(y - g.row_base) * g.W + x];
+  dst[static_cast<size_t>(y - g.y0) * g.W + x] = unorm8(c.z) | (unorm8(c.y) << 8) | (unorm8(c.x) << 16) | (unorm8(c.w) << 24);
+}
+
 }  // namespace
+
+void launch_present(const FrameGeom& g, const float4* image, uint32_t* dst, hipStream_t s) {
+  if (g.y1 <= g.y0) return;
+  hipLaunchKernelGGL(k_present, grid_for(g), dim3(kBlockX, kBlockY), 0, s, g, image, dst);
+}
 
 void launch_moments(const MomentsArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;

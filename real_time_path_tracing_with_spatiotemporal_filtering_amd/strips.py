@@ -251,3 +251,29 @@ def exchange_history(plan: StripPlan, needs, prev_rows_view, full, group=None) -
             recvs.append((full[y0:y1], peer))
     _post(sends, recvs, group)
     return sent
+
+
+# ------------------------------------------------------------------------------------------
+# presenting the frame: the strips meet on one rank
+# ------------------------------------------------------------------------------------------
+def gather_frame(plan: StripPlan, mine, full, root: int = 0, group=None) -> int:
+    """The reference presents every frame (main.cpp:1338-1361: `image` blitted to the swapchain image); with the frame
+    sharded by rows, the presenting rank `root` first has to hold all of it.  `mine` views the rows this rank owns of
+    the finished frame ([rows, W, C]: the float image, or its swapchain-format conversion, rtpt_present), `full` is the
+    [H, W, C] image on the root.  Strips may differ by a row, so this is a group of point-to-point messages rather than
+    a gather collective: the root posts its R-1 receives together (RCCL then drives every xGMI link into the root at
+    once: 7 x 16.6 MB at 4K f32, a quarter of that in swapchain format), every other rank posts one send.  Enqueued on
+    the current stream.  Returns the bytes this rank sent."""
+    if plan.world == 1:
+        return 0
+    o0, o1 = plan.own
+    if plan.rank == root:
+        recvs = []
+        for r in range(plan.world):
+            if r != root:
+                a, b = StripPlan.bounds(plan.height, plan.world, r)
+                recvs.append((full[a:b], r))
+        _post([], recvs, group)
+        return 0
+    _post([(mine, root)], [], group)
+    return mine.numel() * mine.element_size()
