@@ -40,19 +40,31 @@ WORKLOADS = {
 PREWARM_SECONDS = 0.3
 HOST_SECONDS = [0.0]
 HIST_BYTES = [0]
+PRESENT_BYTES = [0]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# ALGORITHMIC bytes per pixel per launch (SURVEY.md 8d / BASELINE.md 3): one a-trous iteration k < N = 16+4+4 read +
-# 16 write = 40, the final one 72.  k_atrous_chain runs CHAIN_LEVELS iterations in one launch, so its algorithmic bytes
-# are CHAIN_LEVELS x 40 — the work 8(d) prices — although the intermediate image never reaches HBM.
+# ALGORITHMIC bytes per pixel per launch: what the operator a launch computes must read and write in
+# the survey's formats (colour 16, depth 4, id 4).  One a-trous iteration k < N: 16+4+4 read + 16 write = 40; the final
+# one 72.  k_atrous_chain computes CHAIN_LEVELS iterations in one launch: as an operator it still reads the input image
+# + guides once and writes one image, so its algorithmic bytes are 40 B/px as well — the intermediate image is not part
+# of the fused operator's interface (round 2 priced the chain at CHAIN_LEVELS x 40, "the passes it replaces", which is a
+# speed-up figure, not a roofline fraction: it is kept as `replaced_pass_bytes` / `frac_vs_separate_passes_at_peak`).
 CHAIN_LEVELS = 2
-BYTES_PER_PX = {"k_atrous": 40, "k_atrous_final": 72, "k_atrous_chain": 40 * CHAIN_LEVELS, "k_gradient": 36, "k_gbuffer": 24,
-                "k_gbuffer_gradient": 24 + 36, "k_pathtrace": 16}
+BYTES_PER_PX = {"k_atrous": 40, "k_atrous_final": 72, "k_atrous_chain": 40, "k_gradient": 36, "k_gbuffer": 24,
+                "k_gbuffer_gradient": 24 + 36, "k_pathtrace": 16, "k_present": 16 + 4}
 # bytes the kernel as built MUST move per pixel (rgbd cells: depth rides in alpha, so 16 + 4 read and 16 written; the
-# chain reads its input once and writes its last level once; the per-pixel-normal variant of large scenes stages 16 more)
+# chain reads its input once and writes its last level once).  Scenes without an id-pair table (> 63 triangles) run the
+# per-pixel-normal variant, which stages a 16-byte (normal, self weight) cell instead of the 4-byte id (+12 B/px; its
+# final pass still reads the id for the reprojection: +16).
 REQUIRED_PER_PX = {"k_atrous": 36, "k_atrous_final": 68, "k_atrous_chain": 36}
+REQUIRED_PER_PX_NRM = {"k_atrous": 48, "k_atrous_final": 84, "k_atrous_chain": 48}
 
 
-def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=True, in_flight=1):
+def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=True, in_flight=1, halo=None, present="default",
+            camera_keys=None):
+    """one measured run; halo / present / camera_keys override the command line (the `also` legs of a multi-rank run)"""
+    halo = halo or args.halo
+    present = args.present if present == "default" else present
+    camera_keys = args.camera_keys if camera_keys is None else camera_keys
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE, make_app
     extra = {}
     if wl.get("instanced"):
@@ -62,9 +74,10 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
         extra = dict(mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar,
                      lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
     app = make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"],
-                   rank=rank, world=world, mode=args.halo, flags=args.flags,
-                   torch_planes=(dist is not None), frames_in_flight=in_flight, **extra)
-    keys_of = (lambda f: (args.camera_keys[f % len(args.camera_keys)],)) if args.camera_keys else (lambda f: ())
+                   rank=rank, world=world, mode=halo, flags=args.flags,
+                   torch_planes=(dist is not None), frames_in_flight=in_flight, present=present, **extra)
+    keys_of = (lambda f: (camera_keys[f % len(camera_keys)],)) if camera_keys else (lambda f: ())
+    present_bytes = [0]
     frame_no = [0]
     hist_bytes = [0]
 
@@ -72,6 +85,7 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
         app.drawScene(keys_of(frame_no[0]))
         frame_no[0] += 1
         hist_bytes[0] += getattr(app, "history_bytes_sent", 0)
+        present_bytes[0] += getattr(app, "present_bytes_sent", 0)
     ctxs = [b.ctx for b in app.backend.be] if in_flight == 2 else [app.backend.ctx]
     ctx = ctxs[0]
     collect_kernels = collect_kernels and in_flight == 1  # overlapping frames stretch every kernel's duration
@@ -79,6 +93,7 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
     def fence():
         for c in ctxs:
             c.sync()
+        app.present_sync()   # gathers posted on the present stream
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -111,7 +126,7 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
     for _ in range(warmup):
         draw()
     fence()
-    hist_bytes[0] = 0
+    hist_bytes[0] = present_bytes[0] = 0
     for c in ctxs:
         c.reset_counters()
     # per-kernel HIP events on the launch stream, sampled: bracketing every launch costs ~6 % of the frame
@@ -121,6 +136,7 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
     for _ in range(steps):
         draw()
     HIST_BYTES[0] = hist_bytes[0]
+    PRESENT_BYTES[0] = present_bytes[0]
     HOST_SECONDS[0] = time.perf_counter() - t0  # time the host needed to submit the K steps (diagnostic)
     fence()
     elapsed = time.perf_counter() - t0
@@ -147,7 +163,7 @@ def kernel_report(kern, wl, plan, steps):
     rows = {
         "k_gbuffer": plan.gbuffer_rows(), "k_gbuffer_gradient": plan.gbuffer_rows(), "k_gradient": plan.gradient_rows(),
         "k_pathtrace": plan.raytrace_rows(),
-        "k_atrous_final": plan.filter_rows(wl["iterations"]),
+        "k_atrous_final": plan.filter_rows(wl["iterations"]), "k_present": plan.own,
     }
     out = {}
     for name, (ms, n) in kern.items():
@@ -169,8 +185,11 @@ def kernel_report(kern, wl, plan, steps):
         if px and name in BYTES_PER_PX:
             e["algorithmic_bytes"] = int(BYTES_PER_PX[name] * px)
             e["algorithmic_GBps"] = round(BYTES_PER_PX[name] * px / (avg_us * 1e-6) / 1e9, 1)
-        if px and name in REQUIRED_PER_PX:
-            e["required_bytes"] = int(REQUIRED_PER_PX[name] * px)
+        req = REQUIRED_PER_PX_NRM if wl.get("instanced") else REQUIRED_PER_PX
+        if px and name in req:
+            e["required_bytes"] = int(req[name] * px)
+        if px and name == "k_atrous_chain":
+            e["replaced_pass_bytes"] = int(40 * CHAIN_LEVELS * px)
         out[name] = e
     return out
 
@@ -281,12 +300,18 @@ def main():
                     help="keys held on successive frames, cycled (e.g. EQ: the camera moves up and down 0.1 per frame, "
                          "main.cpp:1119-1168), so that every frame reprojects and, on strips, exchanges history bands; "
                          "default: camera at rest, like every BASELINE config")
+    ap.add_argument("--present", choices=["auto", "none", "rgba8", "f32"], default="auto",
+                    help="the swapchain blit of main.cpp:1338-1361 inside every step: rgba8 = rtpt_present (B8G8R8A8_UNORM) "
+                         "and, with several ranks, the converted strips gathered on rank 0; f32 = the float strips gathered "
+                         "as they are; none = the frame stays where the final pass left it.  auto: none on one GPU (the "
+                         "frame is already whole), rgba8 on several (a frame that is never assembled cannot be presented)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    args.present = {"auto": "rgba8" if max(world, args.gpus) > 1 else None, "none": None}.get(args.present, args.present)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if args.gpus > 1:
@@ -359,14 +384,17 @@ def main():
                        "width": wl["width"], "height": wl["height"], "max_segments": wl["max_segments"],
                        "atrous_iterations": wl["iterations"], "triangles": 1152000 if wl.get("instanced") else 32,
                        "parallelism": f"row-strips x{world}" + (f" ({args.halo} halo)" if world > 1 else ""),
+                       "present": (args.present or "none") + (" gathered on rank 0" if world > 1 and args.present else ""),
                        "frames_in_flight": args.frames_in_flight},
             "rays_per_frame": round(rays / args.steps, 1),
             "history_exchange_bytes_per_frame_rank0": round(HIST_BYTES[0] / args.steps, 1),
-            # achieved / frac follow the contract: ALGORITHMIC bytes per launch / measured launch time.  For the
-            # chained kernel that is the bytes of the iterations it REPLACES, so frac says how much faster than "those
-            # passes at HBM peak" it runs and can exceed what a kernel moving them could reach; frac_required prices
-            # the bytes this kernel itself must move, frac_traffic the fabric bytes the PMC counters saw (per launch,
-            # profiles/traffic.json: a committed measurement of the commit named in traffic_source, not of this run).
+            "present_gather_bytes_per_frame_rank0": round(PRESENT_BYTES[0] / args.steps, 1),
+            # achieved / frac: ALGORITHMIC bytes of the operator one launch computes / the launch time measured
+            # with HIP events on the launch stream.  frac_required prices the bytes this kernel as built must move (rgbd
+            # cells), frac_traffic the fabric bytes the PMC counters saw (per launch, profiles/traffic.json: a committed
+            # measurement of the commit named in traffic_source, not of this run).  For the chained kernel
+            # frac_vs_separate_passes_at_peak is the old "bytes of the passes it replaces" figure: a speed-up, not a
+            # roofline fraction.
             "roofline": {"kernel": rk + (f" ({CHAIN_LEVELS} a-trous iterations k < N per launch, intermediates in LDS)"
                                         if rk == "k_atrous_chain" else " (one a-trous iteration, k < N)"),
                          "bound": "hbm",
@@ -379,7 +407,9 @@ def main():
                          "traffic": traffic,
                          "frac_traffic": round(traffic / (at["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                          if traffic and at.get("avg_us") else None,
-                         "traffic_source": traffic_source},
+                         "traffic_source": traffic_source,
+                         "frac_vs_separate_passes_at_peak": round(at["replaced_pass_bytes"] / (at["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                         if at.get("replaced_pass_bytes") and at.get("avg_us") else None},
             "kernels": kr,
         }
         pt = kr.get("k_pathtrace")
@@ -395,6 +425,36 @@ def main():
             result.setdefault("also", {})["two_frames_in_flight"] = {
                 "value": round(r3 / e3 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e3 / args.steps * 1e3, 4),
                 "fps": round(args.steps / e3, 1)}
+    if world > 1 and not args.no_secondary:
+        # the legs a scaling run must see (every rank takes part): the frame left distributed, the float gather, the RCCL
+        # halo exchange (k rows per neighbour per iteration instead of redundant rows), and a camera that moves every
+        # frame (history bands travel between strips).  Same steps/warm-up, throughput only.
+        legs = [("without_output_gather", dict(present=None)),
+                ("with_f32_gather", dict(present="f32")),
+                ("halo_exchange" if args.halo != "exchange" else "halo_redundant",
+                 dict(halo="exchange" if args.halo != "exchange" else "redundant")),
+                ("moving_camera", dict(camera_keys=args.camera_keys or "EQ"))]
+        from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripPlan
+        for name, kw in legs:
+            try:   # every rank checks EVERY rank's plan, so a leg is skipped by all of them or by none
+                for r in range(world):
+                    for k in range(1, wl["iterations"] + 1):
+                        StripPlan(wl["height"], world, r, wl["iterations"], kw.get("halo", args.halo), args.flags & 0x1F0).exchange_rows(k)
+            except ValueError as ex:   # strips shorter than the exchange halo
+                if rank == 0:
+                    result.setdefault("also", {})[name] = {"skipped": str(ex)}
+                continue
+            e5, r5, _, _, _ = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist, collect_kernels=False, **kw)
+            if rank == 0:
+                result.setdefault("also", {})[name] = {
+                    "value": round(r5 / e5 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e5 / args.steps * 1e3, 4),
+                    "history_exchange_bytes_per_frame_rank0": round(HIST_BYTES[0] / args.steps, 1),
+                    "present_gather_bytes_per_frame_rank0": round(PRESENT_BYTES[0] / args.steps, 1)}
+    if world == 1 and rank == 0 and not args.no_secondary and args.present is None:
+        e6, r6, k6, p6, tf6 = run_gpu(wl, args, 0, 1, args.steps, args.warmup, torch, None, present="rgba8")
+        result.setdefault("also", {})["with_present_rgba8"] = {
+            "value": round(r6 / e6 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e6 / args.steps * 1e3, 4),
+            "k_present_us": kernel_report(k6, wl, p6, tf6).get("k_present", {}).get("avg_us")}
     if world == 1 and rank == 0 and not args.no_secondary and args.workload == "4k":
         e2, r2, k2, p2, tf2 = run_gpu(WORKLOADS["1080p"], args, 0, 1, args.steps, args.warmup, torch, None)
         kr2 = kernel_report(k2, WORKLOADS["1080p"], p2, tf2)

@@ -527,8 +527,18 @@ class PathTracingApplication:
             self.present_bytes_sent = gather_frame(plan, mine, img, self.present_root, self.group)
 
     def _camera_static(self):
+        """every pixel reprojects onto itself: view, proj AND model unchanged since the previous frame (an animated
+        model matrix moves pixels across strips exactly like a camera move does)"""
         u = self.ubo
-        return list(u.view) == list(u.viewPrev) and list(u.proj) == list(u.projPrev)
+        return (list(u.view) == list(u.viewPrev) and list(u.proj) == list(u.projPrev)
+                and list(u.model) == list(u.modelPrev))
+
+    def _world_bounds(self):
+        """sceneBounds (of the uploaded, un-posed mesh) under the current model matrix: the box of its 8 posed corners"""
+        lo, hi = self.sceneBounds
+        m = np.asarray(self.ubo.model[:], np.float64).reshape(4, 4).T
+        c = np.array([[x, y, z, 1.0] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])]) @ m.T
+        return c[:, :3].min(0), c[:, :3].max(0)
 
     def _prepare_history(self):
         """With several ranks the final pass may fetch history at a reprojected pixel of another strip
@@ -543,7 +553,8 @@ class PathTracingApplication:
             self.history_bytes_sent = 0
             return
         H, R = self.plan.height, self.plan.world
-        needs = [reprojection_rows(self.ubo, self.render_width, H, StripPlan.bounds(H, R, r), self.sceneBounds, self.z_near)
+        bounds = self._world_bounds()
+        needs = [reprojection_rows(self.ubo, self.render_width, H, StripPlan.bounds(H, R, r), bounds, self.z_near)
                  for r in range(R)]
         full = be.history_full()
         self.history_bytes_sent = exchange_history(self.plan, needs, lambda a, b: be.color_rows(abi.PLANE_PREVIOUS, a, b),
@@ -564,7 +575,8 @@ class PathTracingApplication:
         from .strips import exchange_history
         H, R = self.plan.height, self.plan.world
         plans = [StripPlan(H, R, r, self.plan.iterations, self.plan.mode, self.plan.ext_flags) for r in range(R)]
-        needs = [reprojection_rows(self.ubo, self.render_width, H, p.stored, self.sceneBounds, self.z_near) for p in plans]
+        bounds = self._world_bounds()
+        needs = [reprojection_rows(self.ubo, self.render_width, H, p.stored, bounds, self.z_near) for p in plans]
         ids, mom = be.guides_full()
         variance = bool(self.plan.ext_flags & abi.FLAG_EXT_VARIANCE)
         sent = exchange_history(self.plan, needs, lambda a, b: be.guide_rows(abi.PLANE_PREV_VIS_ID, a, b), ids, self.group)

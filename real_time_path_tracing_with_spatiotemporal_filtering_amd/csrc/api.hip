@@ -634,7 +634,9 @@ int rtpt_stream_wait(rtpt_ctx* c, rtpt_ctx* other) {
   if (!c || !other) return fail(RTPT_E_INVALID, "NULL argument");
   // "everything submitted to `other` so far" includes its recorded iterations; this context's own recorded iterations
   // do not depend on `other` and go out ahead of the wait.  Neither call looks at a plane, so both may run chained.
-  int rcw = filter_flush(other, true);
+  int rcw = gbuffer_flush(other);
+  if (rcw == RTPT_OK) rcw = gbuffer_flush(c);
+  if (rcw == RTPT_OK) rcw = filter_flush(other, true);
   if (rcw == RTPT_OK) rcw = filter_flush(c, true);
   if (rcw) return rcw;
   if (c == other || c->stream == other->stream) return RTPT_OK;  // one stream is already in order
@@ -696,7 +698,7 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
           o[2] = v[2];
         }
       }
-  rt::Bvh& bvh = c->bvh_host;
+  rt::Bvh bvh;  // built aside: a failed upload leaves the context's scene (and the topology a later refit uses) untouched
   rt::build_bvh(tris.data(), total, bvh);
   if (bvh.max_depth >= rt::kBvhMaxDepth) return fail(RTPT_E_INVALID, "BVH deeper than the traversal stack");
   if (bvh.leaf_order.size() != total) return fail(RTPT_E_INVALID, "internal: BVH lost triangles");
@@ -739,6 +741,7 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   else
     c->host_tris.clear();
   c->obj_tris.swap(tris);
+  c->bvh_host = std::move(bvh);  // only now: the upload succeeded
   for (int i = 0; i < 16; i++) c->model[i] = (i % 5 == 0) ? 1.0f : 0.0f;
   c->model_version++;
   c->use_bvh = (total > 64) || (c->cfg.flags & RTPT_FLAG_FORCE_BVH);
@@ -1329,6 +1332,12 @@ int rtpt_temporal_filter(rtpt_ctx* c, const rtpt_push_constants* pc, const rtpt_
   if (!record) {
     FLUSH_FILTER(c);
     return filter_launch(c, f, 1);
+  }
+  // a recorded K0 (rtpt_gbuffer without rtpt_temporal_gradient behind it) goes out before the first filter record: the
+  // filters read its id / depth planes and are launched from here on without looking at it again
+  {
+    int rcg = gbuffer_flush(c);
+    if (rcg) return rcg;
   }
   // a record that does not continue the recorded run (same iteration twice, a restart) ends it
   if (!c->pending.empty() && (c->pending.back().pc.waveletIteration + 1 != pc->waveletIteration ||

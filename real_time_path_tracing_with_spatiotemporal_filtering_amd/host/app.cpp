@@ -89,7 +89,13 @@ void PathTracingApplication::createBuffers() {
     if (dev >= 0) host_set_device(dev);
     cfg.device = dev;
     stream_ = host_stream_create();
-    transport_ = local ? make_local_transport() : make_rccl_transport(opt_.ranks, opt_.rank, opt_.rccl_id_file);
+    transport_ = local ? make_local_transport()
+                       : make_rccl_transport(opt_.ranks, opt_.rank, opt_.rccl_id_file, opt_.rccl_nonce, opt_.rccl_timeout_s);
+    if (opt_.present) {
+      presentStream_ = host_stream_create();
+      presentTransport_ = local ? make_local_transport()
+                                : make_rccl_transport(opt_.ranks, opt_.rank, opt_.rccl_id_file + ".present", opt_.rccl_nonce, opt_.rccl_timeout_s);
+    }
     for (int r = local ? 0 : opt_.rank; r < (local ? opt_.ranks : opt_.rank + 1); r++) {
       RankState rs;
       rs.plan.height = static_cast<int>(opt_.height);
@@ -227,7 +233,10 @@ void PathTracingApplication::drawSceneToImage() {
 }
 
 bool PathTracingApplication::cameraStatic() const {
-  return std::memcmp(ubo.view, ubo.viewPrev, sizeof ubo.view) == 0 && std::memcmp(ubo.proj, ubo.projPrev, sizeof ubo.proj) == 0;
+  // "static" = every pixel reprojects onto itself: view, proj AND model unchanged (a moving model matrix sends pixels
+  // to other rows just like a moving camera does; this host's model is the identity of main.cpp:1469 every frame)
+  return std::memcmp(ubo.view, ubo.viewPrev, sizeof ubo.view) == 0 && std::memcmp(ubo.proj, ubo.projPrev, sizeof ubo.proj) == 0 &&
+         std::memcmp(ubo.model, ubo.modelPrev, sizeof ubo.model) == 0;
 }
 
 // exchange mode: before iteration k every rank sends its k boundary rows of the iteration's INPUT plane (rgbd cells, so
@@ -324,11 +333,91 @@ void PathTracingApplication::applyTemporalFiltering() {
 void PathTracingApplication::copyImageToSwapChainsCurrentImage() {
   if (multi()) {
     for (auto& rs : ranks_) check(rtpt_end_frame(rs.ctx), "copyImageToSwapChainsCurrentImage");
+    if (opt_.present) presentFrame();
     return;
   }
   check(rtpt_end_frame(ctx_), "copyImageToSwapChainsCurrentImage");  // history hand-over, :1364-1372
   last_ = ctx_;
   ctx_ = ctxs_[(frameCount + 1) % static_cast<uint32_t>(opt_.frames_in_flight)];
+  if (opt_.present == 1) presentFrame();  // f32 on one context: the frame is already whole where it is
+}
+
+// main.cpp:1338-1361: `image` is blitted to the acquired swapchain image.  Here: rtpt_present converts the rows a
+// context owns into its swapchain image (two images, used alternately like a two-image swapchain); with several ranks
+// the presenting rank (0) then receives every other strip — in swapchain format, or as float rows.  The messages run on
+// the present stream behind this frame's kernels, so the next frame's passes do not wait for the wire; before an image
+// (or, for f32, the strip buffer that was sent) is written again two frames later, the frame stream waits for that
+// gather — vkAcquireNextImageKHR's role (main.cpp:1310-1316).
+void PathTracingApplication::presentFrame() {
+  const size_t W = opt_.width, H = opt_.height;
+  const int idx = static_cast<int>(frameCount & 1);
+  if (!multi()) {
+    if (!swapSingle_[idx]) swapSingle_[idx] = host_device_alloc(W * H * 4);
+    check(rtpt_present(last_, swapSingle_[idx], 0, opt_.height), "rtpt_present");
+    return;
+  }
+  const bool rgba8 = opt_.present == 1;
+  const size_t px_bytes = rgba8 ? 4 : 16, row_bytes = W * px_bytes;
+  // acquire: the gather that last used image idx (frame - 2) must be done before this frame's rows land in it
+  host_stream_wait_stream(stream_, presentStream_);
+  std::vector<const char*> mine(ranks_.size());
+  for (size_t i = 0; i < ranks_.size(); i++) {
+    RankState& rs = ranks_[i];
+    const Rows own = rs.plan.own();
+    const bool root = rs.plan.rank == 0;
+    if (rgba8 || root)
+      if (!rs.swap[idx]) rs.swap[idx] = host_device_alloc(H * row_bytes);
+    if (rgba8) {
+      char* dst = static_cast<char*>(rs.swap[idx]) + static_cast<size_t>(own.first) * row_bytes;
+      check(rtpt_present(rs.ctx, dst, static_cast<uint32_t>(own.first), static_cast<uint32_t>(own.second)), "rtpt_present");
+      mine[i] = dst;
+    } else {
+      void* prev = nullptr;
+      check(rtpt_plane_ptr(rs.ctx, RTPT_PLANE_PREVIOUS, &prev), "rtpt_plane_ptr");
+      mine[i] = static_cast<const char*>(prev) + static_cast<size_t>(own.first - rs.plan.stored().first) * row_bytes;
+      if (root)
+        host_device_copy(static_cast<char*>(rs.swap[idx]) + static_cast<size_t>(own.first) * row_bytes, mine[i],
+                         static_cast<size_t>(own.second - own.first) * row_bytes, stream_);
+    }
+  }
+  host_stream_wait_stream(presentStream_, stream_);
+  presentTransport_->begin(presentStream_);
+  for (size_t i = 0; i < ranks_.size(); i++) {
+    RankState& rs = ranks_[i];
+    const Rows own = rs.plan.own();
+    if (rs.plan.rank == 0) {
+      for (int r = 1; r < opt_.ranks; r++) {
+        const Rows o = StripPlan::bounds(static_cast<int>(H), opt_.ranks, r);
+        presentTransport_->recv(0, static_cast<char*>(rs.swap[idx]) + static_cast<size_t>(o.first) * row_bytes, r,
+                                static_cast<size_t>(o.second - o.first) * row_bytes);
+      }
+    } else {
+      presentTransport_->send(rs.plan.rank, mine[i], 0, static_cast<size_t>(own.second - own.first) * row_bytes);
+    }
+  }
+  presentTransport_->end();
+}
+
+std::vector<unsigned char> PathTracingApplication::readPresented() {
+  std::vector<unsigned char> out;
+  if (!opt_.present || frameCount == 0) return out;
+  const int idx = static_cast<int>((frameCount - 1) & 1);
+  const size_t W = opt_.width, H = opt_.height;
+  if (!multi()) {
+    if (opt_.present != 1 || !swapSingle_[idx]) return out;
+    out.resize(W * H * 4);
+    check(rtpt_sync(last_), "rtpt_sync");
+    host_device_to_host(out.data(), swapSingle_[idx], out.size(), nullptr);
+    return out;
+  }
+  for (auto& rs : ranks_)
+    if (rs.plan.rank == 0 && rs.swap[idx]) {
+      out.resize(W * H * (opt_.present == 1 ? 4 : 16));
+      host_stream_sync(stream_);
+      host_stream_sync(presentStream_);
+      host_device_to_host(out.data(), rs.swap[idx], out.size(), presentStream_);
+    }
+  return out;
 }
 
 void PathTracingApplication::drawScene(const std::string& keys) {
@@ -345,14 +434,25 @@ void PathTracingApplication::freeRessources() {
   for (auto& rs : ranks_) {
     if (rs.ctx) rtpt_destroy(rs.ctx);
     if (rs.history) host_device_free(rs.history);
+    for (void*& p : rs.swap) {
+      if (p) host_device_free(p);
+      p = nullptr;
+    }
+  }
+  for (void*& p : swapSingle_) {
+    if (p) host_device_free(p);
+    p = nullptr;
   }
   if (!ranks_.empty()) {
     ranks_.clear();
     ctxs_[0] = ctxs_[1] = nullptr;
     delete transport_;
     transport_ = nullptr;
+    delete presentTransport_;
+    presentTransport_ = nullptr;
     if (stream_) host_stream_destroy(stream_);
-    stream_ = nullptr;
+    if (presentStream_) host_stream_destroy(presentStream_);
+    stream_ = presentStream_ = nullptr;
     ctx_ = last_ = nullptr;
     return;
   }
@@ -408,11 +508,14 @@ std::string PathTracingApplication::planJson(int frames, const std::vector<std::
   return out;
 }
 
-uint64_t PathTracingApplication::bytesSent() const { return transport_ ? transport_->bytes_sent() : 0; }
+uint64_t PathTracingApplication::bytesSent() const {
+  return (transport_ ? transport_->bytes_sent() : 0) + (presentTransport_ ? presentTransport_->bytes_sent() : 0);
+}
 
 void PathTracingApplication::sync() {
   if (multi()) {
     for (auto& rs : ranks_) check(rtpt_sync(rs.ctx), "rtpt_sync");
+    if (presentStream_) host_stream_sync(presentStream_);
     return;
   }
   for (int i = 0; i < opt_.frames_in_flight; i++) check(rtpt_sync(ctxs_[i]), "rtpt_sync");

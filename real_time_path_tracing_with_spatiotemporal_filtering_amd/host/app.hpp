@@ -28,6 +28,12 @@ struct Options {
                                         // (rehearsal / tests: a message is a device-to-device copy)
   bool exchange_halo = false;           // true: k rows per neighbour travel before iteration k; false: redundant rows
   std::string rccl_id_file;             // rendezvous file for the ncclUniqueId (rank >= 0)
+  uint64_t rccl_nonce = 0;              // same on every rank of one launch, different between launches (strips.hpp)
+  int rccl_timeout_s = 120;             // rendezvous + communicator bring-up watchdog
+  // the swapchain blit of main.cpp:1338-1361 inside every frame: 0 none (the frame stays where the final pass left it,
+  // strips stay on their ranks), 1 rgba8 (rtpt_present: B8G8R8A8_UNORM; strips gathered on rank 0 in that format),
+  // 2 f32 (the float strips gathered on rank 0 as they are)
+  int present = 0;
   int device = -1;                      // HIP device of this process (-1: rank % device count, or the current device)
 };
 
@@ -58,6 +64,9 @@ class PathTracingApplication {
 
   // read-back helpers (the reference's only output is the swapchain image)
   std::vector<float> readImage();              // RGBA32F, width*height*4
+  // the frame as presented by the last drawScene (Options::present != 0): the swapchain image of rank 0 —
+  // width*height*4 bytes B,G,R,A (rgba8) or width*height*16 bytes of floats (f32).  Empty on the other ranks' processes.
+  std::vector<unsigned char> readPresented();
   uint64_t rayCount();
   uint64_t bytesSent() const;                  // strips: bytes this process sent (halo rows + history bands)
   // host-only (no GPU, no context): the strip plan of every rank and, per scripted frame, the previous-frame rows each
@@ -83,7 +92,12 @@ class PathTracingApplication {
     StripPlan plan;
     rtpt_ctx* ctx = nullptr;
     void* history = nullptr;  // full-frame device buffer the previous frame's bands are gathered into (lazily allocated)
+    void* swap[2] = {nullptr, nullptr};  // swapchain images (whole-frame size; a non-presenting rank fills its own rows)
   };
+  void* swapSingle_[2] = {nullptr, nullptr};  // the swapchain images of the one-context host
+  Transport* presentTransport_ = nullptr;     // its own communicator + stream: the gather runs behind the frame, beside the next
+  void* presentStream_ = nullptr;
+  void presentFrame();                        // main.cpp:1338-1361
   std::vector<RankState> ranks_;
   Transport* transport_ = nullptr;
   void* stream_ = nullptr;

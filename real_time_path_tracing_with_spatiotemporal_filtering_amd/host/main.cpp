@@ -6,8 +6,11 @@
 #include <cstring>
 #include <exception>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
+
+#include <unistd.h>
 
 #include "app.hpp"
 
@@ -16,11 +19,16 @@ static void usage(const char* argv0) {
       "usage: %s [--width W] [--height H] [--frames N] [--segments S] [--iterations K]\n"
       "          [--scene file.obj] [--script \"keys0,keys1,...\"] [--dump out.pfm] [--exact-filter]\n"
       "          [--frames-in-flight 1|2]\n"
-      "          [--ranks R [--rank r --rccl-id-file F] [--halo redundant|exchange] [--device D]]\n"
+      "          [--ranks R [--rank r --rccl-id-file F [--rccl-nonce N] [--rccl-timeout S]] [--halo redundant|exchange] [--device D]]\n"
+      "          [--present none|rgba8|f32 [--dump-present out.raw]]\n"
       "          [--plan-only   (print the strip plan and the history bands of the scripted frames as JSON; needs no GPU)]\n"
       "  --ranks R splits the frame into R row strips: with --rank r this process is rank r on its own GPU and talks RCCL\n"
       "  (start R processes; rank 0 publishes the ncclUniqueId in F); without --rank all R strips run in this process\n"
       "          [--flags N   (RTPT_FLAG_* bits of include/rtpt.h, e.g. 0xF0 = all extension modes)]\n"
+      "  --rccl-nonce N: any number, the same on every rank of one launch and different between launches (default: the\n"
+      "  launcher's pid); an id file of another launch is ignored; the communicator bring-up gives up after S seconds (120)\n"
+      "  --present: the swapchain blit of every frame (main.cpp:1338-1361): rgba8 converts to B8G8R8A8_UNORM, and with --ranks the\n"
+      "  strips are gathered on rank 0 (rgba8: in that format, f32: as float rows); --dump-present writes rank 0's last image raw\n"
       "  keys per frame are the reference's GLFW keys: WASDQE move the camera, IJKLUO the light\n"
       "  defaults are the reference's constants: 1000x800, 32 segments, 9 iterations (main.cpp:52-55)\n",
       argv0);
@@ -30,7 +38,8 @@ int main(int argc, char** argv) {
   rtpt_host::Options opt;
   int frames = 3;
   bool plan_only = false;
-  std::string dump, script_arg;
+  std::string dump, dump_present, script_arg;
+  opt.rccl_nonce = static_cast<uint64_t>(::getppid());
   // scene path relative to this binary: <pkg>/scenes/...
   std::string self(argv[0]);
   size_t slash = self.find_last_of('/');
@@ -58,6 +67,14 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--halo")) opt.exchange_halo = !std::strcmp(need("--halo"), "exchange");
     else if (!std::strcmp(argv[i], "--rccl-id-file")) opt.rccl_id_file = need("--rccl-id-file");
     else if (!std::strcmp(argv[i], "--device")) opt.device = std::atoi(need("--device"));
+    else if (!std::strcmp(argv[i], "--rccl-nonce")) opt.rccl_nonce = std::strtoull(need("--rccl-nonce"), nullptr, 0);
+    else if (!std::strcmp(argv[i], "--rccl-timeout")) opt.rccl_timeout_s = std::atoi(need("--rccl-timeout"));
+    else if (!std::strcmp(argv[i], "--dump-present")) dump_present = need("--dump-present");
+    else if (!std::strcmp(argv[i], "--present")) {
+      const char* v = need("--present");
+      opt.present = !std::strcmp(v, "rgba8") ? 1 : !std::strcmp(v, "f32") ? 2 : !std::strcmp(v, "none") ? 0 : -1;
+      if (opt.present < 0) { std::fprintf(stderr, "--present takes none, rgba8 or f32\n"); return 2; }
+    }
     else if (!std::strcmp(argv[i], "--plan-only")) plan_only = true;
     else if (!std::strcmp(argv[i], "--flags") && i + 1 < argc) opt.flags |= static_cast<uint32_t>(std::strtoul(argv[++i], nullptr, 0));
     else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) { usage(argv[0]); return 0; }
@@ -87,6 +104,14 @@ int main(int argc, char** argv) {
                 frames, opt.width, opt.height, opt.ranks, opt.rank, ms / frames, static_cast<unsigned long long>(rays),
                 rays / (ms * 1e-3) / 1e6, static_cast<unsigned long long>(app.bytesSent()));
     if (!dump.empty()) app.writePFM(dump);
+    if (!dump_present.empty()) {
+      const std::vector<unsigned char> img = app.readPresented();
+      if (!img.empty()) {  // rank 0's process (or the only one)
+        FILE* f = std::fopen(dump_present.c_str(), "wb");
+        if (!f || std::fwrite(img.data(), 1, img.size(), f) != img.size()) throw std::runtime_error("cannot write " + dump_present);
+        std::fclose(f);
+      }
+    }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "rtpt_app: %s\n", e.what());
     return 1;

@@ -4,7 +4,11 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -80,41 +84,16 @@ M4 mul(const M4& a, const M4& b) {
     }
   return r;
 }
-// inverse by Gauss-Jordan with partial pivoting; throws on a singular model matrix
-M4 inverse(const M4& a) {
-  double w[4][8];
-  for (int i = 0; i < 4; i++)
-    for (int j = 0; j < 4; j++) {
-      w[i][j] = a.m[i][j];
-      w[i][4 + j] = i == j ? 1.0 : 0.0;
-    }
-  for (int c = 0; c < 4; c++) {
-    int p = c;
-    for (int i = c + 1; i < 4; i++)
-      if (std::fabs(w[i][c]) > std::fabs(w[p][c])) p = i;
-    if (std::fabs(w[p][c]) < 1e-300) throw std::runtime_error("singular model matrix");
-    if (p != c)
-      for (int j = 0; j < 8; j++) std::swap(w[p][j], w[c][j]);
-    const double d = w[c][c];
-    for (int j = 0; j < 8; j++) w[c][j] /= d;
-    for (int i = 0; i < 4; i++)
-      if (i != c) {
-        const double f = w[i][c];
-        for (int j = 0; j < 8; j++) w[i][j] -= f * w[c][j];
-      }
-  }
-  M4 r;
-  for (int i = 0; i < 4; i++)
-    for (int j = 0; j < 4; j++) r.m[i][j] = w[i][4 + j];
-  return r;
-}
 }  // namespace
 
 Rows reprojection_rows(const rtpt_ubo& ubo, int width, int height, Rows rows, const float bmin[3], const float bmax[3], float z_near,
                        int pad) {
+  // a model matrix that changed since the previous frame: the shader's previous position is not M_prev M^-1 p (it takes
+  // the current point's area ratios against the previous triangle, temporalFiltering.comp.glsl:223-233) and nothing
+  // bounds it: the whole frame (strips.py:reprojection_rows has the argument)
+  if (std::memcmp(ubo.model, ubo.modelPrev, sizeof ubo.model) != 0) return {0, height};
   const M4 V = from_cm(ubo.view), P = from_cm(ubo.proj);
-  const M4 D = mul(from_cm(ubo.modelPrev), inverse(from_cm(ubo.model)));
-  const M4 PVp = mul(mul(from_cm(ubo.projPrev), from_cm(ubo.viewPrev)), D);
+  const M4 PVp = mul(from_cm(ubo.projPrev), from_cm(ubo.viewPrev));
   // camera origin = -R^T t, world direction of a view-space direction = R^T v
   double org[3];
   for (int i = 0; i < 3; i++) org[i] = -(V.m[0][i] * V.m[0][3] + V.m[1][i] * V.m[1][3] + V.m[2][i] * V.m[2][3]);
@@ -220,25 +199,54 @@ class LocalTransport : public Transport {
 
 class RcclTransport : public Transport {
  public:
-  RcclTransport(int world, int rank, const std::string& id_file) : rank_(rank) {
-    ncclUniqueId id;
+  RcclTransport(int world, int rank, const std::string& id_file, uint64_t nonce, int timeout_s) : rank_(rank) {
+    struct Published {
+      uint64_t magic, nonce;
+      ncclUniqueId id;
+    } pub;
+    constexpr uint64_t kMagic = 0x3144494C43435452ull;  // "RTCCLID1"
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(timeout_s);
     if (rank == 0) {
-      NCCL_OK(ncclGetUniqueId(&id));
-      const std::string tmp = id_file + ".tmp";
+      (void)::unlink(id_file.c_str());  // a file of an earlier launch must not be readable while ours is being made
+      pub.magic = kMagic;
+      pub.nonce = nonce;
+      NCCL_OK(ncclGetUniqueId(&pub.id));
+      const std::string tmp = id_file + ".tmp." + std::to_string(::getpid());
       {
-        std::ofstream f(tmp, std::ios::binary);
-        f.write(reinterpret_cast<const char*>(&id), sizeof id);
+        std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+        f.write(reinterpret_cast<const char*>(&pub), sizeof pub);
+        f.flush();
+        if (!f) throw std::runtime_error("cannot write the RCCL id to " + tmp);
       }
       if (std::rename(tmp.c_str(), id_file.c_str()) != 0) throw std::runtime_error("cannot publish the RCCL id at " + id_file);
     } else {
-      for (int tries = 0;; tries++) {
+      for (;;) {
         std::ifstream f(id_file, std::ios::binary);
-        if (f && f.read(reinterpret_cast<char*>(&id), sizeof id)) break;
-        if (tries > 600) throw std::runtime_error("timed out waiting for the RCCL id at " + id_file);
-        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        if (f && f.read(reinterpret_cast<char*>(&pub), sizeof pub) && pub.magic == kMagic && pub.nonce == nonce) break;
+        if (std::chrono::steady_clock::now() > deadline)
+          throw std::runtime_error("timed out waiting for an RCCL id with this launch's nonce at " + id_file +
+                                   " (is rank 0 running, with the same --rccl-nonce?)");
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
       }
     }
-    NCCL_OK(ncclCommInitRank(&comm_, world, id, rank));
+    // ncclCommInitRank blocks until all `world` ranks have joined: a peer that never comes, or one holding another id,
+    // is an endless wait.  The watchdog turns that into an error exit.
+    std::atomic<bool> up{false};
+    std::thread watchdog([&up, deadline, rank, world] {
+      while (!up.load()) {
+        if (std::chrono::steady_clock::now() > deadline) {
+          std::fprintf(stderr, "rtpt_app: rank %d: the RCCL communicator of %d ranks did not come up in time (a rank is missing or "
+                               "holds the id of another launch); giving up\n", rank, world);
+          std::fflush(stderr);
+          ::_exit(3);
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+      }
+    });
+    const ncclResult_t rc = ncclCommInitRank(&comm_, world, pub.id, rank);
+    up.store(true);
+    watchdog.join();
+    NCCL_OK(rc);
   }
   ~RcclTransport() override {
     if (comm_) ncclCommDestroy(comm_);
@@ -249,12 +257,12 @@ class RcclTransport : public Transport {
   }
   void send(int src_rank, const void* src, int dst_rank, size_t bytes) override {
     if (src_rank != rank_) throw std::runtime_error("RCCL transport: send from a rank of another process");
-    NCCL_OK(ncclSend(src, bytes / 4, ncclFloat, dst_rank, comm_, stream_));
+    NCCL_OK(ncclSend(src, bytes, ncclChar, dst_rank, comm_, stream_));
     sent_ += bytes;
   }
   void recv(int dst_rank, void* dst, int src_rank, size_t bytes) override {
     if (dst_rank != rank_) throw std::runtime_error("RCCL transport: receive into a rank of another process");
-    NCCL_OK(ncclRecv(dst, bytes / 4, ncclFloat, src_rank, comm_, stream_));
+    NCCL_OK(ncclRecv(dst, bytes, ncclChar, src_rank, comm_, stream_));
   }
   void end() override { NCCL_OK(ncclGroupEnd()); }
   uint64_t bytes_sent() const override { return sent_; }
@@ -289,7 +297,22 @@ void host_device_copy(void* dst, const void* src, size_t bytes, void* stream) {
   HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
 }
 
+void host_device_to_host(void* dst, const void* src, size_t bytes, void* stream) {
+  HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+  HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+}
+void host_stream_wait_stream(void* waiter, void* on) {
+  hipEvent_t e = nullptr;
+  HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_OK(hipEventRecord(e, static_cast<hipStream_t>(on)));
+  HIP_OK(hipStreamWaitEvent(static_cast<hipStream_t>(waiter), e, 0));
+  HIP_OK(hipEventDestroy(e));  // the recorded wait keeps what it needs; the handle can go
+}
+void host_stream_sync(void* stream) { HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream))); }
+
 Transport* make_local_transport() { return new LocalTransport(); }
-Transport* make_rccl_transport(int world, int rank, const std::string& id_file) { return new RcclTransport(world, rank, id_file); }
+Transport* make_rccl_transport(int world, int rank, const std::string& id_file, uint64_t nonce, int timeout_s) {
+  return new RcclTransport(world, rank, id_file, nonce, timeout_s);
+}
 
 }  // namespace rtpt_host

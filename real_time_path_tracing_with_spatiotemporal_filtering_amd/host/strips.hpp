@@ -76,8 +76,13 @@ class Transport {
 // every rank lives in this process (strip contexts on one GPU, one shared stream): a message is a device-to-device copy
 Transport* make_local_transport();
 // one rank per process, one GPU per rank: ncclSend / ncclRecv in a group on the context's stream (RCCL over xGMI).
-// Rendezvous without MPI: rank 0 writes the ncclUniqueId to `id_file`, the others wait for it.
-Transport* make_rccl_transport(int world, int rank, const std::string& id_file);
+// Rendezvous without MPI: rank 0 removes whatever `id_file` holds, then publishes {magic, nonce, ncclUniqueId} there
+// (written to a temporary name and renamed); the others poll until the file carries THEIR nonce — a file left behind by
+// an earlier launch (another nonce) is ignored, not trusted.  `nonce` must be the same on every rank of one launch and
+// should differ between launches (rtpt_app --rccl-nonce; default: the launcher's pid).  ncclCommInitRank runs under a
+// watchdog: if the communicator is not up after `timeout_s` seconds the process prints why and exits with status 3
+// instead of hanging (mismatched ids and missing peers both show up as exactly that hang).
+Transport* make_rccl_transport(int world, int rank, const std::string& id_file, uint64_t nonce, int timeout_s);
 
 // HIP runtime calls the host needs besides the C ABI (kept out of app.cpp, which sees rtpt.h only)
 int host_device_count();
@@ -87,5 +92,9 @@ void host_stream_destroy(void* stream);
 void* host_device_alloc(size_t bytes);
 void host_device_free(void* p);
 void host_device_copy(void* dst, const void* src, size_t bytes, void* stream);
+void host_device_to_host(void* dst, const void* src, size_t bytes, void* stream);  // blocking
+// stream-to-stream ordering without blocking the host: `waiter` continues once everything submitted to `on` so far is done
+void host_stream_wait_stream(void* waiter, void* on);
+void host_stream_sync(void* stream);
 
 }  // namespace rtpt_host

@@ -177,7 +177,8 @@ def reprojection_rows(ubo, width: int, height: int, rows, bounds, z_near: float 
 
     The G-buffer's world position of pixel (x, y) lies on that pixel's centre ray at a view depth z between the
     nearest and the farthest corner of the bounds; its previous-frame pixel row is
-        ppy = ((P_prev V_prev M_prev M^-1 p).y / (...).w * 0.5 + 0.5) * H        (worldToPixel, :178-189)
+        ppy = ((P_prev V_prev p).y / (...).w * 0.5 + 0.5) * H        (worldToPixel, :178-189)
+    (with model == modelPrev the previous world position IS the current one; `bounds` are those of the POSED scene)
     which is a ratio of functions affine in x, in y and in z separately — monotone along each of the three axes — so
     over the box [0, W-1] x [y0, y1-1] x [z_lo, z_hi] it takes its extremes at the 8 corners.  `pad` rows cover the
     binary32 rounding of the device arithmetic (the kernel's value is within a small fraction of a pixel of this
@@ -185,9 +186,14 @@ def reprojection_rows(ubo, width: int, height: int, rows, bounds, z_near: float 
     Background pixels (id 0) fetch their own pixel (:215-217), so `rows` itself is always part of the result."""
     import numpy as np
     y0, y1 = rows
+    if list(ubo.model) != list(ubo.modelPrev):
+        # A model matrix that changed since the previous frame: the shader takes the CURRENT world position's area-ratio
+        # barycentrics against the PREVIOUS frame's triangle (both vertex sets come from LUTprev,
+        # temporalFiltering.comp.glsl:223-233) — a point off that triangle's plane, whose "barycentrics" do not sum to
+        # one — so the previous position is not M_prev M^-1 p and no ray/depth argument bounds it: the whole frame.
+        return 0, height
     V, P = _mat(ubo.view), _mat(ubo.proj)
-    D = _mat(ubo.modelPrev) @ np.linalg.inv(_mat(ubo.model))
-    PVp = _mat(ubo.projPrev) @ _mat(ubo.viewPrev) @ D
+    PVp = _mat(ubo.projPrev) @ _mat(ubo.viewPrev)
     R, t = V[:3, :3], V[:3, 3]
     org = -R.T @ t
     lo, hi = (np.asarray(b, np.float64) for b in bounds)
@@ -263,7 +269,7 @@ def gather_frame(plan: StripPlan, mine, full, root: int = 0, group=None) -> int:
     [H, W, C] image on the root.  Strips may differ by a row, so this is a group of point-to-point messages rather than
     a gather collective: the root posts its R-1 receives together (RCCL then drives every xGMI link into the root at
     once: 7 x 16.6 MB at 4K f32, a quarter of that in swapchain format), every other rank posts one send.  Enqueued on
-    the current stream.  Returns the bytes this rank sent."""
+    the current stream.  Returns the bytes this rank put on or took off the wire."""
     if plan.world == 1:
         return 0
     o0, o1 = plan.own
@@ -274,6 +280,6 @@ def gather_frame(plan: StripPlan, mine, full, root: int = 0, group=None) -> int:
                 a, b = StripPlan.bounds(plan.height, plan.world, r)
                 recvs.append((full[a:b], r))
         _post([], recvs, group)
-        return 0
+        return sum(t.numel() * t.element_size() for t, _ in recvs)
     _post([(mine, root)], [], group)
     return mine.numel() * mine.element_size()

@@ -80,3 +80,31 @@ def test_gloo_ranks_on_one_gpu_reproduce_the_single_context_frames(hip_lib, tmp_
     moved_frames = 3   # E, QA, E
     planes = 1 + (flags & 0x100 != 0) * 1.25 + (flags & 0x180 != 0 and not flags & 0x100) * 0.25
     assert 0 < sent < moved_frames * 3 * H * W * 16 * planes, "bands, not a whole frame to every rank"
+
+
+@pytest.mark.parametrize("mode,present", [("redundant", "rgba8"), ("exchange", "f32")])
+def test_gloo_ranks_on_one_gpu_assemble_the_presented_frame(hip_lib, tmp_path, mode, present):
+    """main.cpp:1338-1361 on strips, on DEVICE memory: three ranks on GPU 0 (gloo as the carrier), the gather issued on
+    its own stream behind each frame; rank 0's assembled frame — float strips, or rtpt_present's B8G8R8A8 conversion —
+    equals the single-context frame (converted by the oracle's restatement of the blit) bit for bit, every frame"""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    W, H, keys = 144, 150, ",E,J,,Q"
+    args = [str(tmp_path), mode, "0", keys, str(W), str(H), present]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    worker = os.path.join(ROOT, "tests", "strip_worker.py")
+    out = subprocess.run([sys.executable, worker] + args, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
+                          "127.0.0.1", "--master-port", str(_port()), worker] + args,
+                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ref = np.load(tmp_path / "w1_r0.npz")
+    root = np.load(tmp_path / "w3_r0.npz")
+    for f in range(len(keys.split(","))):
+        want = ref[f"arr_{f}"]
+        if present == "rgba8":
+            assert ref[f"shown_{f}"].tobytes() == O.present_bgra8(want).tobytes(), "k_present vs the oracle's blit"
+            want = O.present_bgra8(want)
+        assert root[f"shown_{f}"].tobytes() == want.tobytes(), (mode, present, f)

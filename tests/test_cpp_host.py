@@ -100,6 +100,57 @@ def test_cpp_host_rccl_transport_single_rank(app_binary, tmp_path):
     assert out.returncode == 1 and "rank out of range" in out.stderr
 
 
+@pytest.mark.gpu
+def test_cpp_host_rccl_rendezvous_ignores_a_stale_id_and_never_hangs(app_binary, tmp_path):
+    """host/strips.cpp RcclTransport: (a) a rank > 0 that finds an id file of ANOTHER launch (different nonce) does not
+    trust it and gives up with an error when its own launch's id never appears; (b) rank 0 removes the stale file,
+    publishes its own, and when its peer never joins the communicator the watchdog ends the process with status 3
+    instead of hanging in ncclCommInitRank"""
+    import struct
+    import time
+    idf = tmp_path / "id"
+    stale = struct.pack("<QQ", 0x3144494C43435452, 6) + bytes(128)
+    idf.write_bytes(stale)
+    common = [app_binary, "--width", "64", "--height", "48", "--frames", "1", "--segments", "2", "--iterations", "3", "--ranks", "2",
+              "--rccl-id-file", str(idf), "--rccl-nonce", "7"]
+    t0 = time.time()
+    out = subprocess.run(common + ["--rank", "1", "--rccl-timeout", "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 1 and "this launch's nonce" in out.stderr, out.stderr
+    assert idf.read_bytes() == stale
+    out = subprocess.run(common + ["--rank", "0", "--rccl-timeout", "6"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3 and "did not come up in time" in out.stderr, (out.returncode, out.stderr)
+    fresh = idf.read_bytes()
+    assert fresh[:16] == struct.pack("<QQ", 0x3144494C43435452, 7) and fresh != stale, "rank 0 replaced the stale file"
+    assert time.time() - t0 < 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,halo,present", [(1, "redundant", "rgba8"), (3, "redundant", "rgba8"), (4, "exchange", "f32")])
+def test_cpp_host_presents_the_assembled_frame(app_binary, hip_lib, oracle, tmp_path, ranks, halo, present):
+    """--present: main.cpp:1338-1361 in the C++ host.  One context converts its frame with rtpt_present; with --ranks the
+    presenting rank's swapchain image is assembled from every strip (converted rows, or float rows) on the present
+    stream.  The last image equals the Python single-context frame (through the oracle's restatement of the blit)."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    W, H, SEG, N = 160, 121, 3, 5
+    keys = ["", "E", "J", "QA", ""]
+    raw = tmp_path / "present.raw"
+    cmd = [app_binary, "--width", str(W), "--height", str(H), "--segments", str(SEG), "--iterations", str(N), "--frames", str(len(keys)),
+           "--script", ",".join(keys), "--present", present, "--dump-present", str(raw)]
+    if ranks > 1:
+        cmd += ["--ranks", str(ranks), "--halo", halo]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    app = make_app(W, H, max_segments=SEG, iterations=N)
+    for k in keys:
+        app.drawScene(tuple(k))
+    want = app.backend.ctx.readback(hip_lib.PLANE_IMAGE)
+    got = np.fromfile(raw, np.uint8)
+    if present == "rgba8":
+        assert got.tobytes() == oracle.present_bgra8(want).tobytes()
+    else:
+        assert got.tobytes() == want.tobytes()
+
+
 @pytest.mark.parametrize("halo", ["redundant", "exchange"])
 def test_cpp_strip_plan_and_history_bands_equal_the_python_mirror(app_binary, halo):
     """host-only (no GPU): `rtpt_app --plan-only` prints the C++ host's strip plan and, per scripted frame, the

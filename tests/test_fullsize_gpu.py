@@ -235,3 +235,58 @@ def test_device_side_alpha_is_zero_after_the_last_iteration(hip_lib, n_iter):
         prev = be.color_rows(abi.PLANE_PREVIOUS, 0, h).cpu().numpy()
         assert np.array_equal(bits(prev), bits(img))
     be.close()
+
+
+def test_1080p_frames_against_oracle_and_chain_equals_separate_passes(hip_lib, oracle, cornell):
+    """BASELINE configs[1] at its size (1920x1080, 4 segments, N = 5) under the DEFAULT kernel policy — at this size the
+    iterations k < N run as chained pairs on 32 row segments of 34 rows x 16 column strips with an unrounded last step
+    (a geometry no other size exercises).  Two frames, the light moves in the second:
+    * every observable against the oracle: ids, first hits, traced colour, gradient, reprojected pixel bit for bit, the
+      final image within FILTER_TOL;
+    * with RTPT_FLAG_EXACT_FILTER the chained run equals the one-kernel-per-iteration run (RTPT_FLAG_NO_FILTER_FUSION)
+      AND the oracle's image bit for bit."""
+    from test_parity_gpu import l2_ok, make_pair
+    oracle.set_threads(min(16, os.cpu_count() or 1))
+    W, H = 1920, 1080
+    runs = {}
+    try:
+        for name, flags in (("default", 0), ("exact", hip_lib.FLAG_EXACT_FILTER),
+                            ("exact_unfused", hip_lib.FLAG_EXACT_FILTER | hip_lib.FLAG_NO_FILTER_FUSION)):
+            app, ref = make_pair(hip_lib, oracle, cornell, w=W, h=H, seg=4, n=5, flags=flags)
+            ctx = app.backend.ctx
+            ctx.timing_enable(1)
+            frames, total_rays = [], 0
+            for keys, light_move in (((), None), (("J",), (-0.1, 0, 0))):
+                app.updateScene(keys)
+                app.drawVisbilityBuffer()
+                app.computeTemporalGradient()
+                app.drawSceneToImage()
+                obs = dict(vis=ctx.readback(hip_lib.PLANE_VIS_ID), hit=ctx.readback(hip_lib.PLANE_HIT_ID),
+                           traced=ctx.readback(hip_lib.PLANE_IMAGE), grad=ctx.readback(hip_lib.PLANE_GRADIENT), rays=ctx.raycount())
+                app.applyTemporalFiltering()
+                obs["final"], obs["pp"] = ctx.readback(hip_lib.PLANE_IMAGE), ctx.readback(hip_lib.PLANE_PREV_PIXEL)
+                app.copyImageToSwapChainsCurrentImage()
+                app.frameCount += 1
+                if name != "exact_unfused":   # the oracle's frames are the same for both arithmetics of the GPU run
+                    fo = ref.draw_scene(move_light=light_move)
+                    total_rays += fo.rays
+                    assert np.array_equal(obs["vis"], fo.vis) and np.array_equal(obs["hit"], fo.hit_id)
+                    assert np.array_equal(bits(obs["traced"]), bits(fo.traced))
+                    assert np.array_equal(bits(obs["grad"]), bits(fo.gradient))
+                    assert np.array_equal(obs["pp"], fo.prev_pixel)
+                    assert obs["rays"] == total_rays
+                    if name == "exact":
+                        assert np.array_equal(bits(obs["final"]), bits(fo.image)), "exact filter: the oracle's bits"
+                    else:
+                        ok, rel = l2_ok(obs["final"], fo.image)
+                        assert ok, rel
+                frames.append(obs["final"])
+            tm = ctx.timing_collect()
+            chained = tm["k_atrous_chain"][1]
+            assert chained == (0 if name == "exact_unfused" else 4), (name, tm)   # 2 pairs x 2 frames
+            runs[name] = frames
+            app.backend.close()
+        for a, b in zip(runs["exact"], runs["exact_unfused"]):
+            assert np.array_equal(bits(a), bits(b)), "chain == separate passes at 1080p"
+    finally:
+        oracle.set_threads(min(8, os.cpu_count() or 1))

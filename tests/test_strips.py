@@ -104,7 +104,7 @@ class OracleBackend:
         self._ext_rows = None
 
     def scene_upload(self, xyz, idx, xforms=None):
-        self.tris = self.O.flatten(xyz, idx, xforms)
+        self.base_tris = self.tris = self.O.flatten(xyz, idx, xforms)
 
     def _opc(self, pc):
         return self.O.PushConstants.from_buffer_copy(bytes(pc))
@@ -113,9 +113,13 @@ class OracleBackend:
         return self.O.Ubo.from_buffer_copy(bytes(ubo))
 
     def gbuffer(self, ubo, y0, y1):
-        self.lut = self.O.lut(self.tris, np.array(ubo.model[:], np.float32))
+        model = np.array(ubo.model[:], np.float32)
+        self.lut = self.O.lut(self.base_tris, model)
         if self.lut_prev is None:
             self.lut_prev = self.lut.copy()
+        # world triangle = model * uploaded triangle (visibility.vert.glsl:24): exactly the LUT's vertices (oracle.OracleApp)
+        self.tris = self.base_tris if np.array_equal(model, np.eye(4, dtype=np.float32).ravel()) else \
+            np.ascontiguousarray(self.lut[1:].reshape(-1, 3, 4)[:, :, :3].reshape(-1, 9))
         v, w, d = self.O.gbuffer(self.cfg, self.tris, self._oubo(ubo), y0, y1)
         self.vis[y0:y1], self.wp[y0:y1], self.depth[y0:y1] = v[y0:y1], w[y0:y1], d[y0:y1]
 
@@ -194,7 +198,16 @@ W, H, SEG, N, FRAMES = 48, 40, 2, 5, 5
 KEYS = [(), ("J",), ("D",), ("E",), ()]   # light move, lateral and VERTICAL camera moves (history crosses strips), rest
 
 
-def _run_rank(rank, world, mode, port, out_dir, ext=0, in_flight=1, present=None):
+def _model(f):
+    """animated ubo.model for frame f (column-major): the scene bobs up and down and shears a little, so pixels
+    reproject across strip borders while the camera rests"""
+    m = np.eye(4, dtype=np.float32)
+    m[1, 3] = [0.0, 0.25, 0.25, -0.2, 0.1][f % 5]
+    m[0, 1] = 0.05 * (f % 3)
+    return np.ascontiguousarray(m.T).ravel()
+
+
+def _run_rank(rank, world, mode, port, out_dir, ext=0, in_flight=1, present=None, animate=False):
     import sys
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -213,7 +226,9 @@ def _run_rank(rank, world, mode, port, out_dir, ext=0, in_flight=1, present=None
     app.buildAccelerationStructure()
     frames, shown = [], []
     for f in range(FRAMES):
-        app.drawScene(KEYS[f])
+        if animate:
+            app.modelMatrix = _model(f)
+        app.drawScene(() if animate else KEYS[f])
         o0, o1 = plan.own
         last = be.prev if in_flight == 2 else be
         frames.append(last.final_image()[o0:o1].copy())
@@ -221,7 +236,7 @@ def _run_rank(rank, world, mode, port, out_dir, ext=0, in_flight=1, present=None
             img = app.presented_image()
             shown.append(img.numpy().copy() if img is not None else last.final_image().copy())
     rays = sum(b.rays for b in be.be) if in_flight == 2 else be.rays
-    tag = ("p" if in_flight == 2 else "") + (present or "")
+    tag = ("p" if in_flight == 2 else "") + (present or "") + ("anim" if animate else "")
     np.savez(os.path.join(out_dir, f"{mode}{ext}{tag}_{world}_{rank}.npz"), *frames, rays=np.array([rays]),
              **{f"shown_{i}": a for i, a in enumerate(shown)})
     if world > 1:
@@ -269,6 +284,24 @@ def test_two_frames_in_flight_equal_one(tmp_path, oracle, world, mode):
         got = np.concatenate([p[f"arr_{f}"] for p in parts], axis=0)
         assert got.tobytes() == ref[f"arr_{f}"].tobytes(), f"frame {f}"
     assert sum(int(p["rays"][0]) for p in parts) == int(ref["rays"][0])
+
+
+@pytest.mark.parametrize("world,mode", [(3, "redundant"), (2, "exchange")])
+def test_gloo_ranks_with_an_animated_model_matrix(tmp_path, oracle, world, mode):
+    """ubo.model changes every frame while the camera rests (main.cpp:1469 recomputes it per frame): pixels reproject
+    into other strips' rows, so the history bands must travel although view/proj did not change, and the reprojection
+    bound must use the POSED scene bounds — strips equal the single-rank frames bit for bit"""
+    import torch.multiprocessing as mp
+    _run_rank(0, 1, mode, 0, str(tmp_path), 0, 1, None, True)
+    mp.spawn(_run_rank, args=(world, mode, _free_port(), str(tmp_path), 0, 1, None, True), nprocs=world, join=True)
+    ref = np.load(tmp_path / f"{mode}0anim_1_0.npz")
+    parts = [np.load(tmp_path / f"{mode}0anim_{world}_{r}.npz") for r in range(world)]
+    differs = False
+    for f in range(FRAMES):
+        got = np.concatenate([p[f"arr_{f}"] for p in parts], axis=0)
+        assert got.tobytes() == ref[f"arr_{f}"].tobytes(), f"frame {f}"
+        differs |= f > 0 and ref[f"arr_{f}"].tobytes() != ref["arr_0"].tobytes()
+    assert differs and sum(int(p["rays"][0]) for p in parts) == int(ref["rays"][0])
 
 
 @pytest.mark.parametrize("world,mode,present,in_flight", [(2, "redundant", "rgba8", 1), (3, "exchange", "f32", 1),
