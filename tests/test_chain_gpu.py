@@ -45,6 +45,25 @@ def test_chain_equals_separate_passes(hip_lib, size, exact):
             assert np.array_equal(pa, pb)
 
 
+@pytest.mark.parametrize("g", [2, 3, 6])
+def test_sliding_window_variant_equals_separate_passes(hip_lib, monkeypatch, g):
+    """RTPT_CHAIN_SW=1: the round-3 sliding-window kernel (a wave owns a residue class of rows and keeps the 3x3 tap
+    window in registers; not the default — measured slower, profiles/r03_chain_sw_ab.csv) computes the same bits, at the
+    frame borders (top/bottom clamp events), on ragged strips and for every rows-per-step setting"""
+    monkeypatch.setenv("RTPT_CHAIN_SW", "1")
+    monkeypatch.setenv("RTPT_CHAIN_SW_G1", str(g))
+    monkeypatch.setenv("RTPT_CHAIN_SW_G3", str(g))
+    keys = [(), ("J",), ("D", "E"), ()]
+    for (w, h) in ((1, 1), (63, 5), (65, 7), (130, 33), (333, 170), (1000, 800)):
+        for n in (2, 3, 5):
+            for exact in (0, 1):
+                a, _ = _frames(hip_lib, w, h, n, exact, keys)
+                b, _ = _frames(hip_lib, w, h, n, exact | hip_lib.FLAG_NO_FILTER_FUSION, keys)
+                for f, ((ia, pa), (ib, pb)) in enumerate(zip(a, b)):
+                    assert np.array_equal(bits(ia), bits(ib)), (w, h, n, exact, f)
+                    assert np.array_equal(pa, pb)
+
+
 @pytest.mark.parametrize("exact", [0, 1])
 def test_chain_equals_separate_passes_4k(hip_lib, exact):
     """BASELINE configs[2] at its size: 3840x2160, 4 segments, N = 5, three frames"""
