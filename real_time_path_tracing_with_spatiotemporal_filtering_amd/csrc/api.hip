@@ -84,6 +84,8 @@ struct rtpt_ctx {
   bool use_bvh = false;
   rt::BvhGrid bvh_grid{};
   int bvh_depth = 0;
+  bool tris_paired = false;  // every (2q, 2q+1) is a fan pair: same v0, v2_A == v1_B bitwise (kernels.hip tri_pair_test)
+  bool no_pairing = false;   // RTPT_NO_TRI_PAIRS=1: A/B switch
   std::vector<float> host_tris;  // flattened world-space triangles, kept for small scenes (screen bounds)
   // animated model matrix (main.cpp:1469 recomputes ubo.model every frame; it is the identity there): the scene as
   // uploaded (object space = instance transforms applied, model not), its BVH topology, and the model it is posed with
@@ -304,6 +306,7 @@ rt::SceneView scene_view(const rtpt_ctx* c) {
   }
   s.n_tris = c->n_tris;
   s.use_bvh = c->use_bvh ? 1u : 0u;
+  s.paired = (c->tris_paired && !c->no_pairing) ? 1u : 0u;
   s.stack_depth = static_cast<uint32_t>(c->bvh_depth + 2 < 8 ? 8 : c->bvh_depth + 2);
   s.stack_lds = std::min<uint32_t>(s.stack_depth, static_cast<uint32_t>(c->bvh_stack_lds));
   s.stack_spill = static_cast<uint32_t*>(c->stack_spill.ptr);
@@ -497,6 +500,7 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   c->count_y0 = static_cast<int>(cfg->row_begin);
   c->count_y1 = static_cast<int>(cfg->row_end);
   // tuning knobs for A/B runs on the box (never needed for correctness: every setting computes the same pixels)
+  if (const char* v = std::getenv("RTPT_NO_TRI_PAIRS")) c->no_pairing = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_CHAIN_MAX")) c->chain_max = std::max(1, std::min(3, std::atoi(v)));
   if (const char* v = std::getenv("RTPT_CHAIN_FINAL")) c->chain_final = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_BVH_STACK_LDS")) c->bvh_stack_lds = std::max(1, std::atoi(v));
@@ -740,6 +744,14 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
     c->host_tris = tris;
   else
     c->host_tris.clear();
+  // fan pairs (a, b, c), (a, c, d): the posed records are computed from these vertices with one arithmetic, so bitwise
+  // equality here is bitwise equality of v0 and of e2_A / e1_B on the device, whatever the model matrix
+  c->tris_paired = total >= 2 && total % 2 == 0 && total <= static_cast<uint32_t>(rt::kCullMaxTris);
+  for (uint32_t q = 0; c->tris_paired && q < total / 2; q++) {
+    const float* ta = tris.data() + 18 * static_cast<size_t>(q);
+    const float* tb = ta + 9;
+    c->tris_paired = std::memcmp(ta, tb, 12) == 0 && std::memcmp(ta + 6, tb + 3, 12) == 0;
+  }
   c->obj_tris.swap(tris);
   c->bvh_host = std::move(bvh);  // only now: the upload succeeded
   for (int i = 0; i < 16; i++) c->model[i] = (i % 5 == 0) ? 1.0f : 0.0f;

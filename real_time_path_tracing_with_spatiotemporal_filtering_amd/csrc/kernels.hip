@@ -81,6 +81,57 @@ __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float
   }
 }
 
+#if RTPT_TRI_XOR_SIGN
+// Two triangles (a, b, c), (a, c, d) of one fan-triangulated face (main.cpp:416-428 via D5: every `f` line of the
+// Cornell OBJ is a quad) share v0 and the edge c - a: tv = o - v0, c = tv x d and e2_A . c == e1_B . c are the SAME
+// binary32 values in both tests, so the second test reuses them — 17 instead of 30 VALU, each triangle's own arithmetic
+// and the ascending-id update order unchanged (bit-identical hits).  SceneView::paired says every pair (2q, 2q+1) of the
+// scene is such a pair (checked bitwise on the uploaded vertices, rtpt_scene_upload).
+__device__ __forceinline__ void tri_pair_test(f3 o, f3 d, float4 r0, float4 r1, float4 r2, float4 q1, float4 q2, uint32_t id1, HitRec& h) {
+  const f3 v0{r0.x, r0.y, r0.z}, e1{r0.w, r1.x, r1.y}, e2{r1.z, r1.w, r2.x}, n{r2.y, r2.z, r2.w};
+  const f3 e2b{q1.z, q1.w, q2.x}, nb{q2.y, q2.z, q2.w};  // B: e1_B == e2 (bitwise), v0_B == v0
+  const f3 tv = o - v0;
+  const f3 c = exact::cross(tv, d);
+  const float e2c = exact::dot(e2, c);
+  {
+    const float dn = exact::dot(d, n);
+    const uint32_t sm = f2u(dn) & 0x80000000u;
+    const float tt = u2f(f2u(exact::dot(tv, n)) ^ sm);
+    const float u = u2f(f2u(e2c) ^ sm);
+    const float v = u2f(f2u(exact::dot(e1, c)) ^ sm);
+    const float ad = __builtin_fabsf(dn);
+    if ((u <= 0.0f) && (v >= 0.0f) && (v - u <= ad) && (tt < 0.0f)) {
+      const float th = (-tt) / ad;
+      if (th < h.t) {
+        h.t = th;
+        h.id1 = id1;
+        h.u = u;
+        h.v = v;
+        h.ad = ad;
+      }
+    }
+  }
+  {
+    const float dn = exact::dot(d, nb);
+    const uint32_t sm = f2u(dn) & 0x80000000u;
+    const float tt = u2f(f2u(exact::dot(tv, nb)) ^ sm);
+    const float u = u2f(f2u(exact::dot(e2b, c)) ^ sm);
+    const float v = u2f(f2u(e2c) ^ sm);  // e1_B . c
+    const float ad = __builtin_fabsf(dn);
+    if ((u <= 0.0f) && (v >= 0.0f) && (v - u <= ad) && (tt < 0.0f)) {
+      const float th = (-tt) / ad;
+      if (th < h.t) {
+        h.t = th;
+        h.id1 = id1 + 1;
+        h.u = u;
+        h.v = v;
+        h.ad = ad;
+      }
+    }
+  }
+}
+#endif
+
 // Small scenes (<= 64 triangles, the Cornell box has 32): every lane of the wave tests the same
 // triangle at the same time, so the record address is wave-uniform and the loads are scalar
 // (s_load_dwordx4 -> SGPR operands of the VALU ops).  No stack, no divergence, no memory latency.
@@ -95,6 +146,17 @@ __device__ __forceinline__ void closest_hit_brute(const SceneView& sc, f3 o, f3 
   const uint32_t n = sc.n_tris;
 #ifndef RTPT_BRUTE_UNROLL
 #define RTPT_BRUTE_UNROLL 8  // triangles whose records are fetched per batch of scalar loads; K2 at 4K: 2: 517, 4: 505, 8: 499, 16: 498 us
+#endif
+#if RTPT_TRI_XOR_SIGN
+  if (sc.paired) {  // wave-uniform
+#pragma unroll 4
+    for (uint32_t i = 0; i < n; i += 2) {
+      const v4f a0 = rec[3 * i], a1 = rec[3 * i + 1], a2 = rec[3 * i + 2], b1 = rec[3 * i + 4], b2 = rec[3 * i + 5];
+      tri_pair_test(o, d, make_float4(a0.x, a0.y, a0.z, a0.w), make_float4(a1.x, a1.y, a1.z, a1.w), make_float4(a2.x, a2.y, a2.z, a2.w),
+                    make_float4(b1.x, b1.y, b1.z, b1.w), make_float4(b2.x, b2.y, b2.z, b2.w), i + 1, h);
+    }
+    return;
+  }
 #endif
 #pragma unroll RTPT_BRUTE_UNROLL
   for (uint32_t i = 0; i < n; i++) {
@@ -119,10 +181,24 @@ __device__ __forceinline__ void closest_hit_brute_set(const SceneView& sc, unsig
   typedef float v4f __attribute__((ext_vector_type(4)));
   using cv4f = const __attribute__((address_space(4))) v4f;
   cv4f* rec = (cv4f*)sc.isect_id;
+#if RTPT_TRI_XOR_SIGN
+  const bool paired = sc.paired != 0;
+#else
+  const bool paired = false;
+#endif
   while (cand) {
     const uint32_t i = static_cast<uint32_t>(__builtin_ctzll(cand));
     cand &= cand - 1;
     const v4f a0 = rec[3 * i], a1 = rec[3 * i + 1], a2 = rec[3 * i + 2];
+#if RTPT_TRI_XOR_SIGN
+    if (paired && !(i & 1u) && (cand & (1ull << (i + 1)))) {  // both triangles of a fan pair are candidates (wave-uniform)
+      cand &= cand - 1;
+      const v4f b1 = rec[3 * i + 4], b2 = rec[3 * i + 5];
+      tri_pair_test(o, d, make_float4(a0.x, a0.y, a0.z, a0.w), make_float4(a1.x, a1.y, a1.z, a1.w), make_float4(a2.x, a2.y, a2.z, a2.w),
+                    make_float4(b1.x, b1.y, b1.z, b1.w), make_float4(b2.x, b2.y, b2.z, b2.w), i + 1, h);
+      continue;
+    }
+#endif
     tri_test<false>(o, d, make_float4(a0.x, a0.y, a0.z, a0.w), make_float4(a1.x, a1.y, a1.z, a1.w),
                     make_float4(a2.x, a2.y, a2.z, a2.w), i + 1, h);
   }

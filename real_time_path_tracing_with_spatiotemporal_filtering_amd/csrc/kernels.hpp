@@ -21,6 +21,7 @@ struct SceneView {
   float bvh_origin[3], bvh_cell[3];
   uint32_t n_tris;
   uint32_t use_bvh;  // 0: brute force over isect_id, 1: BVH traversal
+  uint32_t paired;   // brute force only: triangles (2q, 2q+1) share v0 and the edge v2_A == v1_B bitwise (fan-triangulated faces)
   uint32_t stack_depth;  // BVH traversal stack entries per lane (tree depth + 2)
   // The first stack_lds entries of a lane's stack live in LDS (what sets the workgroups per CU: the 1.15M-triangle
   // tree is 28 deep, 30 KB per workgroup = 5 per CU, and its trace is that sensitive to occupancy: 2 / 3 / 4 / 5
