@@ -717,7 +717,7 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   std::vector<rt::BvhNodeQ> nodes_h;
   c->bvh_grid = rt::pack_quantised_nodes(bvh, nodes_h);
   if ((rc = alloc_buf(c->nodes, nodes_h.size() * sizeof(rt::BvhNodeQ)))) return rc;
-  if ((rc = alloc_buf(c->normal_tab, (static_cast<size_t>(total) + 1) * 16))) return rc;
+  if ((rc = alloc_buf(c->normal_tab, (static_cast<size_t>(total) + 1) * 32))) return rc;  // normals, then per-id areas
   if ((rc = alloc_buf(c->pair_tab, total + 1 <= 64 ? (static_cast<size_t>(total) + 1) * (total + 1) * 4 : 0))) return rc;
   for (int i = 0; i < 2; i++)
     if ((rc = alloc_buf(c->lut[i], (static_cast<size_t>(total) + 1) * sizeof(rtpt_visibility_data)))) return rc;
@@ -871,6 +871,7 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
     for (int i = 0; i < 16; i++) la.model[i] = (i % 5 == 0) ? 1.0f : 0.0f;
     la.lut = static_cast<float4*>(c->lut[c->lut_cur].ptr);
     la.normal_tab = static_cast<float4*>(c->normal_tab.ptr);
+    la.area_tab = la.normal_tab + (c->n_tris + 1);
     la.pair_tab = static_cast<float*>(c->pair_tab.ptr);
     la.sigma_n = c->cfg.sigma_n;
     rt::launch_lut(la, c->stream);
@@ -915,6 +916,7 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
   a.depth = static_cast<float*>(c->depth.ptr);
   a.normals = nullptr;
   a.normal_tab = static_cast<const float4*>(c->normal_tab.ptr);
+  a.area_tab = a.normal_tab + (c->n_tris + 1);
   if (!c->pair_tab.ptr) {  // more than 63 triangles: the filter stages per-pixel normals instead of ids
     if (!c->normals.ptr) {
       int rc2 = alloc_buf(c->normals, c->pixels() * 16);
@@ -1011,6 +1013,7 @@ int rtpt_temporal_gradient(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t 
   a.lut = static_cast<const float4*>(c->lut[c->lut_cur].ptr);
   a.lut_prev = static_cast<const float4*>(c->lut[c->lut_cur ^ 1].ptr);
   a.normal_tab = static_cast<const float4*>(c->normal_tab.ptr);
+  a.area_tab = a.normal_tab + (c->n_tris + 1);
   a.grad = static_cast<float4*>(c->gradient.ptr);
   {
     Timer tm(c, RTPT_K_GRADIENT);

@@ -549,7 +549,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 896), amdgpu_waves_per
       B = C;
       yB = 0;
     }
-    if (ready()) emit(A, B, C);
+    if (ready()) {
+      // a row whose lower tap row is clamped to H-1 has its window complete EARLY (row H-1 arrived before row y + s
+      // would have): it still goes out in the step row y + s belongs to — the double-buffered ring of the next level
+      // has room for G rows per step, and the row that shares its slot (y - 2G) is read until then
+      if (next_y + sl > H - 1) step_to((next_y + sl - src_origin) / G + 1 + lw);
+      emit(A, B, C);
+    }
     // what comes next
     if (!extra && j == H - 1 && next_y == H - 1 && next_y <= hi_out) {
       extra = true;

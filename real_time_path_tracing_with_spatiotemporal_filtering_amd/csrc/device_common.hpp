@@ -20,6 +20,10 @@ __device__ __forceinline__ f3 bary_coords(f3 p, f3 a, f3 b, f3 c) {
   float at = tri_area(a, b, c);
   return f3{tri_area(p, b, c) / at, tri_area(a, p, c) / at, tri_area(a, b, p) / at};
 }
+// the same with the triangle's own area supplied (at == tri_area(a, b, c) bit for bit: a per-triangle table)
+__device__ __forceinline__ f3 bary_coords_at(f3 p, f3 a, f3 b, f3 c, float at) {
+  return f3{tri_area(p, b, c) / at, tri_area(a, p, c) / at, tri_area(a, b, p) / at};
+}
 __device__ __forceinline__ f3 bary_mix(f3 bc, f3 a, f3 b, f3 c) {
   return f3{fmaf_(bc.z, c.x, fmaf_(bc.y, b.x, bc.x * a.x)), fmaf_(bc.z, c.y, fmaf_(bc.y, b.y, bc.x * a.y)),
             fmaf_(bc.z, c.z, fmaf_(bc.y, b.z, bc.x * a.z))};

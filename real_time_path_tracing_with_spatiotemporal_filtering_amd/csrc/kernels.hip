@@ -422,6 +422,7 @@ __global__ void k_lut(LutArgs a) {
     a.lut[0] = a.lut[1] = a.lut[2] = make_float4(0.f, 0.f, 0.f, 0.f);
     f3 n{0.f, 0.f, 1.f};  // temporalFiltering.comp.glsl:83
     a.normal_tab[0] = make_float4(n.x, n.y, n.z, exact::powi(glsl_max(0.0f, exact::dot(n, n)), a.sigma_n));
+    a.area_tab[0] = make_float4(0.f, 0.f, 0.f, 0.f);  // never read: id 0 has no triangle (temporalGradient.comp.glsl:128-131)
   }
   if (t >= a.n_tris) return;
   f3 v[3];
@@ -432,6 +433,7 @@ __global__ void k_lut(LutArgs a) {
   }
   f3 n = exact::normalize(exact::cross(v[1] - v[0], v[2] - v[0]));  // :90
   a.normal_tab[t + 1] = make_float4(n.x, n.y, n.z, exact::powi(glsl_max(0.0f, exact::dot(n, n)), a.sigma_n));
+  a.area_tab[t + 1] = make_float4(tri_area(v[0], v[1], v[2]), 0.f, 0.f, 0.f);  // temporalGradient.comp.glsl:60, once per triangle
 }
 
 // pow(max(0, dot(n_p, n_q)), sigma_n) for every id pair (temporalFiltering.comp.glsl:62), small scenes
@@ -465,13 +467,14 @@ __device__ __forceinline__ f3 phong(f3 p, f3 n, f3 cam, f3 lpos, f3 lcol) {
 // temporalGradient.comp.glsl:128-167 for one pixel: relative change of the Phong shade of the visible surface point between
 // the previous and the current light (and pose)
 __device__ __forceinline__ float gradient_lambda(uint32_t id, f3 wp, const float4* lut, const float4* lut_prev, const float4* normal_tab,
-                                                 f3 cam, f3 light, f3 light_prev, f3 color, f3 color_prev) {
+                                                 const float4* area_tab, f3 cam, f3 light, f3 light_prev, f3 color, f3 color_prev) {
   if (id == 0) return 0.0f;  // :128-131
   f3 va = xyz(lut[3 * id]), vb = xyz(lut[3 * id + 1]), vc = xyz(lut[3 * id + 2]);
   // :142 normalize(cross(vb - va, vc - va)) — k_lut computed exactly that from exactly these vertices, once per triangle
   // (normal_tab[id]); per pixel it is 36 VALU of a VALU-bound kernel
   f3 nrm = xyz(normal_tab[id]);
-  f3 bc = bary_coords(wp, va, vb, vc);                        // :143
+  // :143; the whole triangle's area (:60) comes from k_lut's table: same vertices, same arithmetic, once per triangle
+  f3 bc = bary_coords_at(wp, va, vb, vc, area_tab[id].x);
   f3 pa = xyz(lut_prev[3 * id]), pb = xyz(lut_prev[3 * id + 1]), pc = xyz(lut_prev[3 * id + 2]);
   f3 wpp = bary_mix(bc, pa, pb, pc);                          // :153
   f3 cur = phong(wp, nrm, cam, light, color);                 // :158
@@ -521,11 +524,12 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
   const size_t i = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
   a.vis[i] = h.id1;  // visibility.frag.glsl:23
   if (a.normals) a.normals[i] = a.normal_tab[h.id1];
+  f3 wp{0.f, 0.f, 0.f};
   if (h.id1) {
     float b1 = -h.u / h.ad, b2 = h.v / h.ad;
     float b0 = 1.0f - b1 - b2;
     const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
-    f3 wp = bary_point(xyz(s[0]), xyz(s[1]), xyz(s[2]), b0, b1, b2);
+    wp = bary_point(xyz(s[0]), xyz(s[1]), xyz(s[2]), b0, b1, b2);
     a.worldpos[i] = make_float4(wp.x, wp.y, wp.z, 1.0f);
     float cz = exact::mat_row_point(a.PV, 2, wp), cw = exact::mat_row_point(a.PV, 3, wp);
     a.depth[i] = cz / cw;
@@ -534,15 +538,10 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
     a.depth[i] = 1.0f;                                  // clear depth  main.cpp:1421
   }
   if (a.grad_on && y >= a.grad_y0 && y < a.grad_y1) {
-    // K1 (temporalGradient.comp.glsl:104-172) on the values K0 just stored — the same bits it would load back
-    f3 wp{0.f, 0.f, 0.f};
-    if (h.id1) {
-      float b1 = -h.u / h.ad, b2 = h.v / h.ad;
-      float b0 = 1.0f - b1 - b2;
-      const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
-      wp = bary_point(xyz(s[0]), xyz(s[1]), xyz(s[2]), b0, b1, b2);
-    }
-    store_gradient(a.grad, i, gradient_lambda(h.id1, wp, a.lut, a.lut_prev, a.normal_tab, ld3(a.g_cam), ld3(a.g_light), ld3(a.g_light_prev),
+    // K1 (temporalGradient.comp.glsl:104-172) on the values K0 just stored — the same bits it would load back (the world
+    // position is computed ONCE: the stores above may alias the vertex records as far as the compiler knows, so a
+    // second evaluation was a second evaluation)
+    store_gradient(a.grad, i, gradient_lambda(h.id1, wp, a.lut, a.lut_prev, a.normal_tab, a.area_tab, ld3(a.g_cam), ld3(a.g_light), ld3(a.g_light_prev),
                                               ld3(a.g_color), ld3(a.g_color_prev)));
   }
 }
@@ -554,7 +553,7 @@ __global__ __launch_bounds__(kThreads) void k_gradient(GradientArgs a) {
   const size_t i = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
   const uint32_t id = a.vis[i];
   const f3 wp = id ? xyz(a.worldpos[i]) : f3{0.f, 0.f, 0.f};
-  store_gradient(a.grad, i, gradient_lambda(id, wp, a.lut, a.lut_prev, a.normal_tab, ld3(a.cam), ld3(a.light), ld3(a.light_prev), ld3(a.color),
+  store_gradient(a.grad, i, gradient_lambda(id, wp, a.lut, a.lut_prev, a.normal_tab, a.area_tab, ld3(a.cam), ld3(a.light), ld3(a.light_prev), ld3(a.color),
                                             ld3(a.color_prev)));
 }
 

@@ -63,6 +63,7 @@ struct GbufferArgs {
   float* depth;
   float4* normals;            // nullable: per-pixel normal_tab[id] for the LDS-staged filter of large scenes
   const float4* normal_tab;   // per-id (n.xyz, self weight), built by k_lut
+  const float4* area_tab;     // per-id (area of LUT[id], 0, 0, 0), built by k_lut (K1 in the same launch)
   int32_t cull;                      // 1: bounds[] is valid
   // K1 in the same launch (rtpt_temporal_gradient arrived right behind rtpt_gbuffer): the pixel's id and world position
   // are still in registers, so the gradient costs its 16 B/px store and none of its 20 B/px of loads
@@ -81,6 +82,8 @@ struct LutArgs {
   float model[16];
   float4* lut;          // (n+1) x 3 float4 (stride 48 B)
   float4* normal_tab;   // (n+1) float4: xyz = unit normal of LUT[id] (id 0: (0,0,1)), w = self weight
+  float4* area_tab;     // (n+1) float4: x = tri_area(LUT[id]) — the denominator of the area-ratio barycentrics
+                        // (temporalGradient.comp.glsl:60), a per-triangle value K1 used to recompute per pixel
   float* pair_tab;      // (n+1)^2 pow(max(0,dot(n_p,n_q)),sigma_n), NULL when n+1 > 64
   int32_t sigma_n;
 };
@@ -93,6 +96,7 @@ struct GradientArgs {
   const float4* lut;
   const float4* lut_prev;
   const float4* normal_tab;  // per-id normals of the current LUT (k_lut)
+  const float4* area_tab;    // per-id triangle areas of the current LUT (k_lut)
   float4* grad;
 };
 
