@@ -371,6 +371,13 @@ int rtpt_util_load_obj_materials(const char* path, uint32_t* tri_material, uint3
  *   [4] triangles not referenced exactly once, [5] boxes that do not contain their subtree,
  *   [6] device (16-bit grid) boxes that do not contain the binary32 box, [7] dangling child references */
 int rtpt_util_bvh_check(const float* tris, uint32_t n_tris, uint64_t stats[8]);
+/* The structure as it stands ON THE DEVICE of a context — after rtpt_scene_upload, or after a changed ubo->model re-posed
+ * the scene and refit the tree inside rtpt_gbuffer (on the device, on the context's stream, without a host
+ * synchronisation: refit.hip) — read back and checked on the host (blocks).
+ *   stats[0] nodes, [1] leaves, [2] deepest level, [3] largest leaf, [4] triangles not referenced exactly once,
+ *   [5] decoded device boxes that do not contain every vertex below them, [6] boxes reaching beyond the padded scene,
+ *   [7] dangling child references */
+int rtpt_debug_bvh_check(rtpt_ctx* ctx, uint64_t stats[8]);
 /* the same invariants after a REFIT: the tree is built over `built_for` and refit to `moved` (the same n_tris
  * triangles after an animated model matrix, rtpt_gbuffer) — topology and leaf order kept, boxes recomputed */
 int rtpt_util_bvh_refit_check(const float* built_for, const float* moved, uint32_t n_tris, uint64_t stats[8]);

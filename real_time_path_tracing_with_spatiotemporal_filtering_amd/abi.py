@@ -95,7 +95,7 @@ SYMBOLS = [
     "rtpt_reset_counters", "rtpt_set_count_rows", "rtpt_enable_debug", "rtpt_timing_enable", "rtpt_timing_collect", "rtpt_kernel_name",
     "rtpt_selftest_math", "rtpt_selftest_trace", "rtpt_util_look_at", "rtpt_util_perspective", "rtpt_util_load_obj", "rtpt_util_bvh_check",
     "rtpt_scene_set_materials", "rtpt_util_load_obj_materials", "rtpt_util_bvh_refit_check", "rtpt_set_external_guides",
-    "rtpt_present",
+    "rtpt_present", "rtpt_debug_bvh_check",
 ]
 
 _lib = None
@@ -149,6 +149,7 @@ def load() -> C.CDLL:
         "rtpt_util_bvh_check": [vp, u32, C.POINTER(C.c_uint64 * 8)],
         "rtpt_scene_set_materials": [vp, vp, u32, vp, u32],
         "rtpt_util_bvh_refit_check": [vp, vp, u32, C.POINTER(C.c_uint64 * 8)],
+        "rtpt_debug_bvh_check": [vp, C.POINTER(C.c_uint64 * 8)],
         "rtpt_util_load_obj_materials": [C.c_char_p, vp, C.POINTER(u32), vp, C.POINTER(u32)],
     }
     for name, args in sigs.items():
@@ -341,6 +342,13 @@ class Context:
 
     def sync(self):
         _check(self._lib.rtpt_sync(self._h))
+
+    def debug_bvh_check(self):
+        """the acceleration structure as it stands on the device (after an upload or a device-side refit), checked on the host"""
+        st = (C.c_uint64 * 8)()
+        _check(self._lib.rtpt_debug_bvh_check(self._h, C.byref(st)))
+        return dict(zip(("nodes", "leaves", "depth", "largest_leaf", "bad_refs_to_triangles", "boxes_not_containing", "boxes_beyond_scene",
+                         "dangling"), (int(v) for v in st)))
 
     # -- data movement
     def readback(self, which: int) -> np.ndarray:

@@ -81,6 +81,12 @@ struct rtpt_ctx {
   // scene
   uint32_t n_tris = 0;
   Buf tris, leaf_order, isect_id, isect_leaf, shade, nodes;
+  // device-side re-pose + refit (refit.hip): the uploaded (un-posed) triangles, the nodes sorted by height, the scratch
+  // boxes and the grid the traversal reads.  BVH scenes only; small brute-force scenes keep host_tris for the screen bounds
+  Buf obj_tris_dev, refit_order, refit_fbox, bvh_grid_dev;
+  std::vector<uint32_t> refit_level_first;  // slice of refit_order per height (levels + 1 entries)
+  uint32_t n_nodes = 0;
+  bool host_refit = false;  // RTPT_HOST_REFIT=1: round 2's host path for every scene (A/B)
   bool use_bvh = false;
   rt::BvhGrid bvh_grid{};
   int bvh_depth = 0;
@@ -300,10 +306,7 @@ rt::SceneView scene_view(const rtpt_ctx* c) {
   s.leaf_ids = static_cast<const uint32_t*>(c->leaf_order.ptr);
   s.shade = static_cast<const float4*>(c->shade.ptr);
   s.nodes = static_cast<const rt::BvhNodeQ*>(c->nodes.ptr);
-  for (int a = 0; a < 3; a++) {
-    s.bvh_origin[a] = c->bvh_grid.origin[a];
-    s.bvh_cell[a] = c->bvh_grid.cell[a];
-  }
+  s.bvh_grid = static_cast<const float*>(c->bvh_grid_dev.ptr);
   s.n_tris = c->n_tris;
   s.use_bvh = c->use_bvh ? 1u : 0u;
   s.paired = (c->tris_paired && !c->no_pairing) ? 1u : 0u;
@@ -501,6 +504,7 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   c->count_y1 = static_cast<int>(cfg->row_end);
   // tuning knobs for A/B runs on the box (never needed for correctness: every setting computes the same pixels)
   if (const char* v = std::getenv("RTPT_NO_TRI_PAIRS")) c->no_pairing = std::atoi(v) != 0;
+  if (const char* v = std::getenv("RTPT_HOST_REFIT")) c->host_refit = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_CHAIN_MAX")) c->chain_max = std::max(1, std::min(3, std::atoi(v)));
   if (const char* v = std::getenv("RTPT_CHAIN_FINAL")) c->chain_final = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_BVH_STACK_LDS")) c->bvh_stack_lds = std::max(1, std::atoi(v));
@@ -533,7 +537,8 @@ int rtpt_destroy(rtpt_ctx* c) {
   for (auto& b : c->variance) free_buf(b);
   for (auto& b : c->lut) free_buf(b);
   for (Buf* b : {&c->worldpos, &c->gradient, &c->depth, &c->prev_pixel, &c->hit_id, &c->raycount, &c->normal_tab, &c->pair_tab, &c->tris,
-                 &c->leaf_order, &c->isect_id, &c->isect_leaf, &c->shade, &c->nodes, &c->materials})
+                 &c->leaf_order, &c->isect_id, &c->isect_leaf, &c->shade, &c->nodes, &c->materials, &c->obj_tris_dev, &c->refit_order,
+                 &c->refit_fbox, &c->bvh_grid_dev})
     free_buf(*b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -724,6 +729,38 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   HIP_TRY(hipMemcpyAsync(c->tris.ptr, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->leaf_order.ptr, bvh.leaf_order.data(), static_cast<size_t>(total) * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->nodes.ptr, nodes_h.data(), nodes_h.size() * sizeof(rt::BvhNodeQ), hipMemcpyHostToDevice, c->stream));
+  // the grid of the node boxes, read by the traversal from device memory (a device-side refit rewrites it)
+  if ((rc = alloc_buf(c->bvh_grid_dev, 8 * sizeof(float)))) return rc;
+  const float grid_h[8] = {c->bvh_grid.origin[0], c->bvh_grid.origin[1], c->bvh_grid.origin[2], c->bvh_grid.cell[0],
+                           c->bvh_grid.cell[1], c->bvh_grid.cell[2], 0.f, 0.f};
+  HIP_TRY(hipMemcpyAsync(c->bvh_grid_dev.ptr, grid_h, sizeof grid_h, hipMemcpyHostToDevice, c->stream));
+  // device-side refit tables: nodes by HEIGHT (a node after both of its subtrees), the un-posed triangles, scratch boxes
+  std::vector<uint32_t> order_h;
+  c->refit_level_first.clear();
+  c->n_nodes = static_cast<uint32_t>(nodes_h.size());
+  {
+    const size_t nn = nodes_h.size();
+    std::vector<int> height(nn, 0);
+    int maxh = 0;
+    for (size_t ii = nn; ii-- > 0;) {  // pre-order numbering: children carry larger indices than their parent
+      int hgt = 0;
+      for (uint32_t ref : {nodes_h[ii].lref, nodes_h[ii].rref})
+        if (ref != rt::kBvhEmpty && !(ref & 0x80000000u) && ref < nn) hgt = std::max(hgt, height[ref] + 1);
+      height[ii] = hgt;
+      maxh = std::max(maxh, hgt);
+    }
+    c->refit_level_first.assign(static_cast<size_t>(maxh) + 2, 0);
+    for (size_t ii = 0; ii < nn; ii++) c->refit_level_first[static_cast<size_t>(height[ii]) + 1]++;
+    for (size_t h = 1; h < c->refit_level_first.size(); h++) c->refit_level_first[h] += c->refit_level_first[h - 1];
+    order_h.resize(nn);
+    std::vector<uint32_t> fill(c->refit_level_first.begin(), c->refit_level_first.end() - 1);
+    for (size_t ii = 0; ii < nn; ii++) order_h[fill[static_cast<size_t>(height[ii])]++] = static_cast<uint32_t>(ii);
+  }
+  if ((rc = alloc_buf(c->obj_tris_dev, tris.size() * sizeof(float)))) return rc;
+  if ((rc = alloc_buf(c->refit_order, order_h.size() * 4))) return rc;
+  if ((rc = alloc_buf(c->refit_fbox, order_h.size() * 12 * sizeof(float)))) return rc;
+  HIP_TRY(hipMemcpyAsync(c->obj_tris_dev.ptr, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->refit_order.ptr, order_h.data(), order_h.size() * 4, hipMemcpyHostToDevice, c->stream));
   for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(c->lut[i].ptr, 0, c->lut[i].bytes, c->stream));
   rt::ScenePrepArgs sp;
   sp.n_tris = total;
@@ -773,8 +810,49 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
 // triangles, the device records are rebuilt.  Every pass — K0, K2, the LUT — sees the posed geometry.
 static int apply_model(rtpt_ctx* c, const float* model) {
   const uint32_t total = c->n_tris;
-  std::vector<float> tris(static_cast<size_t>(total) * 9);
   const bool ident = is_identity(model);
+  if (c->use_bvh && !c->host_refit && c->obj_tris_dev.ptr && c->refit_order.ptr) {
+    // everything on the device and on the context's stream: no upload, no synchronisation (refit.hip)
+    rt::RefitModel rm;
+    std::memcpy(rm.m, model, sizeof rm.m);
+    rm.identity = ident ? 1 : 0;
+    rt::launch_pose(total * 3, static_cast<const float*>(c->obj_tris_dev.ptr), static_cast<float*>(c->tris.ptr), rm, c->stream);
+    rt::RefitArgs ra;
+    ra.tris = static_cast<const float*>(c->tris.ptr);
+    ra.leaf_order = static_cast<const uint32_t*>(c->leaf_order.ptr);
+    ra.order = static_cast<const uint32_t*>(c->refit_order.ptr);
+    ra.nodes = static_cast<rt::BvhNodeQ*>(c->nodes.ptr);
+    ra.fbox = static_cast<float*>(c->refit_fbox.ptr);
+    ra.grid = static_cast<float*>(c->bvh_grid_dev.ptr);
+    rt::launch_refit(ra, c->refit_level_first.data(), static_cast<int>(c->refit_level_first.size()) - 1, c->n_nodes, 1e-5f, c->stream);
+    rt::ScenePrepArgs sp;
+    sp.n_tris = total;
+    sp.tris = static_cast<const float*>(c->tris.ptr);
+    sp.leaf_order = static_cast<const uint32_t*>(c->leaf_order.ptr);
+    sp.isect_id = static_cast<float4*>(c->isect_id.ptr);
+    sp.isect_leaf = static_cast<float4*>(c->isect_leaf.ptr);
+    sp.shade = static_cast<float4*>(c->shade.ptr);
+    rt::launch_scene_prepare(sp, c->stream);
+    int rcd = launch_check("device refit");
+    if (rcd) return rcd;
+    if (total <= static_cast<uint32_t>(rt::kCullMaxTris)) {
+      // a small scene forced onto the BVH path: the screen bounds (unused while it is) still follow the pose
+      c->host_tris.resize(static_cast<size_t>(total) * 9);
+      for (size_t v = 0; v < static_cast<size_t>(total) * 3; v++) {
+        const float* p = c->obj_tris.data() + 3 * v;
+        const rt::f3 q{p[0], p[1], p[2]};
+        float* o = c->host_tris.data() + 3 * v;
+        o[0] = ident ? p[0] : rt::exact::mat_row_point(model, 0, q);
+        o[1] = ident ? p[1] : rt::exact::mat_row_point(model, 1, q);
+        o[2] = ident ? p[2] : rt::exact::mat_row_point(model, 2, q);
+      }
+    }
+    std::memcpy(c->model, model, sizeof c->model);
+    c->model_version++;
+    c->tables_valid = false;
+    return RTPT_OK;
+  }
+  std::vector<float> tris(static_cast<size_t>(total) * 9);
   for (size_t v = 0; v < static_cast<size_t>(total) * 3; v++) {
     const float* p = c->obj_tris.data() + 3 * v;
     float* o = tris.data() + 3 * v;
@@ -793,6 +871,9 @@ static int apply_model(rtpt_ctx* c, const float* model) {
   if (nodes_h.size() * sizeof(rt::BvhNodeQ) != c->nodes.bytes) return fail(RTPT_E_INVALID, "internal: refit changed the node count");
   HIP_TRY(hipMemcpyAsync(c->tris.ptr, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->nodes.ptr, nodes_h.data(), nodes_h.size() * sizeof(rt::BvhNodeQ), hipMemcpyHostToDevice, c->stream));
+  const float grid_h[8] = {c->bvh_grid.origin[0], c->bvh_grid.origin[1], c->bvh_grid.origin[2], c->bvh_grid.cell[0],
+                           c->bvh_grid.cell[1], c->bvh_grid.cell[2], 0.f, 0.f};
+  HIP_TRY(hipMemcpyAsync(c->bvh_grid_dev.ptr, grid_h, sizeof grid_h, hipMemcpyHostToDevice, c->stream));
   rt::ScenePrepArgs sp;
   sp.n_tris = total;
   sp.tris = static_cast<const float*>(c->tris.ptr);
@@ -1622,6 +1703,117 @@ void rtpt_util_perspective(float fovy, float aspect, float zn, float zf, float m
   m[10] = zf / (zn - zf);
   m[11] = -1.0f;
   m[14] = -(zf * zn) / (zf - zn);
+}
+
+// The acceleration structure AS IT STANDS ON THE DEVICE (after rtpt_scene_upload, or after a model matrix re-posed and
+// refit it inside rtpt_gbuffer): nodes, grid, posed triangles and leaf order are read back and checked on the host.
+//   stats[0] nodes, [1] leaves, [2] deepest level, [3] largest leaf, [4] triangles not referenced exactly once,
+//   [5] decoded (origin + q * cell, binary32) child boxes that do not contain every vertex below them,
+//   [6] child boxes wider than the padded scene (a box that was never rewritten), [7] dangling references
+int rtpt_debug_bvh_check(rtpt_ctx* c, uint64_t stats[8]) {
+  if (!c || !stats) return fail(RTPT_E_INVALID, "NULL argument");
+  if (!c->n_tris || !c->nodes.ptr) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");
+  HIP_TRY(hipSetDevice(c->device));
+  FLUSH_FILTER(c);
+  const uint32_t n = c->n_tris, nn = c->n_nodes;
+  std::vector<rt::BvhNodeQ> q(nn);
+  std::vector<float> tris(static_cast<size_t>(n) * 9);
+  std::vector<uint32_t> leaf(n);
+  float g[8];
+  HIP_TRY(hipMemcpyAsync(q.data(), c->nodes.ptr, q.size() * sizeof(rt::BvhNodeQ), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(tris.data(), c->tris.ptr, tris.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(leaf.data(), c->leaf_order.ptr, leaf.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(g, c->bvh_grid_dev.ptr, sizeof g, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 8; i++) stats[i] = 0;
+  stats[0] = nn;
+  std::vector<uint32_t> seen(n, 0);
+  for (uint32_t id : leaf) {
+    if (id >= n)
+      stats[4]++;
+    else
+      seen[id]++;
+  }
+  for (uint32_t i = 0; i < n; i++)
+    if (seen[i] != 1) stats[4]++;
+  struct Bounds { float mn[3], mx[3]; };
+  std::vector<Bounds> sub(nn);
+  std::vector<uint8_t> done(nn, 0);
+  std::vector<std::pair<uint32_t, uint32_t>> st{{0u, 0u}};  // node, level
+  while (!st.empty()) {
+    const uint32_t ni = st.back().first, lvl = st.back().second;
+    stats[2] = std::max<uint64_t>(stats[2], lvl);
+    const rt::BvhNodeQ& nd = q[ni];
+    bool ready = true;
+    for (uint32_t ref : {nd.lref, nd.rref}) {
+      if (ref == rt::kBvhEmpty || (ref & 0x80000000u)) continue;
+      if (ref >= nn || ref <= ni) {  // pre-order: a child comes after its parent
+        stats[7]++;
+        continue;
+      }
+      if (!done[ref]) {
+        st.push_back({ref, lvl + 1});
+        ready = false;
+      }
+    }
+    if (!ready) continue;
+    st.pop_back();
+    Bounds me{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+    for (int side = 0; side < 2; side++) {
+      const uint32_t ref = side ? nd.rref : nd.lref;
+      if (ref == rt::kBvhEmpty) continue;
+      Bounds cb{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+      if (ref & 0x80000000u) {
+        const uint32_t first = (ref & 0x7FFFFFFFu) >> 2, cnt = (ref & 3u) + 1u;
+        stats[1]++;
+        stats[3] = std::max<uint64_t>(stats[3], cnt);
+        if (static_cast<uint64_t>(first) + cnt > n) {
+          stats[7]++;
+          continue;
+        }
+        for (uint32_t j = 0; j < cnt; j++)
+          for (int v = 0; v < 3; v++)
+            for (int a = 0; a < 3; a++) {
+              const float x = tris[9 * static_cast<size_t>(leaf[first + j]) + 3 * v + a];
+              cb.mn[a] = std::min(cb.mn[a], x);
+              cb.mx[a] = std::max(cb.mx[a], x);
+            }
+      } else {
+        if (ref >= nn || !done[ref]) continue;
+        cb = sub[ref];
+      }
+      for (int a = 0; a < 3; a++) {
+        const float qlo = g[a] + static_cast<float>(nd.box[(side ? 6 : 0) + a]) * g[3 + a];
+        const float qhi = g[a] + static_cast<float>(nd.box[(side ? 9 : 3) + a]) * g[3 + a];
+        if (!(qlo <= cb.mn[a] && qhi >= cb.mx[a])) stats[5]++;
+        me.mn[a] = std::min(me.mn[a], cb.mn[a]);
+        me.mx[a] = std::max(me.mx[a], cb.mx[a]);
+      }
+    }
+    sub[ni] = me;
+    done[ni] = 1;
+  }
+  // no child box may be wider than the root's: the grid spans the padded scene plus one cell at either end
+  if (nn) {
+    const Bounds& sc = sub[0];
+    float diag = 0.f, mag = 0.f;
+    for (int a = 0; a < 3; a++) {
+      diag += (sc.mx[a] - sc.mn[a]) * (sc.mx[a] - sc.mn[a]);
+      mag = std::max(mag, std::max(std::fabs(sc.mn[a]), std::fabs(sc.mx[a])));
+    }
+    const float pad = 1e-5f * std::max(std::sqrt(diag), mag);  // bvh.cpp / refit.hip: the padding of every box
+    for (uint32_t ni = 0; ni < nn; ni++)
+      for (int side = 0; side < 2; side++) {
+        if ((side ? q[ni].rref : q[ni].lref) == rt::kBvhEmpty) continue;
+        for (int a = 0; a < 3; a++) {
+          const float slack = 4.0f * g[3 + a] + 2.0f * pad;
+          const float qlo = g[a] + static_cast<float>(q[ni].box[(side ? 6 : 0) + a]) * g[3 + a];
+          const float qhi = g[a] + static_cast<float>(q[ni].box[(side ? 9 : 3) + a]) * g[3 + a];
+          if (qlo < sc.mn[a] - slack || qhi > sc.mx[a] + slack) stats[6]++;
+        }
+      }
+  }
+  return RTPT_OK;
 }
 
 static int bvh_check_impl(const float* build_tris, const float* tris, uint32_t n, uint64_t stats[8]) {

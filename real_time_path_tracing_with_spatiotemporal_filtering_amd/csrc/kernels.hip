@@ -258,8 +258,12 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
   auto nz = [](float v) { return __builtin_fabsf(v) < 1e-20f ? __builtin_copysignf(1e-20f, v) : v; };
   const f3 rd{fast::rcp_(nz(d.x)), fast::rcp_(nz(d.y)), fast::rcp_(nz(d.z))};
   // x = origin + q * cell  =>  t = (x - o) / d = q * (cell / d) + (origin - o) / d
-  const f3 inv{sc.bvh_cell[0] * rd.x, sc.bvh_cell[1] * rd.y, sc.bvh_cell[2] * rd.z};
-  const f3 oi{(sc.bvh_origin[0] - o.x) * rd.x, (sc.bvh_origin[1] - o.y) * rd.y, (sc.bvh_origin[2] - o.z) * rd.z};
+  // the grid lives in device memory (a device-side refit rewrites it without the host knowing the numbers): six scalar
+  // loads through the constant address space
+  using cflt = const __attribute__((address_space(4))) float;
+  cflt* gr = (cflt*)sc.bvh_grid;
+  const f3 inv{gr[3] * rd.x, gr[4] * rd.y, gr[5] * rd.z};
+  const f3 oi{(gr[0] - o.x) * rd.x, (gr[1] - o.y) * rd.y, (gr[2] - o.z) * rd.z};
   int sp = 0;
   uint32_t cur = 0;  // root pair
   // entries [0, stack_lds) in LDS, the rest in global memory (SceneView::stack_spill)

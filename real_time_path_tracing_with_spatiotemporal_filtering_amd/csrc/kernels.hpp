@@ -18,7 +18,7 @@ struct SceneView {
   const uint32_t* leaf_ids;  // triangle id of each leaf slot
   const float4* shade;       // id order
   const BvhNodeQ* nodes;     // 32-byte child-pair nodes, boxes on a 16-bit grid (bvh.hpp)
-  float bvh_origin[3], bvh_cell[3];
+  const float* bvh_grid;  // device: origin xyz, cell xyz of the nodes' 16-bit grid (rewritten by a device-side refit)
   uint32_t n_tris;
   uint32_t use_bvh;  // 0: brute force over isect_id, 1: BVH traversal
   uint32_t paired;   // brute force only: triangles (2q, 2q+1) share v0 and the edge v2_A == v1_B bitwise (fan-triangulated faces)
@@ -228,6 +228,23 @@ struct ScenePrepArgs {
 };
 
 void launch_scene_prepare(const ScenePrepArgs& a, hipStream_t s);
+
+// device-side re-pose + BVH refit (refit.hip)
+struct RefitModel {
+  float m[16];       // column-major model matrix (rtpt_ubo::model)
+  int32_t identity;  // 1: copy the vertices
+};
+struct RefitArgs {
+  const float* tris;           // posed triangles, n x 9
+  const uint32_t* leaf_order;  // leaf slot -> triangle id
+  const uint32_t* order;       // node indices sorted by height (children before parents)
+  BvhNodeQ* nodes;             // device nodes: references are read, boxes rewritten
+  float* fbox;                 // n_nodes x 12 floats: unpadded binary32 child boxes (scratch)
+  float* grid;                 // 8 floats: origin xyz, cell xyz, pad, 0
+};
+void launch_pose(uint32_t n_verts, const float* src, float* dst, const RefitModel& m, hipStream_t s);
+// level_first[h] .. level_first[h + 1]: the slice of `order` holding the nodes of height h (n_levels + 1 entries)
+void launch_refit(const RefitArgs& a, const uint32_t* level_first, int n_levels, uint32_t n_nodes, float pad_rel, hipStream_t s);
 // gather isect records into class order: out[t] = isect_id[ids[t]] (3 float4 each), n entries
 void launch_lut(const LutArgs& a, hipStream_t s);
 void launch_gbuffer(const GbufferArgs& a, hipStream_t s);
