@@ -412,6 +412,20 @@ def main():
                          if at.get("replaced_pass_bytes") and at.get("avg_us") else None},
             "kernels": kr,
         }
+        if wl.get("instanced"):
+            # north_star: "L2-hit/occupancy on the traversal kernel": a committed PMC measurement (profiles/traversal.json,
+            # scripts/pmc_traversal.sh; counters cannot be collected inside this run), named by the commit it was taken at
+            try:
+                tv = json.load(open(os.path.join(ROOT, "profiles", "traversal.json")))
+                kp = tv.get("k_pathtrace", {})
+                result["traversal"] = {"kernel": "k_pathtrace<BVH> (tile kernel + queue windows)",
+                                       "l2_hit_rate": round(kp.get("l2_hit_rate", 0), 4),
+                                       "occupancy_waves_per_simd": round(kp.get("waves_per_simd", 0), 2), "occupancy_max": 8,
+                                       "valu_busy": round(kp.get("valu_busy", 0), 3),
+                                       "lane_utilisation": round(kp.get("lane_utilisation", 0), 3),
+                                       "source": "profiles/traversal.json @ " + str(tv.get("_source"))}
+            except Exception:
+                result["traversal"] = None
         pt = kr.get("k_pathtrace")
         if pt:
             result["pathtrace_kernel_mray_s"] = round(rays / args.steps / (pt["avg_us"] * 1e-6) / 1e6, 1)
