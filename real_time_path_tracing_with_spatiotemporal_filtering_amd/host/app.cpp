@@ -78,7 +78,9 @@ void PathTracingApplication::createBuffers() {
     // one strip context per rank this process runs; all on one stream, which is also the stream the transport's
     // messages are ordered on (RCCL point-to-point calls or device-to-device copies)
     if (opt_.frames_in_flight != 1) throw std::runtime_error("strips run one frame in flight");
-    if (opt_.flags & 0x1F0u) throw std::runtime_error("the extension modes are not served on strips by this host");
+    if ((opt_.flags & RTPT_FLAG_EXT_VARIANCE) && opt_.exchange_halo)
+      throw std::runtime_error("RTPT_FLAG_EXT_VARIANCE on strips needs the redundant halo mode (every stored row is traced, so its "
+                               "moments exist; the exchange mode would have to ship variance and moment halos per iteration)");
     const bool local = opt_.rank < 0;
     if (!local && opt_.rank >= opt_.ranks) throw std::runtime_error("rank out of range");
     int dev = opt_.device;
@@ -103,6 +105,7 @@ void PathTracingApplication::createBuffers() {
       rs.plan.rank = r;
       rs.plan.iterations = opt_.maxWaveletIteration;
       rs.plan.exchange = opt_.exchange_halo;
+      rs.plan.ext_flags = opt_.flags & 0x1F0u;
       const Rows st = rs.plan.stored(), own = rs.plan.own();
       cfg.row_begin = static_cast<uint32_t>(st.first);
       cfg.row_end = static_cast<uint32_t>(st.second);
@@ -301,9 +304,68 @@ void PathTracingApplication::prepareHistory() {
   }
 }
 
+// One plane of the previous frame, gathered where the ranks' pixels can reach it: rank r holds rows needs[r] of `plane`
+// in its full-frame buffer RankState::*dst afterwards (its own rows by a device copy, the others' through the transport)
+void PathTracingApplication::exchangeBands(const std::vector<Rows>& needs, rtpt_plane plane, size_t px_bytes, void* RankState::*dst) {
+  const int H = static_cast<int>(opt_.height);
+  const size_t row_bytes = static_cast<size_t>(opt_.width) * px_bytes;
+  const auto table = history_exchange_plan(H, opt_.ranks, needs);
+  transport_->begin(stream_);
+  for (auto& rs : ranks_) {
+    if (!(rs.*dst)) rs.*dst = host_device_alloc(static_cast<size_t>(H) * row_bytes);
+    void* src = nullptr;
+    check(rtpt_plane_ptr(rs.ctx, plane, &src), "rtpt_plane_ptr");
+    const int row0 = rs.plan.stored().first;
+    auto src_rows = [&](int y) { return static_cast<char*>(src) + static_cast<size_t>(y - row0) * row_bytes; };
+    auto dst_rows = [&](int y) { return static_cast<char*>(rs.*dst) + static_cast<size_t>(y) * row_bytes; };
+    // what this rank owns of what it needs; everything else comes from its owner (strips.py: exchange_history)
+    const Rows own = rs.plan.own(), need = needs[static_cast<size_t>(rs.plan.rank)];
+    const int a = std::max(own.first, need.first), b = std::min(own.second, need.second);
+    if (b > a) host_device_copy(dst_rows(a), src_rows(a), static_cast<size_t>(b - a) * row_bytes, stream_);
+    for (const auto& op : table[static_cast<size_t>(rs.plan.rank)]) {
+      const size_t bytes = static_cast<size_t>(op.rows.second - op.rows.first) * row_bytes;
+      if (op.send)
+        transport_->send(rs.plan.rank, src_rows(op.rows.first), op.peer, bytes);
+      else
+        transport_->recv(rs.plan.rank, dst_rows(op.rows.first), op.peer, bytes);
+    }
+  }
+  transport_->end();
+}
+
+// RTPT_FLAG_EXT_VARIANCE / _DISOCCLUSION on strips: the moment accumulation (before iteration 1) and the disocclusion test
+// (final pass) read the PREVIOUS frame's id and moment planes at reprojected pixels.  Every rank holds them for its stored
+// rows; when the camera (or the model) moved, the rows a rank's stored pixels can reach beyond that are gathered from their
+// owners — the history image's bound and plan — into buffers registered with rtpt_set_external_guides.
+void PathTracingApplication::prepareGuides() {
+  if (frameCount == 0 || cameraStatic()) {
+    for (auto& rs : ranks_) check(rtpt_set_external_guides(rs.ctx, nullptr, nullptr, 0, 0), "rtpt_set_external_guides");
+    return;
+  }
+  const int H = static_cast<int>(opt_.height);
+  const bool variance = (opt_.flags & RTPT_FLAG_EXT_VARIANCE) != 0;
+  std::vector<Rows> needs;
+  for (int r = 0; r < opt_.ranks; r++) {
+    StripPlan p = ranks_[0].plan;
+    p.rank = r;
+    needs.push_back(reprojection_rows(ubo, static_cast<int>(opt_.width), H, p.stored(), sceneMin_, sceneMax_, 0.1f));
+  }
+  exchangeBands(needs, RTPT_PLANE_PREV_VIS_ID, 4, &RankState::guide_ids);
+  if (variance) exchangeBands(needs, RTPT_PLANE_MOMENTS_PREV, 16, &RankState::guide_moments);
+  for (auto& rs : ranks_) {
+    const Rows need = needs[static_cast<size_t>(rs.plan.rank)];
+    const size_t W = opt_.width;
+    check(rtpt_set_external_guides(rs.ctx, static_cast<char*>(rs.guide_ids) + static_cast<size_t>(need.first) * W * 4,
+                                   variance ? static_cast<char*>(rs.guide_moments) + static_cast<size_t>(need.first) * W * 16 : nullptr,
+                                   static_cast<uint32_t>(need.first), static_cast<uint32_t>(need.second)),
+          "rtpt_set_external_guides");
+  }
+}
+
 void PathTracingApplication::applyTemporalFiltering() {
   pushConstants.maxWaveletIteration = opt_.maxWaveletIteration;   // :1258
   if (multi()) {
+    if (opt_.flags & (RTPT_FLAG_EXT_VARIANCE | RTPT_FLAG_EXT_DISOCCLUSION)) prepareGuides();
     for (int k = 1; k <= opt_.maxWaveletIteration; k++) {         // :1259
       pushConstants.waveletIteration = k;                         // :1260
       if (opt_.exchange_halo) exchangeHalo(k);
@@ -434,6 +496,8 @@ void PathTracingApplication::freeRessources() {
   for (auto& rs : ranks_) {
     if (rs.ctx) rtpt_destroy(rs.ctx);
     if (rs.history) host_device_free(rs.history);
+    if (rs.guide_ids) host_device_free(rs.guide_ids);
+    if (rs.guide_moments) host_device_free(rs.guide_moments);
     for (void*& p : rs.swap) {
       if (p) host_device_free(p);
       p = nullptr;

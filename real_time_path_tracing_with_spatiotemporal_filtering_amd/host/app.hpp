@@ -92,6 +92,8 @@ class PathTracingApplication {
     StripPlan plan;
     rtpt_ctx* ctx = nullptr;
     void* history = nullptr;  // full-frame device buffer the previous frame's bands are gathered into (lazily allocated)
+    void* guide_ids = nullptr;      // extension modes: the previous frame's id plane ([H, W] u32) ...
+    void* guide_moments = nullptr;  // ... and moment plane ([H, W] float4), bands gathered like the history
     void* swap[2] = {nullptr, nullptr};  // swapchain images (whole-frame size; a non-presenting rank fills its own rows)
   };
   void* swapSingle_[2] = {nullptr, nullptr};  // the swapchain images of the one-context host
@@ -106,6 +108,8 @@ class PathTracingApplication {
   bool cameraStatic() const;
   void exchangeHalo(int k);
   void prepareHistory();
+  void prepareGuides();   // RTPT_FLAG_EXT_VARIANCE / _DISOCCLUSION on strips (app.py: _prepare_guides)
+  void exchangeBands(const std::vector<Rows>& needs, rtpt_plane plane, size_t px_bytes, void* RankState::*dst);
   std::vector<float> objVertices;              // main.cpp:255
   std::vector<uint32_t> objIndices;            // main.cpp:256
   std::vector<rtpt_material> objMaterials;     // tinyobj's `materials` (main.cpp:419), used when the OBJ has a library

@@ -26,12 +26,18 @@ using Rows = std::pair<int, int>;  // [first, second)
 struct StripPlan {
   int height = 0, world = 1, rank = 0, iterations = 0;
   bool exchange = false;  // halo mode: exchange | redundant
+  uint32_t ext_flags = 0; // RTPT_FLAG_EXT_*: the tap-shape modes change how far iteration k reaches
 
   static Rows bounds(int height, int world, int rank) {
     return {static_cast<int>(static_cast<int64_t>(rank) * height / world), static_cast<int>(static_cast<int64_t>(rank + 1) * height / world)};
   }
   Rows own() const { return bounds(height, world, rank); }
-  int reach(int k) const { return k; }  // temporalFiltering.comp.glsl:135 (the extension modes are not served here)
+  // rows above/below a pixel that iteration k reads: k for the reference's 3x3 linear-stride taps
+  // (temporalFiltering.comp.glsl:135); radius 2 with EXT_GAUSS5, stride 2^(k-1) with EXT_POW2_STRIDE (strips.py: reach)
+  int reach(int k) const {
+    const int stride = (ext_flags & RTPT_FLAG_EXT_POW2_STRIDE) ? (1 << (k - 1)) : k;
+    return stride * ((ext_flags & RTPT_FLAG_EXT_GAUSS5) ? 2 : 1);
+  }
   int halo() const;                     // rows stored beyond the owned strip on each side
   Rows stored() const;
   Rows grow(int rows) const;

@@ -101,6 +101,33 @@ def test_cpp_host_rccl_transport_single_rank(app_binary, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks,halo,flags", [(3, "exchange", 0xF0), (3, "redundant", 0x1F0), (2, "redundant", 0x180)])
+def test_cpp_host_strips_serve_the_extension_modes(app_binary, hip_lib, tmp_path, ranks, halo, flags):
+    """SURVEY 8(f) rank 1 in the product host's strip mode: 5x5 taps / 2^(k-1) stride widen the halo (StripPlan::reach),
+    adaptive alpha reads the gradient, and the disocclusion test / moment accumulation read the previous frame's id and
+    moment planes at reprojected pixels — bands of them travel between the strips when the camera moves
+    (rtpt_set_external_guides).  R in-process strips equal the Python single context bit for bit, vertical camera moves
+    in the script."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    W, H, SEG, N = 160, 144, 3, 3
+    keys = ["", "E", "J", "QA", "", "E"]
+    pfm = tmp_path / "ext.pfm"
+    out = subprocess.run([app_binary, "--width", str(W), "--height", str(H), "--segments", str(SEG), "--iterations", str(N),
+                          "--frames", str(len(keys)), "--script", ",".join(keys), "--dump", str(pfm), "--flags", hex(flags),
+                          "--ranks", str(ranks), "--halo", halo], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    app = make_app(W, H, max_segments=SEG, iterations=N, flags=flags)
+    for k in keys:
+        app.drawScene(tuple(k))
+    want = app.backend.ctx.readback(hip_lib.PLANE_IMAGE)
+    got = read_pfm(pfm)
+    assert np.array_equal(bits(got), bits(np.ascontiguousarray(want[..., :3])))
+    out = subprocess.run([app_binary, "--width", "64", "--height", "64", "--frames", "1", "--flags", "0x100", "--ranks", "2", "--halo", "exchange"],
+                         capture_output=True, text=True)
+    assert out.returncode == 1 and "redundant halo" in out.stderr
+
+
+@pytest.mark.gpu
 def test_cpp_host_rccl_rendezvous_ignores_a_stale_id_and_never_hangs(app_binary, tmp_path):
     """host/strips.cpp RcclTransport: (a) a rank > 0 that finds an id file of ANOTHER launch (different nonce) does not
     trust it and gives up with an error when its own launch's id never appears; (b) rank 0 removes the stale file,
