@@ -453,6 +453,11 @@ class PathTracingApplication:
             if self.plan.world > 1 and self.plan.mode == "exchange":
                 in_plane = abi.PLANE_IMAGE if (k & 1) else abi.PLANE_FILTERED
                 exchange_halo(self.plan, k, lambda a, b: self.backend.color_rows(in_plane, a, b), self.group)
+                if k > 1 and (self.plan.ext_flags & abi.FLAG_EXT_VARIANCE):
+                    # the variance iteration k-1 filtered travels with the colour it guides (north_star: "colour/moment/
+                    # depth/normal strips between iterations").  Iteration 1 needs no message: its variance comes from the
+                    # moment accumulation, which every rank also runs on the halo rows it just received the colour of
+                    exchange_halo(self.plan, k, lambda a, b: self.backend.guide_rows(abi.PLANE_VARIANCE, a, b), self.group)
             if self.plan.world > 1 and k == self.maxWaveletIteration and (k & 1):
                 self._prepare_history()
             self.backend.temporal_filter(pc, self.ubo, *self.plan.filter_rows(k))
@@ -611,9 +616,6 @@ def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode=
     """createBuffers + loadMesh + buildAccelerationStructure for one rank.  `mesh` = (xyz, idx) replaces
     the OBJ (synthetic scenes of scenes.py)."""
     plan = StripPlan(height, world, rank, iterations, mode, flags & abi.FLAG_EXT_MASK)
-    if world > 1 and (flags & abi.FLAG_EXT_VARIANCE) and mode != "redundant":
-        raise ValueError("RTPT_FLAG_EXT_VARIANCE on strips needs the redundant halo mode (every stored row is traced, so "
-                         "its moments exist; the exchange mode would have to ship variance and moment halos per iteration)")
     if torch_planes is None:
         torch_planes = world > 1  # halo exchange and the history all-gather move rows of torch-owned planes
     def one():

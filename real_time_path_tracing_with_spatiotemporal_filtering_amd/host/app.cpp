@@ -78,9 +78,6 @@ void PathTracingApplication::createBuffers() {
     // one strip context per rank this process runs; all on one stream, which is also the stream the transport's
     // messages are ordered on (RCCL point-to-point calls or device-to-device copies)
     if (opt_.frames_in_flight != 1) throw std::runtime_error("strips run one frame in flight");
-    if ((opt_.flags & RTPT_FLAG_EXT_VARIANCE) && opt_.exchange_halo)
-      throw std::runtime_error("RTPT_FLAG_EXT_VARIANCE on strips needs the redundant halo mode (every stored row is traced, so its "
-                               "moments exist; the exchange mode would have to ship variance and moment halos per iteration)");
     const bool local = opt_.rank < 0;
     if (!local && opt_.rank >= opt_.ranks) throw std::runtime_error("rank out of range");
     int dev = opt_.device;
@@ -245,8 +242,14 @@ bool PathTracingApplication::cameraStatic() const {
 // exchange mode: before iteration k every rank sends its k boundary rows of the iteration's INPUT plane (rgbd cells, so
 // the depth travels with the colour) to each neighbour — the one real exchange step of the path
 void PathTracingApplication::exchangeHalo(int k) {
-  const rtpt_plane in_plane = (k & 1) ? RTPT_PLANE_IMAGE : RTPT_PLANE_FILTERED;
-  const size_t row_bytes = static_cast<size_t>(opt_.width) * 16;
+  exchangeHaloPlane(k, (k & 1) ? RTPT_PLANE_IMAGE : RTPT_PLANE_FILTERED, 16);
+  // RTPT_FLAG_EXT_VARIANCE: the variance iteration k-1 filtered travels with the colour it guides; iteration 1's comes from
+  // the moment accumulation, which every rank also runs on the halo rows it has just received the colour of
+  if (k > 1 && (opt_.flags & RTPT_FLAG_EXT_VARIANCE)) exchangeHaloPlane(k, RTPT_PLANE_VARIANCE, 4);
+}
+
+void PathTracingApplication::exchangeHaloPlane(int k, rtpt_plane in_plane, size_t px_bytes) {
+  const size_t row_bytes = static_cast<size_t>(opt_.width) * px_bytes;
   transport_->begin(stream_);
   for (auto& rs : ranks_) {
     void* base = nullptr;

@@ -107,6 +107,7 @@ class PathTracingApplication {
   bool multi() const { return opt_.ranks > 1; }
   bool cameraStatic() const;
   void exchangeHalo(int k);
+  void exchangeHaloPlane(int k, rtpt_plane plane, size_t px_bytes);
   void prepareHistory();
   void prepareGuides();   // RTPT_FLAG_EXT_VARIANCE / _DISOCCLUSION on strips (app.py: _prepare_guides)
   void exchangeBands(const std::vector<Rows>& needs, rtpt_plane plane, size_t px_bytes, void* RankState::*dst);

@@ -52,7 +52,7 @@ def test_two_rank_rehearsal_counts_the_same_rays(hip_lib, halo):
     assert two["rays_per_frame"] == one["rays_per_frame"]
 
 
-@pytest.mark.parametrize("mode,flags", [("redundant", 0), ("exchange", 0), ("redundant", 0x100), ("redundant", 0x81)])
+@pytest.mark.parametrize("mode,flags", [("redundant", 0), ("exchange", 0), ("redundant", 0x100), ("redundant", 0x81), ("exchange", 0x100)])
 def test_gloo_ranks_on_one_gpu_reproduce_the_single_context_frames(hip_lib, tmp_path, mode, flags):
     """the Python host's multi-rank path on DEVICE memory — halo rows, the history bands bounded by the reprojection
     reach, and (extension flags 0x100 variance, 0x80 disocclusion) the previous frame's id / moment bands — with three
