@@ -84,6 +84,9 @@ struct rtpt_ctx {
   // device-side re-pose + refit (refit.hip): the uploaded (un-posed) triangles, the nodes sorted by height, the scratch
   // boxes and the grid the traversal reads.  BVH scenes only; small brute-force scenes keep host_tris for the screen bounds
   Buf obj_tris_dev, refit_order, refit_fbox, bvh_grid_dev;
+  Buf ray_tab;  // K0: view-space ray direction per column / per row, for the projection and size below
+  float ray_tab_p00 = 0.f, ray_tab_p11 = 0.f;
+  uint32_t ray_tab_w = 0, ray_tab_h = 0;
   std::vector<uint32_t> refit_level_first;  // slice of refit_order per height (levels + 1 entries)
   uint32_t n_nodes = 0;
   bool host_refit = false;  // RTPT_HOST_REFIT=1: round 2's host path for every scene (A/B)
@@ -538,7 +541,7 @@ int rtpt_destroy(rtpt_ctx* c) {
   for (auto& b : c->lut) free_buf(b);
   for (Buf* b : {&c->worldpos, &c->gradient, &c->depth, &c->prev_pixel, &c->hit_id, &c->raycount, &c->normal_tab, &c->pair_tab, &c->tris,
                  &c->leaf_order, &c->isect_id, &c->isect_leaf, &c->shade, &c->nodes, &c->materials, &c->obj_tris_dev, &c->refit_order,
-                 &c->refit_fbox, &c->bvh_grid_dev})
+                 &c->refit_fbox, &c->bvh_grid_dev, &c->ray_tab})
     free_buf(*b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -982,6 +985,20 @@ int rtpt_gbuffer(rtpt_ctx* c, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1) {
   a.c2[0] = c2.x; a.c2[1] = c2.y; a.c2[2] = c2.z;
   a.p00 = ubo->proj[0];
   a.p11 = ubo->proj[5];
+  // per-column / per-row view-space ray directions (kernels.hip k_ray_tables): rebuilt when the projection or the frame
+  // size they were built for changes (the reference's projection is constant after start-up, main.cpp:1471)
+  if (!c->ray_tab.ptr || c->ray_tab_p00 != a.p00 || c->ray_tab_p11 != a.p11 || c->ray_tab_w != c->cfg.width || c->ray_tab_h != c->cfg.height) {
+    int rct = alloc_buf(c->ray_tab, (static_cast<size_t>(c->cfg.width) + c->cfg.height) * sizeof(float));
+    if (rct) return rct;
+    rt::launch_ray_tables(static_cast<int>(c->cfg.width), static_cast<int>(c->cfg.height), a.p00, a.p11, static_cast<float*>(c->ray_tab.ptr),
+                          static_cast<float*>(c->ray_tab.ptr) + c->cfg.width, c->stream);
+    c->ray_tab_p00 = a.p00;
+    c->ray_tab_p11 = a.p11;
+    c->ray_tab_w = c->cfg.width;
+    c->ray_tab_h = c->cfg.height;
+  }
+  a.dvx = static_cast<const float*>(c->ray_tab.ptr);
+  a.dvy = a.dvx + c->cfg.width;
   rt::exact::mat_mul(ubo->proj, ubo->view, a.PV);
   a.tmax = c->cfg.ray_tmax;
   {

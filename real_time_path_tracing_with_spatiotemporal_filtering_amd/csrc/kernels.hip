@@ -503,6 +503,19 @@ __device__ __forceinline__ void store_gradient(float4* grad, size_t i, float lam
 // ------------------------------------------------------------------------------------------
 // K0 G-buffer
 // ------------------------------------------------------------------------------------------
+// dvx[x] = ((2 (x + .5) - W) / W) / P00 for every column, dvy[y] likewise for every frame row (see k_gbuffer)
+__global__ void k_ray_tables(int W, int H, float p00, float p11, float* dvx, float* dvy) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < W) {
+    const float fw = static_cast<float>(W);
+    dvx[i] = (fmaf_(2.0f, static_cast<float>(i) + 0.5f, -fw) / fw) / p00;
+  }
+  if (i < H) {
+    const float fh = static_cast<float>(H);
+    dvy[i] = (fmaf_(2.0f, static_cast<float>(i) + 0.5f, -fh) / fh) / p11;
+  }
+}
+
 template <bool BVH>
 __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
   extern __shared__ uint32_t stack[];  // BVH: stack_depth x 256 entries (dynamic); unused otherwise
@@ -513,10 +526,10 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
   if (!BVH && a.cull)
     cand = span_candidates(a.bounds, a.scene.n_tris, static_cast<int>(blockIdx.x) * kBlockX, __builtin_amdgcn_readfirstlane(y));
   if (x >= a.g.W || y >= a.g.y1) return;
-  const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
-  float nx = fmaf_(2.0f, static_cast<float>(x) + 0.5f, -fw) / fw;
-  float ny = fmaf_(2.0f, static_cast<float>(y) + 0.5f, -fh) / fh;
-  f3 dv{nx / a.p00, ny / a.p11, -1.0f};
+  // view-space direction of the pixel-centre ray: (ndc.x / P00, ndc.y / P11, -1) with ndc = (2 (x + .5) - W) / W.  Each
+  // component is a function of the column or of the row alone: k_ray_tables evaluates the two divisions per column / row
+  // once (same operands, same correctly-rounded operations), K0 reads them back — 4 divisions less per pixel
+  f3 dv{a.dvx[x], a.dvy[y], -1.0f};
   f3 c0 = ld3(a.c0), c1 = ld3(a.c1), c2 = ld3(a.c2);
   f3 d = exact::normalize(f3{exact::dot(c0, dv), exact::dot(c1, dv), exact::dot(c2, dv)});
   f3 o = ld3(a.org);
@@ -833,7 +846,10 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
         d = f3{st.dx[tid], st.dy[tid], st.dz[tid]};
         acc = f3{st.ar[tid], st.ag[tid], st.ab[tid]};
       }
-      __syncthreads();  // everybody has read its slot before the next compaction writes
+      // BVH: the traversal's node stack aliases the exchange buffer, so everybody must have read its slot before any
+      // wave walks on.  Brute force: nothing writes the buffer before the NEXT compaction's first barrier, which every
+      // thread reaches only after these reads — a third barrier per segment would only hold the fast waves back.
+      if (BVH) __syncthreads();
     }
     if (a.seg_end < a.max_segments) {  // only with spp == 1: the unfinished paths continue in a queue kernel
       const uint32_t pixg = (static_cast<uint32_t>(tile_y0 + static_cast<int>(pix >> 6)) << 16) |
@@ -960,7 +976,7 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace_queue(PathtraceArgs a)
         d = f3{st.dx[tid], st.dy[tid], st.dz[tid]};
         acc = f3{st.ar[tid], st.ag[tid], st.ab[tid]};
       }
-      __syncthreads();
+      if (BVH) __syncthreads();  // the node stack aliases the exchange buffer (see k_pathtrace)
     }
     if (a.seg_end < a.max_segments) enqueue_paths(a, region, wave_cnt, &q_base, alive, wave, lane, pix, rng, o, d, acc);
     __syncthreads();  // wave_cnt / st are reused by the next chunk
@@ -1015,6 +1031,10 @@ void launch_lut(const LutArgs& a, hipStream_t s) {
     const uint32_t n = (a.n_tris + 1) * (a.n_tris + 1);
     hipLaunchKernelGGL(k_pair_weights, dim3((n + 255) / 256), dim3(256), 0, s, a);
   }
+}
+void launch_ray_tables(int W, int H, float p00, float p11, float* dvx, float* dvy, hipStream_t s) {
+  const int n = W > H ? W : H;
+  hipLaunchKernelGGL(k_ray_tables, dim3((n + 255) / 256), dim3(256), 0, s, W, H, p00, p11, dvx, dvy);
 }
 void launch_gbuffer(const GbufferArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;

@@ -56,6 +56,8 @@ struct GbufferArgs {
   float org[3];          // camera origin = -R^T t
   float c0[3], c1[3], c2[3];  // columns of the view rotation
   float p00, p11;        // proj[0][0], proj[1][1]
+  const float* dvx;      // [W] view-space ray direction x per column, [H] y per frame row (launch_ray_tables)
+  const float* dvy;
   float PV[16];          // proj * view (host product, fixed order)
   float tmax;
   uint32_t* vis;
@@ -248,6 +250,7 @@ void launch_refit(const RefitArgs& a, const uint32_t* level_first, int n_levels,
 // gather isect records into class order: out[t] = isect_id[ids[t]] (3 float4 each), n entries
 void launch_lut(const LutArgs& a, hipStream_t s);
 void launch_gbuffer(const GbufferArgs& a, hipStream_t s);
+void launch_ray_tables(int W, int H, float p00, float p11, float* dvx, float* dvy, hipStream_t s);
 void launch_gradient(const GradientArgs& a, hipStream_t s);
 void launch_pathtrace(const PathtraceArgs& a, hipStream_t s);
 void launch_atrous(const AtrousArgs& a, bool final_pass, hipStream_t s);
