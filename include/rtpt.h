@@ -301,6 +301,12 @@ int rtpt_end_frame(rtpt_ctx* ctx);
  * buffer is the caller's "swapchain image"; with several ranks each rank converts its own rows and the presenting rank
  * gathers them (4 B/px on the wire instead of 16).  Runs on the context's stream. */
 int rtpt_present(rtpt_ctx* ctx, void* dst_device, uint32_t y0, uint32_t y1);
+/* Optional, before the frame's rtpt_temporal_filter calls: name the swapchain rows of this frame in advance.  The final
+ * filter pass then writes them in swapchain format as it stores the frame (one launch and one 16 B/px read less), and the
+ * later rtpt_present of the same rows and image returns at once; where the final pass runs in a kernel that cannot fuse
+ * the store (extension modes, direct-load variants), rtpt_present does the work as before — the calling sequence is the
+ * same either way.  The registration stays until changed; dst_device == NULL clears it. */
+int rtpt_present_target(rtpt_ctx* ctx, void* dst_device, uint32_t y0, uint32_t y1);
 
 /* ---- synchronisation / data movement ---------------------------------------------------- */
 int rtpt_sync(rtpt_ctx* ctx);

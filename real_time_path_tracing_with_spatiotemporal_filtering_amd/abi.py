@@ -95,7 +95,7 @@ SYMBOLS = [
     "rtpt_reset_counters", "rtpt_set_count_rows", "rtpt_enable_debug", "rtpt_timing_enable", "rtpt_timing_collect", "rtpt_kernel_name",
     "rtpt_selftest_math", "rtpt_selftest_trace", "rtpt_util_look_at", "rtpt_util_perspective", "rtpt_util_load_obj", "rtpt_util_bvh_check",
     "rtpt_scene_set_materials", "rtpt_util_load_obj_materials", "rtpt_util_bvh_refit_check", "rtpt_set_external_guides",
-    "rtpt_present", "rtpt_debug_bvh_check",
+    "rtpt_present", "rtpt_debug_bvh_check", "rtpt_present_target",
 ]
 
 _lib = None
@@ -135,6 +135,7 @@ def load() -> C.CDLL:
         "rtpt_temporal_filter": [vp, C.POINTER(PushConstants), C.POINTER(Ubo), u32, u32],
         "rtpt_end_frame": [vp],
         "rtpt_present": [vp, vp, u32, u32],
+        "rtpt_present_target": [vp, vp, u32, u32],
         "rtpt_sync": [vp],
         "rtpt_readback": [vp, C.c_int, vp, sz],
         "rtpt_set_plane": [vp, C.c_int, vp, sz],
@@ -335,6 +336,10 @@ class Context:
 
     def end_frame(self):
         _check(self._lib.rtpt_end_frame(self._h))
+
+    def present_target(self, dst_device_ptr: int | None, y0=0, y1=0):
+        """name the swapchain rows of the frame being built: the final filter pass writes them too (fused blit)"""
+        _check(self._lib.rtpt_present_target(self._h, C.c_void_p(dst_device_ptr) if dst_device_ptr else None, y0, y1))
 
     def present(self, dst_device_ptr: int, y0=0, y1=0):
         """main.cpp:1338-1361: rows [y0,y1) of the finished frame -> B8G8R8A8_UNORM at the device address"""

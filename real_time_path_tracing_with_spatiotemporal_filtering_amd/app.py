@@ -165,6 +165,10 @@ class HipBackend:
         """rtpt_present: rows [y0,y1) of the finished frame -> rows [y0,y1) of the [H, W, 4] uint8 swapchain image"""
         self.ctx.present(image8.data_ptr() + y0 * self.width * 4, y0, y1)
 
+    def present_target(self, image8, y0: int, y1: int):
+        """rtpt_present_target: the frame's final filter pass writes these rows of the swapchain image itself"""
+        self.ctx.present_target(image8.data_ptr() + y0 * self.width * 4, y0, y1)
+
     def final_rows(self, y0: int, y1: int):
         """torch view of rows of the finished frame (after end_frame: the PREVIOUS plane)"""
         return self.color_rows(abi.PLANE_PREVIOUS, y0, y1)
@@ -289,6 +293,9 @@ class PipelinedBackend:
 
     def present_rows(self, image8, y0, y1):
         self.prev.present_rows(image8, y0, y1)
+
+    def present_target(self, image8, y0, y1):   # called while the frame is being built: its backend is `cur`
+        self.cur.present_target(image8, y0, y1)
 
     def final_rows(self, y0, y1):
         return self.prev.final_rows(y0, y1)
@@ -446,6 +453,10 @@ class PathTracingApplication:
         """main.cpp:1255-1306: k = 1..N, ping-pong by parity; one ABI call per iteration."""
         pc = self.pushConstants
         pc.maxWaveletIteration = self.maxWaveletIteration  # :1258
+        if self.present == "rgba8" and hasattr(self.backend, "present_target"):
+            # name this frame's swapchain rows now: the final pass then stores them in swapchain format itself (one
+            # launch and one read of the frame less); _present() below calls rtpt_present all the same
+            self.backend.present_target(self._present_image(self.frameCount & 1), *self.plan.own)
         if self.plan.world > 1 and (self.plan.ext_flags & (abi.FLAG_EXT_VARIANCE | abi.FLAG_EXT_DISOCCLUSION)):
             self._prepare_guides()
         for k in range(1, self.maxWaveletIteration + 1):   # :1259
@@ -489,21 +500,25 @@ class PathTracingApplication:
             import torch
             torch.cuda.current_stream().wait_event(ev)
 
-    def _present(self):
+    def _present_image(self, idx: int):
         be, plan = self.backend, self.plan
-        o0, o1 = plan.own
-        f = self.frameCount            # drawScene increments after this call
-        idx = f & 1
         H, W = plan.height, self.render_width
-        rgba8 = self.present == "rgba8"
         if self._present_images is None:
-            if rgba8:
+            if self.present == "rgba8":
                 self._present_images = [be.alloc((H, W, 4), "uint8") for _ in range(2)]
             elif plan.world > 1 and plan.rank == self.present_root:
                 self._present_images = [be.alloc((H, W, 4), "float32") for _ in range(2)]
             else:
                 self._present_images = [None, None]
-        img = self._present_images[idx]
+        return self._present_images[idx]
+
+    def _present(self):
+        be, plan = self.backend, self.plan
+        o0, o1 = plan.own
+        f = self.frameCount            # drawScene increments after this call
+        idx = f & 1
+        rgba8 = self.present == "rgba8"
+        img = self._present_image(idx)
         if rgba8:
             be.present_rows(img, o0, o1)
             mine = img[o0:o1]

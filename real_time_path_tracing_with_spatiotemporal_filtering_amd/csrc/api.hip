@@ -84,6 +84,12 @@ struct rtpt_ctx {
   // device-side re-pose + refit (refit.hip): the uploaded (un-posed) triangles, the nodes sorted by height, the scratch
   // boxes and the grid the traversal reads.  BVH scenes only; small brute-force scenes keep host_tris for the screen bounds
   Buf obj_tris_dev, refit_order, refit_fbox, bvh_grid_dev;
+  // rtpt_present_target: the swapchain image rows the NEXT final pass also writes (fused blit); present_fused_* describe
+  // what the last final pass actually wrote, so that rtpt_present can skip its own launch
+  void* present_dst = nullptr;
+  int present_y0 = 0, present_y1 = 0;
+  void* present_fused_dst = nullptr;
+  int present_fused_y0 = 0, present_fused_y1 = 0;
   Buf ray_tab;  // K0: view-space ray direction per column / per row, for the projection and size below
   float ray_tab_p00 = 0.f, ray_tab_p11 = 0.f;
   uint32_t ray_tab_w = 0, ray_tab_h = 0;
@@ -1339,6 +1345,16 @@ int filter_launch(rtpt_ctx* c, const FilterCall& f, int levels) {
     a.var_out = static_cast<float*>(c->variance[c->variance_last ^ 1].ptr);
     c->variance_last ^= 1;
   }
+  if (final_pass) c->present_fused_dst = nullptr;  // a new frame's final pass: the previous frame's blit is history
+  if (final_pass && levels == 1 && c->present_dst && static_cast<int>(y0) <= c->present_y0 && static_cast<int>(y1) >= c->present_y1 &&
+      rt::atrous_final_fuses_present(a)) {
+    a.present = static_cast<uint32_t*>(c->present_dst);
+    a.present_y0 = c->present_y0;
+    a.present_y1 = c->present_y1;
+    c->present_fused_dst = c->present_dst;
+    c->present_fused_y0 = c->present_y0;
+    c->present_fused_y1 = c->present_y1;
+  }
   {
     Timer tm(c, levels > 1 ? (final_pass ? RTPT_K_ATROUS_CHAIN_FINAL : RTPT_K_ATROUS_CHAIN) : (final_pass ? RTPT_K_ATROUS_FINAL : RTPT_K_ATROUS));
     if (levels > 1)
@@ -1486,6 +1502,23 @@ int rtpt_end_frame(rtpt_ctx* c) {
   return RTPT_OK;
 }
 
+// the swapchain image rows the next final filter pass should also write (fused blit); NULL clears the registration
+int rtpt_present_target(rtpt_ctx* c, void* dst_device, uint32_t y0, uint32_t y1) {
+  if (!c) return fail(RTPT_E_INVALID, "ctx is NULL");
+  if (!dst_device) {
+    c->present_dst = nullptr;
+    return RTPT_OK;
+  }
+  if (reinterpret_cast<uintptr_t>(dst_device) & 3u) return fail(RTPT_E_INVALID, "swapchain image must be 4-byte aligned");
+  FLUSH_FILTER(c);  // recorded iterations were recorded without it: they go out as they are
+  int rc = check_rows(c, y0, y1);
+  if (rc) return rc;
+  c->present_dst = dst_device;
+  c->present_y0 = static_cast<int>(y0);
+  c->present_y1 = static_cast<int>(y1);
+  return RTPT_OK;
+}
+
 // main.cpp:1338-1361: the blit of `image` to the swapchain image
 int rtpt_present(rtpt_ctx* c, void* dst_device, uint32_t y0, uint32_t y1) {
   if (!c || !dst_device) return fail(RTPT_E_INVALID, "NULL argument");
@@ -1493,6 +1526,10 @@ int rtpt_present(rtpt_ctx* c, void* dst_device, uint32_t y0, uint32_t y1) {
   FLUSH_FILTER(c);
   int rc = check_rows(c, y0, y1);
   if (rc) return rc;
+  // already there: the frame's final pass wrote these rows of this image in swapchain format (rtpt_present_target)
+  if (c->present_fused_dst && static_cast<int>(y0) >= c->present_fused_y0 && static_cast<int>(y1) <= c->present_fused_y1 &&
+      static_cast<char*>(dst_device) == static_cast<char*>(c->present_fused_dst) + static_cast<size_t>(static_cast<int>(y0) - c->present_fused_y0) * c->cfg.width * 4)
+    return RTPT_OK;
   // the finished frame: IMAGE until rtpt_end_frame, PREVIOUS after it (the reference blits before it copies, the pixels
   // are the same); only rows the last final pass wrote hold it
   Buf* b = plane_buf(c, c->image_alias ? RTPT_PLANE_PREVIOUS : RTPT_PLANE_IMAGE);

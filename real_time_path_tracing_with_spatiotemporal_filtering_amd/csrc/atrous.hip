@@ -24,6 +24,15 @@
 namespace rt {
 namespace {
 
+// main.cpp:1338-1361 vkCmdBlitImage image (RGBA32F) -> swapchain image (B8G8R8A8_UNORM): the float -> UNORM
+// conversion clamps to [0,1] and quantises; defined here as trunc(x*255 + 0.5) with separate multiply and add (the
+// file is compiled -ffp-contract=off), NaN -> 0 (max(NaN, 0) = 0), which is what output.to_unorm8 / the oracle compute.
+__device__ __forceinline__ uint32_t unorm8(float x) {
+  const float c = fminf(fmaxf(x, 0.0f), 1.0f);
+  return static_cast<uint32_t>(c * 255.0f + 0.5f);
+}
+
+
 // x^n for the normal weight (temporalFiltering.comp.glsl:62).  The reference's exponent is 128: seven squarings,
 // written straight-line — exact::powi's square-and-multiply LOOP yields the same products in the same order but
 // runs its control flow on the CU's single scalar unit, which made per-tap use of it SALU-bound.
@@ -659,6 +668,9 @@ void k_atrous_comb_sh(AtrousArgs a) {
 #else
     a.out[ip] = make_float4(blend.x, blend.y, blend.z, 0.0f);  // :263 (D1: distinct buffer)
 #endif
+    // main.cpp:1338-1361, fused: the blit reads exactly the value stored above (alpha 0), k_present's conversion
+    if (a.present && y >= a.present_y0 && y < a.present_y1)
+      a.present[static_cast<size_t>(y - a.present_y0) * W + x] = unorm8(blend.z) | (unorm8(blend.y) << 8) | (unorm8(blend.x) << 16);
   }
   }  // work list
 }
@@ -673,13 +685,6 @@ __global__ __launch_bounds__(kThreads) void k_stamp_depth(FrameGeom g, float4* c
   reinterpret_cast<float*>(color + i)[3] = depth[i];
 }
 
-// main.cpp:1338-1361 vkCmdBlitImage image (RGBA32F) -> swapchain image (B8G8R8A8_UNORM): the float -> UNORM
-// conversion clamps to [0,1] and quantises; defined here as trunc(x*255 + 0.5) with separate multiply and add (the
-// file is compiled -ffp-contract=off), NaN -> 0 (max(NaN, 0) = 0), which is what output.to_unorm8 / the oracle compute.
-__device__ __forceinline__ uint32_t unorm8(float x) {
-  const float c = fminf(fmaxf(x, 0.0f), 1.0f);
-  return static_cast<uint32_t>(c * 255.0f + 0.5f);
-}
 __global__ __launch_bounds__(kThreads) void k_present(FrameGeom g, const float4* __restrict__ image, uint32_t* __restrict__ dst) {
   const int x = blockIdx.x * kBlockX + threadIdx.x;
   const int y = g.y0 + blockIdx.y * kBlockY + threadIdx.y;
@@ -744,6 +749,15 @@ hipError_t prepare_device_atrous() {
   if (e == hipSuccess) e = comb_attrs<b + 16, true>();
   if (e == hipSuccess) e = comb_attrs<b + 32, true>();
   return e;
+}
+
+// true when a FINAL launch of `a` runs in the LDS-staged kernel, whose epilogue can also write the swapchain format
+// (AtrousArgs::present); every other final variant leaves the blit to k_present
+bool atrous_final_fuses_present(const AtrousArgs& a) {
+  const int np = static_cast<int>(a.n_tris) + 1;
+  const bool pair_mode = a.pair_tab && np <= kPairMax;
+  const bool nrm_mode = !pair_mode && a.normals != nullptr;
+  return !a.ext && !a.direct && (pair_mode || nrm_mode) && a.k >= 1 && a.k <= 16;
 }
 
 void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {

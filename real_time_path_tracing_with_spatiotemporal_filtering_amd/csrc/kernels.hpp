@@ -173,6 +173,10 @@ struct AtrousArgs {
   const float4* gradient;         // K1 output (adaptive alpha)
   const uint32_t* prev_vis;       // previous frame's id plane, rows [pvis_y0,pvis_y1) valid, stored from pvis_row_base
   int32_t pvis_y0, pvis_y1, pvis_row_base;
+  // final pass only, optional: the swapchain blit (main.cpp:1338-1361) fused into the pass — rows [present_y0, present_y1)
+  // of the blended frame are also written as B8G8R8A8_UNORM to present (first byte = pixel (0, present_y0)); rtpt_present_target
+  uint32_t* present;
+  int32_t present_y0, present_y1;
   const float* var_in;            // RTPT_FLAG_EXT_VARIANCE: per-pixel luminance variance read by this iteration
   float* var_out;                 //                         ... and the filtered variance it writes
 };
@@ -254,6 +258,7 @@ void launch_ray_tables(int W, int H, float p00, float p11, float* dvx, float* dv
 void launch_gradient(const GradientArgs& a, hipStream_t s);
 void launch_pathtrace(const PathtraceArgs& a, hipStream_t s);
 void launch_atrous(const AtrousArgs& a, bool final_pass, hipStream_t s);
+bool atrous_final_fuses_present(const AtrousArgs& a);
 // `levels` consecutive iterations k, k+1, .. in one launch, intermediates in LDS (atrous_chain.hip): a.k = the first
 // stride, a.in / a.out = input of the first and output of the last iteration (distinct buffers), final_pass = the last
 // level is the frame's FINAL pass (reprojection + blend)

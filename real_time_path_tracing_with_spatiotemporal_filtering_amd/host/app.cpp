@@ -365,8 +365,36 @@ void PathTracingApplication::prepareGuides() {
   }
 }
 
+void* PathTracingApplication::presentImage(RankState* rs, int idx) {
+  const size_t bytes = static_cast<size_t>(opt_.width) * opt_.height * (opt_.present == 1 ? 4 : 16);
+  void*& p = rs ? rs->swap[idx] : swapSingle_[idx];
+  if (!p) p = host_device_alloc(bytes);
+  return p;
+}
+
+// vkAcquireNextImageKHR's role (main.cpp:1310-1316): image idx may be written again once the gather that read it — two
+// frames ago — is done; then the rows are named to the final filter pass, which stores them in swapchain format itself
+void PathTracingApplication::armPresent() {
+  if (opt_.present != 1) return;
+  const int idx = static_cast<int>(frameCount & 1);
+  if (!multi()) {
+    check(rtpt_present_target(ctx_, presentImage(nullptr, idx), 0, opt_.height), "rtpt_present_target");
+    return;
+  }
+  if (presentDone_[idx]) host_stream_wait_event(stream_, presentDone_[idx]);
+  const size_t row_bytes = static_cast<size_t>(opt_.width) * 4;
+  for (auto& rs : ranks_) {
+    const Rows own = rs.plan.own();
+    char* img = static_cast<char*>(presentImage(&rs, idx));
+    check(rtpt_present_target(rs.ctx, img + static_cast<size_t>(own.first) * row_bytes, static_cast<uint32_t>(own.first),
+                              static_cast<uint32_t>(own.second)),
+          "rtpt_present_target");
+  }
+}
+
 void PathTracingApplication::applyTemporalFiltering() {
   pushConstants.maxWaveletIteration = opt_.maxWaveletIteration;   // :1258
+  armPresent();
   if (multi()) {
     if (opt_.flags & (RTPT_FLAG_EXT_VARIANCE | RTPT_FLAG_EXT_DISOCCLUSION)) prepareGuides();
     for (int k = 1; k <= opt_.maxWaveletIteration; k++) {         // :1259
@@ -417,23 +445,21 @@ void PathTracingApplication::presentFrame() {
   const size_t W = opt_.width, H = opt_.height;
   const int idx = static_cast<int>(frameCount & 1);
   if (!multi()) {
-    if (!swapSingle_[idx]) swapSingle_[idx] = host_device_alloc(W * H * 4);
-    check(rtpt_present(last_, swapSingle_[idx], 0, opt_.height), "rtpt_present");
+    // returns at once when the final pass already wrote the image (armPresent)
+    check(rtpt_present(last_, presentImage(nullptr, idx), 0, opt_.height), "rtpt_present");
     return;
   }
   const bool rgba8 = opt_.present == 1;
   const size_t px_bytes = rgba8 ? 4 : 16, row_bytes = W * px_bytes;
-  // acquire: the gather that last used image idx (frame - 2) must be done before this frame's rows land in it
-  host_stream_wait_stream(stream_, presentStream_);
+  // f32: the root's image and the strip buffers the others send from are written again two frames later: same acquire
+  if (!rgba8 && presentDone_[idx]) host_stream_wait_event(stream_, presentDone_[idx]);
   std::vector<const char*> mine(ranks_.size());
   for (size_t i = 0; i < ranks_.size(); i++) {
     RankState& rs = ranks_[i];
     const Rows own = rs.plan.own();
     const bool root = rs.plan.rank == 0;
-    if (rgba8 || root)
-      if (!rs.swap[idx]) rs.swap[idx] = host_device_alloc(H * row_bytes);
     if (rgba8) {
-      char* dst = static_cast<char*>(rs.swap[idx]) + static_cast<size_t>(own.first) * row_bytes;
+      char* dst = static_cast<char*>(presentImage(&rs, idx)) + static_cast<size_t>(own.first) * row_bytes;
       check(rtpt_present(rs.ctx, dst, static_cast<uint32_t>(own.first), static_cast<uint32_t>(own.second)), "rtpt_present");
       mine[i] = dst;
     } else {
@@ -441,7 +467,7 @@ void PathTracingApplication::presentFrame() {
       check(rtpt_plane_ptr(rs.ctx, RTPT_PLANE_PREVIOUS, &prev), "rtpt_plane_ptr");
       mine[i] = static_cast<const char*>(prev) + static_cast<size_t>(own.first - rs.plan.stored().first) * row_bytes;
       if (root)
-        host_device_copy(static_cast<char*>(rs.swap[idx]) + static_cast<size_t>(own.first) * row_bytes, mine[i],
+        host_device_copy(static_cast<char*>(presentImage(&rs, idx)) + static_cast<size_t>(own.first) * row_bytes, mine[i],
                          static_cast<size_t>(own.second - own.first) * row_bytes, stream_);
     }
   }
@@ -461,6 +487,8 @@ void PathTracingApplication::presentFrame() {
     }
   }
   presentTransport_->end();
+  if (!presentDone_[idx]) presentDone_[idx] = host_event_create();
+  host_event_record(presentDone_[idx], presentStream_);
 }
 
 std::vector<unsigned char> PathTracingApplication::readPresented() {
@@ -509,6 +537,10 @@ void PathTracingApplication::freeRessources() {
   for (void*& p : swapSingle_) {
     if (p) host_device_free(p);
     p = nullptr;
+  }
+  for (void*& e : presentDone_) {
+    if (e) host_event_destroy(e);
+    e = nullptr;
   }
   if (!ranks_.empty()) {
     ranks_.clear();

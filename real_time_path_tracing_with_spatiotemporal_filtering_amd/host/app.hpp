@@ -99,7 +99,10 @@ class PathTracingApplication {
   void* swapSingle_[2] = {nullptr, nullptr};  // the swapchain images of the one-context host
   Transport* presentTransport_ = nullptr;     // its own communicator + stream: the gather runs behind the frame, beside the next
   void* presentStream_ = nullptr;
+  void* presentDone_[2] = {nullptr, nullptr}; // recorded behind the gather that read swapchain image i
   void presentFrame();                        // main.cpp:1338-1361
+  void armPresent();                          // acquire this frame's image, name its rows to the final pass (rtpt_present_target)
+  void* presentImage(RankState* rs, int idx); // allocate on first use
   std::vector<RankState> ranks_;
   Transport* transport_ = nullptr;
   void* stream_ = nullptr;

@@ -309,6 +309,14 @@ void host_stream_wait_stream(void* waiter, void* on) {
   HIP_OK(hipEventDestroy(e));  // the recorded wait keeps what it needs; the handle can go
 }
 void host_stream_sync(void* stream) { HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream))); }
+void* host_event_create() {
+  hipEvent_t e = nullptr;
+  HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return e;
+}
+void host_event_destroy(void* ev) { (void)hipEventDestroy(static_cast<hipEvent_t>(ev)); }
+void host_event_record(void* ev, void* stream) { HIP_OK(hipEventRecord(static_cast<hipEvent_t>(ev), static_cast<hipStream_t>(stream))); }
+void host_stream_wait_event(void* stream, void* ev) { HIP_OK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev), 0)); }
 
 Transport* make_local_transport() { return new LocalTransport(); }
 Transport* make_rccl_transport(int world, int rank, const std::string& id_file, uint64_t nonce, int timeout_s) {

@@ -102,5 +102,10 @@ void host_device_to_host(void* dst, const void* src, size_t bytes, void* stream)
 // stream-to-stream ordering without blocking the host: `waiter` continues once everything submitted to `on` so far is done
 void host_stream_wait_stream(void* waiter, void* on);
 void host_stream_sync(void* stream);
+// events (timing disabled): record on a stream now, make another stream wait for that point later
+void* host_event_create();
+void host_event_destroy(void* ev);
+void host_event_record(void* ev, void* stream);
+void host_stream_wait_event(void* stream, void* ev);
 
 }  // namespace rtpt_host

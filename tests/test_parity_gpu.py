@@ -836,3 +836,39 @@ def test_present_through_the_app_incl_two_frames_in_flight(hip_lib, oracle, corn
             ok, rel = l2_ok(want_img, fo.image)
             assert ok, rel
         app.backend.close()
+
+
+def test_fused_blit_equals_the_separate_blit(hip_lib, oracle, cornell):
+    """rtpt_present_target: the final filter pass writes the swapchain rows itself (LDS-staged final kernel) and the later
+    rtpt_present returns at once; same bytes as the separate k_present.  Variants that cannot fuse (an extension mode's final
+    pass, the direct-load kernels) leave the work to rtpt_present — same calls, same bytes.  Timing hooks tell which ran."""
+    import torch
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    w, h = 333, 170
+    for flags, fused in ((0, True), (hip_lib.FLAG_EXACT_FILTER, True), (0x4, False), (hip_lib.FLAG_EXT_ADAPTIVE_ALPHA, False)):
+        app = make_app(w, h, max_segments=3, iterations=5, flags=flags)
+        ctx = app.backend.ctx
+        ctx.timing_enable(1)
+        img_a = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        img_b = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for f, key in enumerate([(), ("J",), ("E",)]):
+            app.updateScene(key)
+            app.drawVisbilityBuffer()
+            app.computeTemporalGradient()
+            app.drawSceneToImage()
+            ctx.present_target(img_a.data_ptr() + 20 * w * 4, 20, 150)   # a band: rows 20..149
+            app.applyTemporalFiltering()
+            app.copyImageToSwapChainsCurrentImage()
+            app.frameCount += 1
+            ctx.present(img_a.data_ptr() + 20 * w * 4, 20, 150)          # no launch when the final pass did it
+            ctx.present_target(None)
+            ctx.present(img_b.data_ptr() + 20 * w * 4, 20, 150)          # the separate blit
+            ctx.sync()
+            final = ctx.readback(hip_lib.PLANE_PREVIOUS)
+            a, b = img_a.cpu().numpy(), img_b.cpu().numpy()
+            assert a.tobytes() == b.tobytes(), (hex(flags), f)
+            assert b[20:150].tobytes() == oracle.present_bgra8(final)[20:150].tobytes() and not b[:20].any() and not b[150:].any()
+        n_present = ctx.timing_collect()["k_present"][1]
+        assert n_present == (3 if fused else 6), (hex(flags), n_present)
+        app.backend.close()
