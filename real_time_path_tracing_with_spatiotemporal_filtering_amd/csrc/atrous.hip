@@ -381,7 +381,7 @@ constexpr int kShThreads = 64 * kShWaves;
 #ifndef RTPT_COMB_MIN_WAVES
 #define RTPT_COMB_MIN_WAVES 0
 #endif
-template <int CWp, bool FINAL, bool EXACT, bool NRM = false, int R = 1, bool EXTA = false>
+template <int CWp, bool FINAL, bool EXACT, bool NRM = false, int R = 1, bool EXTA = false, bool VAR = false>
 __global__ __launch_bounds__(kShThreads)
 #if RTPT_COMB_MIN_WAVES
 __attribute__((amdgpu_waves_per_eu(RTPT_COMB_MIN_WAVES)))
@@ -401,6 +401,10 @@ void k_atrous_comb_sh(AtrousArgs a) {
   const float4* nrm = reinterpret_cast<const float4*>(mine + 16 * cells);   // NRM: (n.xyz, self weight) instead of ids
   const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)mine));
   const uint32_t lds_col = lds0, lds_ids = lds0 + 16u * static_cast<uint32_t>(cells);
+  // EXTA with RTPT_FLAG_EXT_VARIANCE: the variance plane this iteration reads is staged as a third plane (4 B per cell)
+  constexpr bool use_var = EXTA && !NRM && VAR;  // the launch picks VAR iff (a.ext & kExtVariance) && a.var_in
+  const float* varp = reinterpret_cast<const float*>(mine + 20 * cells);
+  const uint32_t lds_var = lds0 + 20u * static_cast<uint32_t>(cells);
 
   // id-pair weight table -> LDS (plain loads; no DMA is in flight yet)
   for (int i = wave * 64 + lane; i < NP * NP; i += kShThreads) pairw[i] = a.pair_tab[i];
@@ -487,6 +491,7 @@ void k_atrous_comb_sh(AtrousArgs a) {
     const float4* rin = a.in + grow;
     const uint32_t* rvis = a.vis + grow;
     const float4* rnrm = NRM ? a.normals + grow : nullptr;
+    const float* rvar = use_var ? a.var_in + grow : nullptr;
     const uint32_t cj = static_cast<uint32_t>(j * CWp);
 #pragma unroll
     for (int hf = 0; hf < kShHalves; hf++) {
@@ -495,6 +500,7 @@ void k_atrous_comb_sh(AtrousArgs a) {
         dma_b128(rnrm, o16[hf], lds_ids + (cj + 64u * hf) * 16u);
       else
         dma_b32(rvis, o4[hf], lds_ids + (cj + 64u * hf) * 4u);
+      if (use_var) dma_b32(rvar, o4[hf], lds_var + (cj + 64u * hf) * 4u);
     }
     if (tail_lane) {
       dma_b128(rin, o16[kShHalves], lds_col + (cj + 64u * kShHalves) * 16u);
@@ -502,6 +508,7 @@ void k_atrous_comb_sh(AtrousArgs a) {
         dma_b128(rnrm, o16[kShHalves], lds_ids + (cj + 64u * kShHalves) * 16u);
       else
         dma_b32(rvis, o4[kShHalves], lds_ids + (cj + 64u * kShHalves) * 4u);
+      if (use_var) dma_b32(rvar, o4[kShHalves], lds_var + (cj + 64u * kShHalves) * 4u);
     }
   }
 #if RTPT_COMB_PRIO
@@ -567,7 +574,11 @@ void k_atrous_comb_sh(AtrousArgs a) {
         hc = xyz(a.history[static_cast<size_t>(ppy - a.hist_row_base) * W + ppx]);
     }
     f3 num{0.f, 0.f, 0.f};
-    float den = 0.f;
+    float den = 0.f, vsum = 0.f;
+    // variance guidance (k_atrous_ext's arithmetic): the colour term compares luminances, scaled by the pixel's own deviation
+    const float lum_p = use_var ? luminance(cp) : 0.0f;
+    const float lum_scale = use_var ? fmaf_(a.sigma_l, exact::sqrt_(glsl_max(varp[cc], 0.0f)), 1e-4f) : 1.0f;
+    const float cl_var = -1.44269504088896341f * fast::rcp_(lum_scale);
 #pragma unroll
     for (int i = -R; i <= R; i++) {  // :132 (x offset outer: the reference's accumulation order)
 #pragma unroll
@@ -591,11 +602,13 @@ void k_atrous_comb_sh(AtrousArgs a) {
           const f3 dc = cp - cq;
           if (EXACT) {
             const float wd = exact::exp_(-__builtin_fabsf(dp - dq) / a.sigma_z);  // :67-68
-            const float wl = exact::exp_(-exact::length(dc) / a.sigma_l);         // :73
+            const float wl = (EXTA && use_var) ? exact::exp_(-__builtin_fabsf(lum_p - luminance(cq)) / lum_scale)
+                                               : exact::exp_(-exact::length(dc) / a.sigma_l);         // :73
             w = (wn * wd) * wl;                                                   // :77
           } else {
             // exp(-|dz|/sz) * exp(-|dc|/sl) = exp2(|dz| * cz + |dc| * cl), cz/cl = -log2(e)/sigma
-            const float e = fmaf_(__builtin_fabsf(dp - dq), a.cz, fast::sqrt_(exact::dot(dc, dc)) * a.cl);
+            const float dl = (EXTA && use_var) ? __builtin_fabsf(lum_p - luminance(cq)) * cl_var : fast::sqrt_(exact::dot(dc, dc)) * a.cl;
+            const float e = fmaf_(__builtin_fabsf(dp - dq), a.cz, dl);
             w = wn * __builtin_amdgcn_exp2f(e);
           }
         }
@@ -607,6 +620,7 @@ void k_atrous_comb_sh(AtrousArgs a) {
           const float hw = hh * w;
           num = f3{fmaf_(hw, cq.x, num.x), fmaf_(hw, cq.y, num.y), fmaf_(hw, cq.z, num.z)};  // :146
           den = den + hw;                                                                    // :147
+          if (use_var) vsum = fmaf_(hw * hw, varp[cc + jj * CWp + i * k], vsum);
         } else if (EXACT) {
           const float hw = h * w;
           num = f3{fmaf_(hw, cq.x, num.x), fmaf_(hw, cq.y, num.y), fmaf_(hw, cq.z, num.z)};  // :146
@@ -624,6 +638,7 @@ void k_atrous_comb_sh(AtrousArgs a) {
     } else {
       filtered = num * fast::rcp_(den);
     }
+    if (EXTA && use_var && a.var_out) a.var_out[ip] = vsum / (den * den);
     if (!FINAL) {
 #if RTPT_COMB_NT_STORE
       {
@@ -654,10 +669,24 @@ void k_atrous_comb_sh(AtrousArgs a) {
     }
     if (a.prev_pixel) a.prev_pixel[ip] = make_int2(ppx, ppy);
     f3 blend = filtered;  // :258
-    if (a.frame > 0) {    // :251
-      const float oma = 1.0f - a.alpha;
-      blend = f3{fmaf_(filtered.x, a.alpha, hc.x * oma), fmaf_(filtered.y, a.alpha, hc.y * oma),
-                 fmaf_(filtered.z, a.alpha, hc.z * oma)};  // :254
+    bool use_history = a.frame > 0;  // :251
+    float alpha = a.alpha;
+    if (EXTA) {  // the final pass of the extension modes (k_atrous_ext's epilogue)
+      if (use_history && (a.ext & kExtDisocclusion)) {
+        // same primitive at the reprojected pixel; rows this context does not hold count as disoccluded
+        const bool inside = ppx >= 0 && ppx < W && ppy >= 0 && ppy < H;
+        use_history = inside && ppy >= a.pvis_y0 && ppy < a.pvis_y1 &&
+                      a.prev_vis[static_cast<size_t>(ppy - a.pvis_row_base) * W + ppx] == idp;
+      }
+      if (a.ext & kExtAdaptiveAlpha) {  // :247-248
+        const float g = a.gradient[ip].x;
+        alpha = fmaf_(1.0f - g, alpha, g);
+      }
+    }
+    if (use_history) {
+      const float oma = 1.0f - alpha;
+      blend = f3{fmaf_(filtered.x, alpha, hc.x * oma), fmaf_(filtered.y, alpha, hc.y * oma),
+                 fmaf_(filtered.z, alpha, hc.z * oma)};  // :254
     }
 #if RTPT_COMB_NT_STORE > 1
     {
@@ -722,23 +751,27 @@ static hipError_t comb_attrs() {
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, false, NRM>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
   return e;
 }
-template <int CW, int RR>
+template <int CW, int RR, bool VV>
 static hipError_t comb_ext_attrs() {
   constexpr int kMax = 160 * 1024;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, true, false, RR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, false, false, RR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, true, false, RR, true, VV>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, false, false, false, RR, true, VV>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, true, true, false, RR, true, VV>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_comb_sh<CW, true, false, false, RR, true, VV>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
   return e;
 }
 hipError_t prepare_device_atrous() {
   {
-    hipError_t e = comb_ext_attrs<72, 1>();
-    if (e == hipSuccess) e = comb_ext_attrs<80, 1>();
-    if (e == hipSuccess) e = comb_ext_attrs<96, 1>();
-    if (e == hipSuccess) e = comb_ext_attrs<128, 1>();
-    if (e == hipSuccess) e = comb_ext_attrs<72, 2>();
-    if (e == hipSuccess) e = comb_ext_attrs<80, 2>();
-    if (e == hipSuccess) e = comb_ext_attrs<96, 2>();
-    if (e == hipSuccess) e = comb_ext_attrs<128, 2>();
+    hipError_t e = comb_ext_attrs<72, 1, false>();
+    if (e == hipSuccess) e = comb_ext_attrs<96, 1, false>();
+    if (e == hipSuccess) e = comb_ext_attrs<72, 2, false>();
+    if (e == hipSuccess) e = comb_ext_attrs<96, 2, false>();
+    if (e == hipSuccess) e = comb_ext_attrs<128, 2, false>();
+    if (e == hipSuccess) e = comb_ext_attrs<72, 1, true>();
+    if (e == hipSuccess) e = comb_ext_attrs<96, 1, true>();
+    if (e == hipSuccess) e = comb_ext_attrs<72, 2, true>();
+    if (e == hipSuccess) e = comb_ext_attrs<96, 2, true>();
+    if (e == hipSuccess) e = comb_ext_attrs<128, 2, true>();
     if (e != hipSuccess) return e;
   }
   constexpr int b = kBlockX * kShHalves;
@@ -753,11 +786,20 @@ hipError_t prepare_device_atrous() {
 
 // true when a FINAL launch of `a` runs in the LDS-staged kernel, whose epilogue can also write the swapchain format
 // (AtrousArgs::present); every other final variant leaves the blit to k_present
+// the extension modes run LDS-staged (k_atrous_comb_sh<..., R, EXTA>) when the scene has an id-pair table and the halo
+// 2 R s fits the widest staged row: every flag combination, final pass included (round 3; before: tap shapes of k < N only)
+static bool ext_staged(const AtrousArgs& a) {
+  const int np = static_cast<int>(a.n_tris) + 1;
+  const int R = (a.ext & kExtGauss5) ? 2 : 1;
+  // staged row strides instantiated: 72 / 96 for 3x3 taps (strides <= 16), 72 / 96 / 128 for 5x5 taps
+  return a.ext && !a.direct && a.pair_tab && np <= kPairMax && a.stride >= 1 && kBlockX + 2 * R * a.stride <= (R == 1 ? 96 : 128);
+}
 bool atrous_final_fuses_present(const AtrousArgs& a) {
   const int np = static_cast<int>(a.n_tris) + 1;
   const bool pair_mode = a.pair_tab && np <= kPairMax;
   const bool nrm_mode = !pair_mode && a.normals != nullptr;
-  return !a.ext && !a.direct && (pair_mode || nrm_mode) && a.k >= 1 && a.k <= 16;
+  if (a.ext) return ext_staged(a);
+  return !a.direct && (pair_mode || nrm_mode) && a.k >= 1 && a.k <= 16;
 }
 
 void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
@@ -768,12 +810,11 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
   dim3 block(kBlockX, kBlockY);
   const int np = static_cast<int>(a.n_tris) + 1;
   {
-    // the tap-shape extensions (5x5 taps, 2^(k-1) stride) of a non-final pass run LDS-staged when the scene has an
-    // id-pair table and the halo 2*R*s fits the widest staged row; everything else that is an extension mode (variance
-    // guidance, the final pass's adaptive alpha / disocclusion test) stays in the generic direct-load kernel
+    // the extension modes run LDS-staged when the scene has an id-pair table and the halo 2*R*s fits a staged row the
+    // kernel is instantiated for — tap shapes, variance guidance and the final pass's adaptive alpha / disocclusion test
+    // alike (round 3); what does not fit runs in the generic direct-load kernel k_atrous_ext (same arithmetic)
     const int R = (a.ext & kExtGauss5) ? 2 : 1, sk = a.stride;
-    const bool taps_only = (a.ext & (kExtGauss5 | kExtPow2Stride)) && !(a.ext & kExtVariance) && !final_pass;
-    if (taps_only && !a.direct && a.pair_tab && np <= kPairMax && sk >= 1 && kBlockX + 2 * R * sk <= 128) {
+    if (ext_staged(a)) {
       const int seg_w = kBlockX;
       a.tiles_x = (a.g.W + seg_w - 1) / seg_w;
       const int nrows = a.g.y1 - a.g.y0;
@@ -782,32 +823,42 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
       const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
       const uint32_t nlb = static_cast<uint32_t>(a.tiles_x) * static_cast<uint32_t>(a.tiles_y) * static_cast<uint32_t>(sk);
       const int need = seg_w + 2 * R * sk;
-      const int cw = need <= 72 ? 72 : (need <= 80 ? 80 : (need <= 96 ? 96 : 128));
-      const size_t lds = static_cast<size_t>((np * np * 4 + 15) & ~15) + static_cast<size_t>(kShWaves * kCombM + 2 * R) * cw * 20;
+      const int cw = need <= 72 ? 72 : (need <= 96 ? 96 : 128);  // staged row strides the kernel is instantiated for
+      const bool use_var = (a.ext & kExtVariance) && a.var_in;
+      const size_t lds = static_cast<size_t>((np * np * 4 + 15) & ~15) + static_cast<size_t>(kShWaves * kCombM + 2 * R) * cw * (use_var ? 24 : 20);
       uint32_t per_cu = static_cast<uint32_t>((160u * 1024u) / lds);
       if (per_cu > 32u / kShWaves) per_cu = 32u / kShWaves;
       if (per_cu < 1u) per_cu = 1u;
       uint32_t per_xcd = static_cast<uint32_t>((n_cu + 7) / 8) * per_cu;
       if (per_xcd > (nlb + 7) / 8) per_xcd = (nlb + 7) / 8;
       const dim3 grid(per_xcd * 8u), sblock(kBlockX, kShWaves);
-#define RTPT_LAUNCH_EXT(CW, RR)                                                                                     \
+#define RTPT_LAUNCH_EXT(CW, RR, VV)                                                                                 \
   do {                                                                                                              \
-    if (a.exact)                                                                                                    \
-      hipLaunchKernelGGL((k_atrous_comb_sh<CW, false, true, false, RR, true>), grid, sblock, lds, s, a);           \
+    if (final_pass) {                                                                                               \
+      if (a.exact)                                                                                                  \
+        hipLaunchKernelGGL((k_atrous_comb_sh<CW, true, true, false, RR, true, VV>), grid, sblock, lds, s, a);      \
+      else                                                                                                          \
+        hipLaunchKernelGGL((k_atrous_comb_sh<CW, true, false, false, RR, true, VV>), grid, sblock, lds, s, a);     \
+    } else if (a.exact)                                                                                             \
+      hipLaunchKernelGGL((k_atrous_comb_sh<CW, false, true, false, RR, true, VV>), grid, sblock, lds, s, a);       \
     else                                                                                                            \
-      hipLaunchKernelGGL((k_atrous_comb_sh<CW, false, false, false, RR, true>), grid, sblock, lds, s, a);          \
+      hipLaunchKernelGGL((k_atrous_comb_sh<CW, false, false, false, RR, true, VV>), grid, sblock, lds, s, a);      \
   } while (0)
-#define RTPT_LAUNCH_EXT_CW(RR)                   \
-  do {                                           \
-    if (cw == 72) RTPT_LAUNCH_EXT(72, RR);       \
-    else if (cw == 80) RTPT_LAUNCH_EXT(80, RR);  \
-    else if (cw == 96) RTPT_LAUNCH_EXT(96, RR);  \
-    else RTPT_LAUNCH_EXT(128, RR);               \
+#define RTPT_LAUNCH_EXT_CW(RR, VV)                   \
+  do {                                               \
+    if (cw == 72) RTPT_LAUNCH_EXT(72, RR, VV);       \
+    else if (cw == 96) RTPT_LAUNCH_EXT(96, RR, VV);  \
+    else RTPT_LAUNCH_EXT(128, RR, VV);               \
   } while (0)
-      if (R == 2)
-        RTPT_LAUNCH_EXT_CW(2);
-      else
-        RTPT_LAUNCH_EXT_CW(1);
+      if (R == 2) {
+        if (use_var) RTPT_LAUNCH_EXT_CW(2, true); else RTPT_LAUNCH_EXT_CW(2, false);
+      } else if (cw <= 96) {  // R == 1: 64 + 2 s <= 96 for every stride the staged kernel takes (s <= 16)
+        if (use_var) {
+          if (cw == 72) RTPT_LAUNCH_EXT(72, 1, true); else RTPT_LAUNCH_EXT(96, 1, true);
+        } else {
+          if (cw == 72) RTPT_LAUNCH_EXT(72, 1, false); else RTPT_LAUNCH_EXT(96, 1, false);
+        }
+      }
 #undef RTPT_LAUNCH_EXT_CW
 #undef RTPT_LAUNCH_EXT
       return;

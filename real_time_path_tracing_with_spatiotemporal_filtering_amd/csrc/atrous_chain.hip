@@ -665,6 +665,10 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, hipS
   if (per_cu > 32 / waves) per_cu = 32 / waves;
   if (per_cu < 1) per_cu = 1;
   const int rows = a.g.y1 - a.g.y0;
+  if (const char* e = std::getenv("RTPT_CHAIN_WG_PER_CU")) {  // A/B: workgroups per CU the row segments are sized for
+    const int v = std::atoi(e);
+    if (v >= 1 && v < per_cu) per_cu = v;
+  }
   int n_segs = (n_cu * per_cu) / a.n_strips;
   if (n_segs < 1) n_segs = 1;
   int seg_rows = (rows + n_segs - 1) / n_segs;

@@ -148,8 +148,11 @@ __device__ __forceinline__ void closest_hit_brute(const SceneView& sc, f3 o, f3 
 #define RTPT_BRUTE_UNROLL 8  // triangles whose records are fetched per batch of scalar loads; K2 at 4K: 2: 517, 4: 505, 8: 499, 16: 498 us
 #endif
 #if RTPT_TRI_XOR_SIGN
+#ifndef RTPT_PAIR_UNROLL
+#define RTPT_PAIR_UNROLL 8  // faces whose records are fetched per batch of scalar loads; K2 at 4K: 2: 384.7, 4: 378.1, 8: 376.3, 16: 376.0 us
+#endif
   if (sc.paired) {  // wave-uniform
-#pragma unroll 4
+#pragma unroll RTPT_PAIR_UNROLL
     for (uint32_t i = 0; i < n; i += 2) {
       const v4f a0 = rec[3 * i], a1 = rec[3 * i + 1], a2 = rec[3 * i + 2], b1 = rec[3 * i + 4], b2 = rec[3 * i + 5];
       tri_pair_test(o, d, make_float4(a0.x, a0.y, a0.z, a0.w), make_float4(a1.x, a1.y, a1.z, a1.w), make_float4(a2.x, a2.y, a2.z, a2.w),

@@ -840,12 +840,13 @@ def test_present_through_the_app_incl_two_frames_in_flight(hip_lib, oracle, corn
 
 def test_fused_blit_equals_the_separate_blit(hip_lib, oracle, cornell):
     """rtpt_present_target: the final filter pass writes the swapchain rows itself (LDS-staged final kernel) and the later
-    rtpt_present returns at once; same bytes as the separate k_present.  Variants that cannot fuse (an extension mode's final
-    pass, the direct-load kernels) leave the work to rtpt_present — same calls, same bytes.  Timing hooks tell which ran."""
+    rtpt_present returns at once; same bytes as the separate k_present.  Variants that cannot fuse (the direct-load kernels,
+    RTPT_FLAG_DIRECT_FILTER) leave the work to rtpt_present — same calls, same bytes.  Timing hooks tell which ran."""
     import torch
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
     w, h = 333, 170
-    for flags, fused in ((0, True), (hip_lib.FLAG_EXACT_FILTER, True), (0x4, False), (hip_lib.FLAG_EXT_ADAPTIVE_ALPHA, False)):
+    for flags, fused in ((0, True), (hip_lib.FLAG_EXACT_FILTER, True), (0x4, False), (hip_lib.FLAG_EXT_ADAPTIVE_ALPHA, True),
+                         (hip_lib.FLAG_EXT_ADAPTIVE_ALPHA | 0x4, False)):
         app = make_app(w, h, max_segments=3, iterations=5, flags=flags)
         ctx = app.backend.ctx
         ctx.timing_enable(1)
