@@ -295,7 +295,9 @@ class PipelinedBackend:
         self.prev.present_rows(image8, y0, y1)
 
     def present_target(self, image8, y0, y1):   # called while the frame is being built: its backend is `cur`
-        self.cur.present_target(image8, y0, y1)
+        fn = getattr(self.cur, "present_target", None)   # optional in the backend protocol (the fused blit is a shortcut)
+        if fn:
+            fn(image8, y0, y1)
 
     def final_rows(self, y0, y1):
         return self.prev.final_rows(y0, y1)
