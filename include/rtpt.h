@@ -128,6 +128,14 @@ typedef struct rtpt_visibility_data {
                                               frame's id and moment rows the strip can reach from the other strips
                                               (rtpt_set_external_guides) like it does for the history image. */
 
+#define RTPT_FLAG_EXT_SVGF_VARIANCE 0x800u /* with RTPT_FLAG_EXT_VARIANCE (required), the two pieces of SVGF's variance handling
+                                              (Schied et al. 2017) that flag leaves out: a pixel whose moment history is shorter
+                                              than 4 frames takes its variance from the 7x7 neighbourhood of the current frame's
+                                              luminance (taps on the same primitive only) instead of the temporal estimate, still
+                                              scaled by 4/n; and the variance that scales an iteration's luminance weight is the 3x3
+                                              Gaussian (1 2 1 / 2 4 2 / 1 2 1) / 16 of the variance plane around the pixel.
+                                              Whole-frame contexts only. */
+
 typedef struct rtpt_config {
   uint32_t struct_size;          /* = sizeof(rtpt_config), ABI guard */
   uint32_t width, height;        /* full frame; main.cpp:52-53 (1000x800) */

@@ -34,6 +34,7 @@ class OracleConfig(C.Structure):
 
 
 EXT_ADAPTIVE_ALPHA, EXT_GAUSS5, EXT_POW2_STRIDE, EXT_DISOCCLUSION, EXT_VARIANCE = 0x10, 0x20, 0x40, 0x80, 0x100
+EXT_SVGF_VARIANCE = 0x800
 
 
 class PushConstants(C.Structure):
@@ -241,6 +242,14 @@ def moments(cfg, pc: PushConstants, ubo: Ubo, traced, vis, worldpos, lut_prev, p
     lib().oracle_moments(C.byref(cfg), C.byref(pc), C.byref(ubo), _p(traced), _p(vis), _p(worldpos), _p(lut_prev),
                          _p(prev_vis), _p(moments_prev), C.c_uint32(y0), C.c_uint32(y1), _p(mo), _p(var))
     return mo, var
+
+
+def var_prefilter(cfg, var: np.ndarray) -> np.ndarray:
+    """EXT_SVGF_VARIANCE: the 3x3 Gaussian of the variance plane that scales an iteration's luminance weight"""
+    var = np.ascontiguousarray(var, np.float32)
+    out = np.zeros_like(var)
+    lib().oracle_var_prefilter(C.byref(cfg), _p(var), C.c_uint32(0), C.c_uint32(cfg.height), _p(out))
+    return out
 
 
 def atrous(cfg, pc: PushConstants, ubo: Ubo, img_in, depth, vis, lut_, lut_prev, worldpos, history,

@@ -727,7 +727,28 @@ static void moments_rows(const oracle_config* cfg, const oracle_push_constants* 
         n = dm_min(mp[2] + 1.0f, 255.0f);
       }
       float var = dm_max(0.0f, dm_fma(-m1, m1, m2));
-      if (n < 4.0f) var = var * (4.0f / n);
+      if (n < 4.0f) {
+        if (cfg->ext_flags & ORACLE_EXT_SVGF_VARIANCE) {
+          /* SVGF: too short a history says nothing about the variance yet — estimate it spatially, from the current
+           * frame's luminance over the 7x7 neighbourhood, taps on the same primitive only (the centre always counts) */
+          float s1 = 0.0f, s2 = 0.0f, cnt = 0.0f;
+          for (int dy = -3; dy <= 3; dy++)
+            for (int dx = -3; dx <= 3; dx++) {
+              int qx = x + dx, qy = y + dy;
+              qx = qx < 0 ? 0 : (qx > W - 1 ? W - 1 : qx);
+              qy = qy < 0 ? 0 : (qy > H - 1 ? H - 1 : qy);
+              uint64_t iqn = (uint64_t)qy * W + qx;
+              if (vis[iqn] != id) continue;
+              float l = luminance(v3(traced[4 * iqn], traced[4 * iqn + 1], traced[4 * iqn + 2]));
+              s1 = s1 + l;
+              s2 = dm_fma(l, l, s2);
+              cnt = cnt + 1.0f;
+            }
+          float m1s = s1 / cnt, m2s = s2 / cnt;
+          var = dm_max(0.0f, dm_fma(-m1s, m1s, m2s));
+        }
+        var = var * (4.0f / n);
+      }
       float* mo = moments_out + 4 * ip;
       mo[0] = m1; mo[1] = m2; mo[2] = n; mo[3] = var;
       var_out[ip] = var;
@@ -756,6 +777,25 @@ static void moments_range(void* ctx, int64_t a, int64_t b) {
 void oracle_moments(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo, const float* traced, const uint32_t* vis, const float* worldpos, const float* lut_prev, const uint32_t* prev_vis, const float* moments_prev, uint32_t y0, uint32_t y1, float* moments_out, float* var_out) {
   moments_args A = {cfg, pc, ubo, traced, vis, worldpos, lut_prev, prev_vis, moments_prev, moments_out, var_out};
   run_ranges((int64_t)y0, (int64_t)y1, 4, moments_range, &A);
+}
+
+/* ORACLE_EXT_SVGF_VARIANCE (ii): 3x3 Gaussian of the variance plane around (x, y), frame-clamped */
+static inline float var_prefilter_at(const float* var, int W, int H, int x, int y) {
+  static const float g[3][3] = {{1.f, 2.f, 1.f}, {2.f, 4.f, 2.f}, {1.f, 2.f, 1.f}};
+  float acc = 0.0f;
+  for (int dy = -1; dy <= 1; dy++)
+    for (int dx = -1; dx <= 1; dx++) {
+      int qx = x + dx, qy = y + dy;
+      qx = qx < 0 ? 0 : (qx > W - 1 ? W - 1 : qx);
+      qy = qy < 0 ? 0 : (qy > H - 1 ? H - 1 : qy);
+      acc = dm_fma(g[dy + 1][dx + 1], var[(uint64_t)qy * W + qx], acc);
+    }
+  return acc * 0.0625f;
+}
+void oracle_var_prefilter(const oracle_config* cfg, const float* var, uint32_t y0, uint32_t y1, float* out) {
+  const int W = (int)cfg->width, H = (int)cfg->height;
+  for (int y = (int)y0; y < (int)y1; y++)
+    for (int x = 0; x < W; x++) out[(uint64_t)y * W + x] = var_prefilter_at(var, W, H, x, y);
 }
 
 /* gaussianKernel2D, temporalFiltering.comp.glsl:93-99 (sum 273) */
@@ -805,7 +845,8 @@ static void atrous_var_rows(const oracle_config* cfg, const oracle_push_constant
       vec3 num = v3(0.f, 0.f, 0.f);
       float den = 0.f, vsum = 0.f;
       const float lum_p = luminance(cp);
-      const float lum_scale = use_var ? dm_fma(cfg->sigma_l, dm_sqrt(dm_max(var_in[ip], 0.0f)), 1e-4f) : 1.0f;
+      const float var_c = !use_var ? 0.0f : ((ext & ORACLE_EXT_SVGF_VARIANCE) ? var_prefilter_at(var_in, W, H, x, y) : var_in[ip]);
+      const float lum_scale = use_var ? dm_fma(cfg->sigma_l, dm_sqrt(dm_max(var_c, 0.0f)), 1e-4f) : 1.0f;
       for (int i = -R; i <= R; i++)     /* :132 (-1..1; -2..2 with the 5x5 table) */
         for (int j = -R; j <= R; j++) { /* :133 */
           int qx = x + i * k, qy = y + j * k; /* :135 */

@@ -40,6 +40,12 @@ typedef struct oracle_config {
 #define ORACLE_EXT_VARIANCE 0x100u      /* SVGF-style luminance moments: temporally accumulated first and second moments
                                            of the traced luminance give a per-pixel variance that scales the colour
                                            edge-stopping term and is filtered along (see oracle_moments) */
+#define ORACLE_EXT_SVGF_VARIANCE 0x800u /* with ORACLE_EXT_VARIANCE, the two pieces of SVGF's variance handling (Schied et al. 2017)
+                                          the flag above leaves out: (i) a pixel whose moment history is shorter than 4 frames
+                                          takes its variance from the 7x7 neighbourhood of the CURRENT frame's luminance (taps on
+                                          the same primitive only) instead of the temporal one, still scaled by 4/n; (ii) the
+                                          variance that scales an iteration's luminance weight is the 3x3 Gaussian
+                                          (1 2 1 / 2 4 2 / 1 2 1) / 16 of the variance plane around the pixel, not its own value */
 #define ORACLE_EXT_DISOCCLUSION 0x80u   /* previousVisibilityBuffer (main.cpp:375,:1367: copied every frame, never read):
                                            history is used only where the reprojected pixel showed the same primitive */
 
@@ -147,6 +153,9 @@ void oracle_moments(const oracle_config* cfg, const oracle_push_constants* pc, c
 /* oracle_atrous_ext with the variance planes: with ORACLE_EXT_VARIANCE the colour term of the weight becomes
  *   exp(-|lum_p - lum_q| / (sigma_l * sqrt(var_in[p]) + 1e-4))
  * and var_out[p] = sum((h w)^2 var_in[q]) / (sum(h w))^2 is filtered along.  var_in / var_out may be NULL otherwise. */
+/* ORACLE_EXT_SVGF_VARIANCE (ii): out[p] = sum_{dy,dx in -1..1} g[dy][dx] var[clamp(p + (dx,dy))] / 16, dy outer, dx inner, fma
+ * accumulation from 0, then * 0.0625 */
+void oracle_var_prefilter(const oracle_config* cfg, const float* var, uint32_t y0, uint32_t y1, float* out);
 void oracle_atrous_var(const oracle_config* cfg, const oracle_push_constants* pc, const oracle_ubo* ubo,
                        const float* in, const float* depth, const uint32_t* vis, const float* lut,
                        const float* lut_prev, const float* worldpos, const float* history,

@@ -24,7 +24,8 @@ FLAG_EXT_ADAPTIVE_ALPHA, FLAG_EXT_GAUSS5, FLAG_EXT_POW2_STRIDE, FLAG_EXT_DISOCCL
 FLAG_EXT_VARIANCE = 0x100
 FLAG_SINGLE_LAUNCH_PATHS = 0x200
 FLAG_NO_FILTER_FUSION = 0x400
-FLAG_EXT_MASK = 0x1F0
+FLAG_EXT_SVGF_VARIANCE = 0x800
+FLAG_EXT_MASK = 0x9F0
 DEBUG_HIT_ID, DEBUG_PREV_PIXEL = 0x1, 0x2
 
 # rtpt_plane

@@ -633,6 +633,9 @@ def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode=
     """createBuffers + loadMesh + buildAccelerationStructure for one rank.  `mesh` = (xyz, idx) replaces
     the OBJ (synthetic scenes of scenes.py)."""
     plan = StripPlan(height, world, rank, iterations, mode, flags & abi.FLAG_EXT_MASK)
+    if world > 1 and (flags & abi.FLAG_EXT_SVGF_VARIANCE):
+        raise ValueError("RTPT_FLAG_EXT_SVGF_VARIANCE needs a whole-frame context (its 7x7 spatial estimate reads traced rows a "
+                         "strip does not hold)")
     if torch_planes is None:
         torch_planes = world > 1  # halo exchange and the history all-gather move rows of torch-owned planes
     def one():

@@ -71,6 +71,7 @@ struct rtpt_ctx {
   int lut_cur = 0;
   Buf worldpos, gradient, depth, prev_pixel, hit_id, raycount, normal_tab, pair_tab;
   Buf moments[2], variance[2];  // RTPT_FLAG_EXT_VARIANCE
+  Buf var_scale;                // RTPT_FLAG_EXT_SVGF_VARIANCE: the prefiltered variance of the iteration being launched
   Buf path_queue[2], path_queue_count;  // long paths: survivors handed from one k_pathtrace launch to the next
   Buf normals;                  // per-pixel normal plane for the LDS-staged filter of scenes without an id-pair table
   int normals_y0 = 0, normals_y1 = 0;  // rows for which it matches VIS_ID
@@ -434,6 +435,7 @@ static int alloc_planes(rtpt_ctx* c) {
     }
     c->moments_cur = 0;
     c->variance_last = 0;
+    if (rc == RTPT_OK && (c->cfg.flags & RTPT_FLAG_EXT_SVGF_VARIANCE)) rc = alloc_buf(c->var_scale, px * 4);
   }
   if (rc == RTPT_OK && (c->debug_mask & RTPT_DEBUG_HIT_ID)) rc = alloc_buf(c->hit_id, px * 4);
   if (rc == RTPT_OK && (c->debug_mask & RTPT_DEBUG_PREV_PIXEL)) rc = alloc_buf(c->prev_pixel, px * 8);
@@ -474,6 +476,10 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
     return fail(RTPT_E_INVALID, "bad frame / row range");
   if (cfg->max_segments == 0 || cfg->samples_per_pixel == 0 || cfg->sigma_n < 1)
     return fail(RTPT_E_INVALID, "max_segments, samples_per_pixel and sigma_n must be >= 1");
+  if ((cfg->flags & RTPT_FLAG_EXT_SVGF_VARIANCE) && !(cfg->flags & RTPT_FLAG_EXT_VARIANCE))
+    return fail(RTPT_E_INVALID, "RTPT_FLAG_EXT_SVGF_VARIANCE completes RTPT_FLAG_EXT_VARIANCE: set both");
+  if ((cfg->flags & RTPT_FLAG_EXT_SVGF_VARIANCE) && (cfg->row_begin != 0 || cfg->row_end != cfg->height))
+    return fail(RTPT_E_INVALID, "RTPT_FLAG_EXT_SVGF_VARIANCE needs a whole-frame context (its 7x7 estimate reads traced rows a strip does not hold)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
@@ -544,6 +550,7 @@ int rtpt_destroy(rtpt_ctx* c) {
   for (auto& b : c->path_queue) free_buf(b);
   for (auto& b : c->moments) free_buf(b);
   for (auto& b : c->variance) free_buf(b);
+  free_buf(c->var_scale);
   for (auto& b : c->lut) free_buf(b);
   for (Buf* b : {&c->worldpos, &c->gradient, &c->depth, &c->prev_pixel, &c->hit_id, &c->raycount, &c->normal_tab, &c->pair_tab, &c->tris,
                  &c->leaf_order, &c->isect_id, &c->isect_leaf, &c->shade, &c->nodes, &c->materials, &c->obj_tris_dev, &c->refit_order,
@@ -1336,6 +1343,7 @@ int filter_launch(rtpt_ctx* c, const FilterCall& f, int levels) {
         m.hist_row_base = m.hist_y0 = c->ext_guides_y0;
         m.hist_y1 = c->ext_guides_y1;
       }
+      m.svgf = (ext & rt::kExtSvgfVariance) ? 1 : 0;
       m.moments_out = static_cast<float4*>(c->moments[c->moments_cur].ptr);
       m.var_out = static_cast<float*>(c->variance[0].ptr);
       rt::launch_moments(m, c->stream);
@@ -1344,6 +1352,10 @@ int filter_launch(rtpt_ctx* c, const FilterCall& f, int levels) {
     a.var_in = static_cast<const float*>(c->variance[c->variance_last].ptr);
     a.var_out = static_cast<float*>(c->variance[c->variance_last ^ 1].ptr);
     c->variance_last ^= 1;
+    if ((ext & rt::kExtSvgfVariance) && c->var_scale.ptr) {  // SVGF's variance prefilter: the centre's scale only
+      rt::launch_var_prefilter(geom(c, y0, y1), a.var_in, static_cast<float*>(c->var_scale.ptr), c->stream);
+      a.var_scale = static_cast<const float*>(c->var_scale.ptr);
+    }
   }
   if (final_pass) c->present_fused_dst = nullptr;  // a new frame's final pass: the previous frame's blit is history
   if (final_pass && levels == 1 && c->present_dst && static_cast<int>(y0) <= c->present_y0 && static_cast<int>(y1) >= c->present_y1 &&

@@ -223,9 +223,52 @@ __global__ __launch_bounds__(kThreads) void k_moments(MomentsArgs a) {
     n = glsl_min(mp.z + 1.0f, 255.0f);
   }
   float var = glsl_max(0.0f, fmaf_(-m1, m1, m2));
-  if (n < 4.0f) var = var * (4.0f / n);
+  if (n < 4.0f) {
+    if (a.svgf) {
+      // SVGF: a history this short says nothing about the variance yet — estimate it from the current frame's luminance
+      // over the 7x7 neighbourhood, taps on the same primitive only (the centre always counts); rows the context does
+      // not hold are clamped like the frame border (whole-frame contexts only: rtpt_create refuses the flag on strips)
+      float s1 = 0.0f, s2 = 0.0f, cnt = 0.0f;
+      for (int dy = -3; dy <= 3; dy++)
+        for (int dx = -3; dx <= 3; dx++) {
+          int qx = x + dx, qy = y + dy;
+          qx = qx < 0 ? 0 : (qx > W - 1 ? W - 1 : qx);
+          qy = qy < 0 ? 0 : (qy > H - 1 ? H - 1 : qy);
+          const size_t iqn = static_cast<size_t>(qy - a.g.row_base) * W + qx;
+          if (a.vis[iqn] != id) continue;
+          const float l = luminance(xyz(a.traced[iqn]));
+          s1 = s1 + l;
+          s2 = fmaf_(l, l, s2);
+          cnt = cnt + 1.0f;
+        }
+      const float m1s = s1 / cnt, m2s = s2 / cnt;
+      var = glsl_max(0.0f, fmaf_(-m1s, m1s, m2s));
+    }
+    var = var * (4.0f / n);
+  }
   a.moments_out[ip] = make_float4(m1, m2, n, var);
   a.var_out[ip] = var;
+}
+
+// RTPT_FLAG_EXT_SVGF_VARIANCE: the variance that scales an iteration's luminance weight is the 3x3 Gaussian of the variance
+// plane around the pixel (SVGF's variance prefilter), unit spacing whatever the iteration's stride: a pass of its own (8 B/px)
+// because the staged filter kernels hold rows k apart
+__global__ __launch_bounds__(kThreads) void k_var_prefilter(FrameGeom g, const float* __restrict__ var, float* __restrict__ out) {
+  const int x = blockIdx.x * kBlockX + threadIdx.x;
+  const int y = g.y0 + blockIdx.y * kBlockY + threadIdx.y;
+  if (x >= g.W || y >= g.y1) return;
+  float acc = 0.0f;
+#pragma unroll
+  for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+    for (int dx = -1; dx <= 1; dx++) {
+      int qx = x + dx, qy = y + dy;
+      qx = qx < 0 ? 0 : (qx > g.W - 1 ? g.W - 1 : qx);
+      qy = qy < 0 ? 0 : (qy > g.H - 1 ? g.H - 1 : qy);
+      const float gw = (dx == 0 ? 2.0f : 1.0f) * (dy == 0 ? 2.0f : 1.0f);
+      acc = fmaf_(gw, var[static_cast<size_t>(qy - g.row_base) * g.W + qx], acc);
+    }
+  out[static_cast<size_t>(y - g.row_base) * g.W + x] = acc * 0.0625f;
 }
 
 template <bool FINAL, bool EXACT>
@@ -252,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void k_atrous_ext(AtrousArgs a) {
   // standard deviation
   const bool use_var = (a.ext & kExtVariance) && a.var_in;
   const float lum_p = luminance(cp);
-  const float lum_scale = use_var ? fmaf_(a.sigma_l, exact::sqrt_(glsl_max(a.var_in[rowp + x], 0.0f)), 1e-4f) : 1.0f;
+  const float lum_scale = use_var ? fmaf_(a.sigma_l, exact::sqrt_(glsl_max((a.var_scale ? a.var_scale : a.var_in)[rowp + x], 0.0f)), 1e-4f) : 1.0f;
   const float cl_var = -1.44269504088896341f * fast::rcp_(lum_scale);
   for (int i = -R; i <= R; i++) {    // :132
     for (int j = -R; j <= R; j++) {  // :133
@@ -577,7 +620,7 @@ void k_atrous_comb_sh(AtrousArgs a) {
     float den = 0.f, vsum = 0.f;
     // variance guidance (k_atrous_ext's arithmetic): the colour term compares luminances, scaled by the pixel's own deviation
     const float lum_p = use_var ? luminance(cp) : 0.0f;
-    const float lum_scale = use_var ? fmaf_(a.sigma_l, exact::sqrt_(glsl_max(varp[cc], 0.0f)), 1e-4f) : 1.0f;
+    const float lum_scale = use_var ? fmaf_(a.sigma_l, exact::sqrt_(glsl_max(a.var_scale ? a.var_scale[ip] : varp[cc], 0.0f)), 1e-4f) : 1.0f;
     const float cl_var = -1.44269504088896341f * fast::rcp_(lum_scale);
 #pragma unroll
     for (int i = -R; i <= R; i++) {  // :132 (x offset outer: the reference's accumulation order)
@@ -727,6 +770,11 @@ __global__ __launch_bounds__(kThreads) void k_present(FrameGeom g, const float4*
 void launch_present(const FrameGeom& g, const float4* image, uint32_t* dst, hipStream_t s) {
   if (g.y1 <= g.y0) return;
   hipLaunchKernelGGL(k_present, grid_for(g), dim3(kBlockX, kBlockY), 0, s, g, image, dst);
+}
+
+void launch_var_prefilter(const FrameGeom& g, const float* var, float* out, hipStream_t s) {
+  if (g.y1 <= g.y0) return;
+  hipLaunchKernelGGL(k_var_prefilter, grid_for(g), dim3(kBlockX, kBlockY), 0, s, g, var, out);
 }
 
 void launch_moments(const MomentsArgs& a, hipStream_t s) {

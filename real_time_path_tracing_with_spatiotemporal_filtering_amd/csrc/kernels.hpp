@@ -177,6 +177,8 @@ struct AtrousArgs {
   // of the blended frame are also written as B8G8R8A8_UNORM to present (first byte = pixel (0, present_y0)); rtpt_present_target
   uint32_t* present;
   int32_t present_y0, present_y1;
+  const float* var_scale;         // RTPT_FLAG_EXT_SVGF_VARIANCE: the 3x3-prefiltered variance that scales the luminance weight of
+                                  // the centre pixel (k_var_prefilter of var_in); NULL: var_in's own value
   const float* var_in;            // RTPT_FLAG_EXT_VARIANCE: per-pixel luminance variance read by this iteration
   float* var_out;                 //                         ... and the filtered variance it writes
 };
@@ -194,10 +196,13 @@ struct MomentsArgs {
   const uint32_t* prev_vis;     // previous frame's ids and moments: frame rows [hist_y0, hist_y1), stored from hist_row_base
   const float4* moments_prev;
   int32_t hist_row_base, hist_y0, hist_y1;
+  int32_t svgf;         // RTPT_FLAG_EXT_SVGF_VARIANCE: spatial estimate for histories shorter than 4 frames
   float4* moments_out;  // (m1, m2, n, var)
   float* var_out;
 };
 void launch_moments(const MomentsArgs& a, hipStream_t s);
+// RTPT_FLAG_EXT_SVGF_VARIANCE: out = 3x3 Gaussian (1 2 1 / 2 4 2 / 1 2 1) / 16 of var, frame-clamped, rows [g.y0, g.y1)
+void launch_var_prefilter(const FrameGeom& g, const float* var, float* out, hipStream_t s);
 
 // Long paths: segments handled by the tile kernel before the survivors are queued; every later window is twice as
 // long.  Swept at 4K on the Cornell box (k_pathtrace, 8 / 16 / 32 segments; single launch 969 / 1627 / 2843 us):
@@ -222,7 +227,8 @@ constexpr uint32_t kRayCounters = 256;  // RAYCOUNT is kept as this many partial
 
 constexpr uint32_t kExtAdaptiveAlpha = 0x10u, kExtGauss5 = 0x20u, kExtPow2Stride = 0x40u, kExtDisocclusion = 0x80u;
 constexpr uint32_t kExtVariance = 0x100u;
-constexpr uint32_t kExtMask = 0x1F0u;
+constexpr uint32_t kExtSvgfVariance = 0x800u;  // with kExtVariance: spatial estimate for short histories + 3x3 prefilter
+constexpr uint32_t kExtMask = 0x9F0u;
 
 struct ScenePrepArgs {
   uint32_t n_tris;

@@ -30,7 +30,7 @@ def make_pair(hip_lib, oracle, cornell, w=W, h=H, seg=4, n=5, flags=0):
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
     app = make_app(w, h, max_segments=seg, iterations=n, flags=flags,
                    debug_mask=hip_lib.DEBUG_HIT_ID | hip_lib.DEBUG_PREV_PIXEL)
-    ref = oracle.OracleApp(w, h, cornell[2], max_segments=seg, iterations=n, ext_flags=flags & 0x1F0)
+    ref = oracle.OracleApp(w, h, cornell[2], max_segments=seg, iterations=n, ext_flags=flags & 0x9F0)
     return app, ref
 
 
@@ -171,10 +171,12 @@ def test_extension_modes_match_oracle(hip_lib, oracle, cornell, ext, exact):
             assert ok, f"ext {ext:#x}: filtered image outside FILTER_TOL: {rel}"
 
 
-@pytest.mark.parametrize("flags", [0x100, 0x101, 0x1F1])
+@pytest.mark.parametrize("flags", [0x100, 0x101, 0x1F1, 0x900, 0x901, 0x9F1, 0x905])
 def test_variance_extension_matches_oracle(hip_lib, oracle, cornell, flags):
-    """RTPT_FLAG_EXT_VARIANCE (alone, with exact arithmetic, and with every other extension): image, moments and
-    filtered variance against the oracle's restatement of the same definitions, over light and camera moves"""
+    """RTPT_FLAG_EXT_VARIANCE (alone, with exact arithmetic, and with every other extension) and its SVGF completion
+    RTPT_FLAG_EXT_SVGF_VARIANCE (0x800: 7x7 spatial estimate for short histories, 3x3 variance prefilter; staged and, with
+    0x4, direct-load kernels): image, moments and filtered variance against the oracle's restatement of the same
+    definitions, over light and camera moves"""
     exact = flags & 1
     app, ref = make_pair(hip_lib, oracle, cornell, w=96, h=72, n=3, flags=flags)
     ctx = app.backend.ctx
@@ -873,3 +875,27 @@ def test_fused_blit_equals_the_separate_blit(hip_lib, oracle, cornell):
         n_present = ctx.timing_collect()["k_present"][1]
         assert n_present == (3 if fused else 6), (hex(flags), n_present)
         app.backend.close()
+
+
+def test_svgf_variance_flag_rules_and_prefilter_known_answers(hip_lib, oracle):
+    """RTPT_FLAG_EXT_SVGF_VARIANCE completes RTPT_FLAG_EXT_VARIANCE (both must be set) and needs a whole-frame context;
+    the oracle's prefilter: a constant plane is a fixed point, an impulse spreads as (1 2 1 / 2 4 2 / 1 2 1) / 16, the frame
+    border clamps"""
+    cfg = hip_lib.config_default(64, 64)
+    cfg.flags = hip_lib.FLAG_EXT_SVGF_VARIANCE
+    with pytest.raises(hip_lib.RtptError):
+        hip_lib.Context(cfg)
+    cfg.flags = hip_lib.FLAG_EXT_SVGF_VARIANCE | hip_lib.FLAG_EXT_VARIANCE
+    cfg.row_begin, cfg.row_end = 8, 40
+    with pytest.raises(hip_lib.RtptError):
+        hip_lib.Context(cfg)
+    ocfg = oracle.config_default(7, 5)
+    assert np.array_equal(oracle.var_prefilter(ocfg, np.full((5, 7), 0.375, np.float32)), np.full((5, 7), 0.375, np.float32))
+    imp = np.zeros((5, 7), np.float32)
+    imp[2, 3] = 16.0
+    want = np.zeros((5, 7), np.float32)
+    want[1:4, 2:5] = [[1, 2, 1], [2, 4, 2], [1, 2, 1]]
+    assert np.array_equal(oracle.var_prefilter(ocfg, imp), want)
+    corner = np.zeros((5, 7), np.float32)
+    corner[0, 0] = 16.0
+    assert oracle.var_prefilter(ocfg, corner)[0, 0] == 9.0   # the clamped taps pile up on the corner: 4 + 2 + 2 + 1
