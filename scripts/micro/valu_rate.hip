@@ -39,6 +39,27 @@ __global__ void k(float* out, long long* clk, int iters, float a, float b) {
                      "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5"
                      : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(aa), "v"(bb));
         x0 = p0.x; x1 = p0.y; x2 = p1.x; x3 = p1.y; x4 = p2.x; x5 = p2.y; x6 = p3.x; x7 = p3.y;
+      } else if (KIND == 7) {  // v_div_fixup_f32
+        asm volatile("v_div_fixup_f32 %0, %0, %8, %9\n v_div_fixup_f32 %1, %1, %8, %9\n v_div_fixup_f32 %2, %2, %8, %9\n v_div_fixup_f32 %3, %3, %8, %9\n"
+                     "v_div_fixup_f32 %4, %4, %8, %9\n v_div_fixup_f32 %5, %5, %8, %9\n v_div_fixup_f32 %6, %6, %8, %9\n v_div_fixup_f32 %7, %7, %8, %9"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+      } else if (KIND == 8) {  // v_div_scale_f32 (writes vcc)
+        asm volatile("v_div_scale_f32 %0, vcc, %0, %8, %9\n v_div_scale_f32 %1, vcc, %1, %8, %9\n v_div_scale_f32 %2, vcc, %2, %8, %9\n v_div_scale_f32 %3, vcc, %3, %8, %9\n"
+                     "v_div_scale_f32 %4, vcc, %4, %8, %9\n v_div_scale_f32 %5, vcc, %5, %8, %9\n v_div_scale_f32 %6, vcc, %6, %8, %9\n v_div_scale_f32 %7, vcc, %7, %8, %9"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc");
+      } else if (KIND == 9) {  // v_div_fmas_f32 (reads vcc)
+        asm volatile("v_div_fmas_f32 %0, %0, %8, %9\n v_div_fmas_f32 %1, %1, %8, %9\n v_div_fmas_f32 %2, %2, %8, %9\n v_div_fmas_f32 %3, %3, %8, %9\n"
+                     "v_div_fmas_f32 %4, %4, %8, %9\n v_div_fmas_f32 %5, %5, %8, %9\n v_div_fmas_f32 %6, %6, %8, %9\n v_div_fmas_f32 %7, %7, %8, %9"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc");
+      } else if (KIND == 10) {  // v_sqrt_f32
+        asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3\n"
+                     "v_sqrt_f32 %4, %4\n v_sqrt_f32 %5, %5\n v_sqrt_f32 %6, %6\n v_sqrt_f32 %7, %7"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+      } else if (KIND == 11) {  // a / b as hipcc expands it (correctly rounded)
+        x0 = x0 / a; x1 = x1 / a; x2 = x2 / a; x3 = x3 / a; x4 = x4 / b; x5 = x5 / b; x6 = x6 / b; x7 = x7 / b;
+      } else if (KIND == 12) {  // sqrtf as hipcc expands it (correctly rounded)
+        x0 = __builtin_sqrtf(x0 + a); x1 = __builtin_sqrtf(x1 + a); x2 = __builtin_sqrtf(x2 + a); x3 = __builtin_sqrtf(x3 + a);
+        x4 = __builtin_sqrtf(x4 + a); x5 = __builtin_sqrtf(x5 + a); x6 = __builtin_sqrtf(x6 + a); x7 = __builtin_sqrtf(x7 + a);
       } else if (KIND == 6) {  // dependent v_fma chain (one accumulator)
         asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
                      "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2"
@@ -85,5 +106,11 @@ int main() {
   run<4>("v_cmp + v_cndmask", out, clk);
   run<3>("v_rcp_f32", out, clk);
   run<5>("v_pk_fma_f32", out, clk);
+  run<10>("v_sqrt_f32", out, clk);
+  run<8>("v_div_scale_f32", out, clk);
+  run<9>("v_div_fmas_f32", out, clk);
+  run<7>("v_div_fixup_f32", out, clk);
+  run<11>("x / a (IEEE, hipcc), per division", out, clk);
+  run<12>("sqrtf (IEEE, hipcc), per sqrt", out, clk);
   return 0;
 }
