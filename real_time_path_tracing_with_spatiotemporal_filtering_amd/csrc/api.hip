@@ -573,6 +573,11 @@ int rtpt_resize(rtpt_ctx* c, uint32_t width, uint32_t height, uint32_t row_begin
   c->cfg.height = height;
   c->cfg.row_begin = row_begin;
   c->cfg.row_end = row_end;
+  c->present_dst = c->present_fused_dst = nullptr;  // a swapchain image registered for the old size is not this size's
+  if ((c->cfg.flags & RTPT_FLAG_EXT_SVGF_VARIANCE) && (row_begin != 0 || row_end != height)) {
+    c->cfg = old;
+    return fail(RTPT_E_INVALID, "RTPT_FLAG_EXT_SVGF_VARIANCE needs a whole-frame context");
+  }
   int rc = alloc_planes(c);
   if (rc != RTPT_OK) {  // leave a usable context behind if the old size still fits
     c->cfg = old;
