@@ -146,3 +146,32 @@ def test_output_unorm8_png_pfm_roundtrip(tmp_path):
     clean = np.nan_to_num(img)
     output.write_pfm(str(q), clean)
     assert np.array_equal(output.read_pfm(str(q)), clean[..., :3])
+
+
+def test_posed_scene_bounds_and_static_test_follow_the_model_matrix():
+    """app._world_bounds: the reprojection bound's depth range uses the POSED scene; app._camera_static also requires
+    model == modelPrev (a moving model reprojects pixels across strips like a moving camera does)"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE, PathTracingApplication
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import reprojection_rows
+    abi.load()
+    app = PathTracingApplication(Recorder(), 64, 48, 3)
+    app.loadMesh(DEFAULT_SCENE)
+    app.buildAccelerationStructure()
+    app.updateScene()
+    app.frameCount += 1
+    lo, hi = app._world_bounds()
+    assert np.allclose(lo, app.sceneBounds[0]) and np.allclose(hi, app.sceneBounds[1])
+    m = np.eye(4, dtype=np.float32)
+    m[1, 3] = 0.5      # lift the scene by half a unit (column-major storage below)
+    app.modelMatrix = np.ascontiguousarray(m.T).ravel()
+    app.updateScene()
+    assert not app._camera_static(), "view and proj rest, the model moved"
+    lo2, hi2 = app._world_bounds()
+    assert np.allclose(lo2, lo + [0, 0.5, 0]) and np.allclose(hi2, hi + [0, 0.5, 0])
+    assert reprojection_rows(app.ubo, 64, 48, (10, 20), (lo2, hi2)) == (0, 48), "a changed model: the whole previous frame"
+    app.frameCount += 1
+    app.updateScene()   # same model again: static
+    assert app._camera_static()
+    a, b = reprojection_rows(app.ubo, 64, 48, (10, 20), app._world_bounds())
+    assert a <= 10 and b >= 20 and (b - a) < 48
