@@ -741,8 +741,10 @@ void k_atrous_comb_sh(AtrousArgs a) {
     a.out[ip] = make_float4(blend.x, blend.y, blend.z, 0.0f);  // :263 (D1: distinct buffer)
 #endif
     // main.cpp:1338-1361, fused: the blit reads exactly the value stored above (alpha 0), k_present's conversion
-    if (a.present && y >= a.present_y0 && y < a.present_y1)
-      a.present[static_cast<size_t>(y - a.present_y0) * W + x] = unorm8(blend.z) | (unorm8(blend.y) << 8) | (unorm8(blend.x) << 16);
+    // (not in the per-pixel-normal variant: its final pass sits at 79 VGPRs = 6 waves per SIMD, and the store's operands
+    // cost it a wave — 142 -> 176 us at 4K; k_present serves those scenes)
+    if (!NRM && a.present && y >= a.present_y0 && y < a.present_y1)  // index = ip minus a wave-uniform row offset: no new per-lane address
+      (a.present - static_cast<ptrdiff_t>(a.present_y0 - a.g.row_base) * W)[ip] = unorm8(blend.z) | (unorm8(blend.y) << 8) | (unorm8(blend.x) << 16);
   }
   }  // work list
 }
@@ -847,7 +849,8 @@ bool atrous_final_fuses_present(const AtrousArgs& a) {
   const bool pair_mode = a.pair_tab && np <= kPairMax;
   const bool nrm_mode = !pair_mode && a.normals != nullptr;
   if (a.ext) return ext_staged(a);
-  return !a.direct && (pair_mode || nrm_mode) && a.k >= 1 && a.k <= 16;
+  (void)nrm_mode;  // the per-pixel-normal final pass does not carry the store (register budget, see the kernel)
+  return !a.direct && pair_mode && a.k >= 1 && a.k <= 16;
 }
 
 void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
