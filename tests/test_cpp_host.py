@@ -175,6 +175,25 @@ def test_cpp_host_presents_the_assembled_frame(app_binary, hip_lib, oracle, tmp_
         assert got.tobytes() == want.tobytes()
 
 
+@pytest.mark.gpu
+def test_cpp_host_present_with_two_frames_in_flight_and_odd_sizes(app_binary, hip_lib, oracle, tmp_path):
+    """the fused blit (rtpt_present_target armed on the context that builds the frame, rtpt_present on the one that finished
+    it) with even / odd frames in two contexts, on a frame whose width is not a multiple of the 64-pixel segments"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    W, H, SEG, N = 203, 77, 3, 5
+    keys = ["", "J", "E", "", "Q"]
+    raw = tmp_path / "p.raw"
+    out = subprocess.run([app_binary, "--width", str(W), "--height", str(H), "--segments", str(SEG), "--iterations", str(N),
+                          "--frames", str(len(keys)), "--script", ",".join(keys), "--present", "rgba8", "--dump-present", str(raw),
+                          "--frames-in-flight", "2"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    app = make_app(W, H, max_segments=SEG, iterations=N)
+    for k in keys:
+        app.drawScene(tuple(k))
+    want = app.backend.ctx.readback(hip_lib.PLANE_IMAGE)
+    assert np.fromfile(raw, np.uint8).tobytes() == oracle.present_bgra8(want).tobytes()
+
+
 @pytest.mark.parametrize("halo", ["redundant", "exchange"])
 def test_cpp_strip_plan_and_history_bands_equal_the_python_mirror(app_binary, halo):
     """host-only (no GPU): `rtpt_app --plan-only` prints the C++ host's strip plan and, per scripted frame, the
