@@ -35,8 +35,10 @@ namespace {
 #ifndef RTPT_CHAIN_G
 #define RTPT_CHAIN_G 3
 #endif
-constexpr int kChG = RTPT_CHAIN_G;  // rows per level per step = waves per level / 2.  4K pair launches: 1: 107.9 us, 2: 100.4,
-                                    // 3: 97.7, 4: 103.1 (more waves per workgroup hide more latency until the rings cost a workgroup per CU)
+constexpr int kChG = RTPT_CHAIN_G;  // rows per level per step = waves per level / 2 (the default; chain_g() picks per pair).
+                                    // 4K pair launches, both pairs averaged: 1: 107.9 us, 2: 100.4, 3: 97.7, 4: 103.1 (more waves
+                                    // per workgroup hide more latency until the rings cost a workgroup per CU).  Per pair
+                                    // (profiles/r03_chain_g_ab.csv): (1,2): 2: 90.1, 3: 95.2, 4: 90.4; (3,4): 2: 107.2, 3: 97.5, 4: 111.0
 #ifndef RTPT_CHAIN_P
 #define RTPT_CHAIN_P 1
 #endif
@@ -50,9 +52,8 @@ __device__ __forceinline__ int posmod(int n, int r) {
   return m < 0 ? m + r : m;
 }
 
-template <int L, bool FINAL, bool EXACT>
-__global__ __launch_bounds__(128 * L * kChG) void k_atrous_chain(AtrousArgs a) {
-  constexpr int G = kChG;
+template <int L, bool FINAL, bool EXACT, int G>
+__global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int W = a.g.W, H = a.g.H;
   const int lane = static_cast<int>(threadIdx.x);
@@ -579,13 +580,26 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 896), amdgpu_waves_per
 
 }  // namespace
 
+// rows per level per step of a launch.  The short-stride pair runs best with two where the frame is tall enough (its rings
+// then admit four workgroups of 8 waves per CU; 4K: 90.4 us against 95.6), but twice the workgroups also means row segments
+// half as long, each re-staging 2*sum(s) rows: at 1080p (17-row segments) two rows per step lose 0.5 us (30.5 against 30.0).
+// The switch sits between the two measured points (segments of 17 and 66 rows); RTPT_CHAIN_G1=2|3 pins it for A/B.
+static int chain_g(int k0, int levels, int n_strips, int rows, int n_cu) {
+  if (levels != 2 || k0 != 1 || kChG != 3) return kChG;
+  const char* e = std::getenv("RTPT_CHAIN_G1");  // read per launch (~0.2 us): tests switch it inside one process
+  const int pin = e ? std::atoi(e) : 0;
+  if (pin == 2 || pin == 3) return pin;
+  const int n_segs = (n_cu * 4) / (n_strips > 0 ? n_strips : 1);
+  return n_segs >= 1 && rows / n_segs >= 40 ? 2 : 3;
+}
+
 // bytes of dynamic LDS of a chain of `levels` iterations starting at stride k0 (host mirror of the kernel's layout)
-size_t atrous_chain_lds(int k0, int levels, uint32_t n_tris) {
+static size_t chain_lds(int k0, int levels, uint32_t n_tris, int G) {
   const int np = static_cast<int>(n_tris) + 1;
   size_t off = static_cast<size_t>((np * np * 4 + 15) & ~15);
   for (int l = 0; l < levels; l++) {
     const int s = k0 + l;
-    const size_t cells = static_cast<size_t>(2 * s + 2 * kChG + (l == 0 ? (kChP - 1) * kChG : 0)) * (l == 0 ? kChCols + 2 * k0 : kChCols);
+    const size_t cells = static_cast<size_t>(2 * s + 2 * G + (l == 0 ? (kChP - 1) * G : 0)) * (l == 0 ? kChCols + 2 * k0 : kChCols);
     off += 20 * cells;
   }
   return off;
@@ -619,24 +633,25 @@ int atrous_chain_strip_width(int k0, int levels) {
   return kChCols - 2 * e0;
 }
 
-template <int L>
+template <int L, int G>
 static hipError_t chain_attrs() {
   constexpr int kMax = 160 * 1024;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, false, false, G>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, false, true, G>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, true, false, G>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, true, true, G>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
   return e;
 }
 hipError_t prepare_device_atrous_chain() {
-  hipError_t e = chain_attrs<2>();
+  hipError_t e = chain_attrs<2, kChG>();
+  if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 2>());
   constexpr int kMaxLds = 160 * 1024;
 #define RTPT_SW_ATTR(GG)                                                                                                              \
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain_sw<false, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds); \
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain_sw<true, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
   RTPT_SW_ATTR(2) RTPT_SW_ATTR(3) RTPT_SW_ATTR(4) RTPT_SW_ATTR(6)
 #undef RTPT_SW_ATTR
-  if (e == hipSuccess) e = chain_attrs<3>();
+  if (e == hipSuccess) e = (chain_attrs<3, kChG>());
   return e;
 }
 
@@ -646,7 +661,7 @@ bool atrous_chain_supported(int k0, int levels, uint32_t n_tris) {
   if (128 * levels * kChG > 1024) return false;  // two waves per row and level: the workgroup must fit 1024 threads
   if (n_tris + 1 > 64) return false;  // id-pair table in LDS (the per-pixel-normal variant is not chained)
   if (atrous_chain_strip_width(k0, levels) < 64) return false;
-  return atrous_chain_lds(k0, levels, n_tris) <= 160 * 1024;
+  return chain_lds(k0, levels, n_tris, kChG) <= 160 * 1024;  // chain_g() never picks more rows per step than kChG
 }
 
 void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, hipStream_t s) {
@@ -656,11 +671,12 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, hipS
   a.cl = -1.44269504088896341f / a.sigma_l;
   const bool sw = levels == 2 && !final_pass && chain_variant() != 0 && chain_sw_supported(a.k);
   const int bw = atrous_chain_strip_width(a.k, levels);
-  const size_t lds = sw ? atrous_chain_sw_lds(a.k, a.n_tris) : atrous_chain_lds(a.k, levels, a.n_tris);
   a.n_strips = (a.g.W + bw - 1) / bw;
+  const int g = chain_g(a.k, levels, a.n_strips, a.g.y1 - a.g.y0, a.n_cu > 0 ? a.n_cu : 256);
+  const size_t lds = sw ? atrous_chain_sw_lds(a.k, a.n_tris) : chain_lds(a.k, levels, a.n_tris, g);
   // one resident generation of workgroups: as many per CU as the LDS admits, row segments sized to fill them
   const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
-  const int waves = sw ? 2 * (2 * a.k + 1) : 2 * levels * kChG;
+  const int waves = sw ? 2 * (2 * a.k + 1) : 2 * levels * g;
   int per_cu = static_cast<int>((160u * 1024u) / lds);
   if (per_cu > 32 / waves) per_cu = 32 / waves;
   if (per_cu < 1) per_cu = 1;
@@ -677,7 +693,7 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, hipS
   // pair, 34.3 with 8 k rows and 480 workgroups; 4K and a 300-row strip do not change)
   const int min_rows = 8 * a.k;
   if (seg_rows < min_rows) seg_rows = min_rows;
-  // (not rounded up to whole steps of kChG rows: a partly used last step costs less than the workgroup slots the longer
+  // (not rounded up to whole steps of g rows: a partly used last step costs less than the workgroup slots the longer
   // segments leave empty — 1080p pair (1,2): 30 segments of 36 rows 34.5 us, 32 of 34 rows 33.4)
   a.seg_rows = seg_rows;
   a.n_segs = (rows + seg_rows - 1) / seg_rows;
@@ -698,24 +714,26 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, hipS
 #undef RTPT_SW_LAUNCH
     return;
   }
-#define RTPT_LAUNCH_CHAIN(LV)                                                              \
-  do {                                                                                     \
-    if (a.exact) {                                                                         \
-      if (final_pass)                                                                      \
-        hipLaunchKernelGGL((k_atrous_chain<LV, true, true>), grid, block, lds, s, a);      \
-      else                                                                                 \
-        hipLaunchKernelGGL((k_atrous_chain<LV, false, true>), grid, block, lds, s, a);     \
-    } else {                                                                               \
-      if (final_pass)                                                                      \
-        hipLaunchKernelGGL((k_atrous_chain<LV, true, false>), grid, block, lds, s, a);     \
-      else                                                                                 \
-        hipLaunchKernelGGL((k_atrous_chain<LV, false, false>), grid, block, lds, s, a);    \
-    }                                                                                      \
+#define RTPT_LAUNCH_CHAIN(LV, GG)                                                              \
+  do {                                                                                         \
+    if (a.exact) {                                                                             \
+      if (final_pass)                                                                          \
+        hipLaunchKernelGGL((k_atrous_chain<LV, true, true, GG>), grid, block, lds, s, a);      \
+      else                                                                                     \
+        hipLaunchKernelGGL((k_atrous_chain<LV, false, true, GG>), grid, block, lds, s, a);     \
+    } else {                                                                                   \
+      if (final_pass)                                                                          \
+        hipLaunchKernelGGL((k_atrous_chain<LV, true, false, GG>), grid, block, lds, s, a);     \
+      else                                                                                     \
+        hipLaunchKernelGGL((k_atrous_chain<LV, false, false, GG>), grid, block, lds, s, a);    \
+    }                                                                                          \
   } while (0)
-  if (levels == 2)
-    RTPT_LAUNCH_CHAIN(2);
+  if (levels == 2 && g == 2 && kChG == 3)
+    RTPT_LAUNCH_CHAIN(2, 2);
+  else if (levels == 2)
+    RTPT_LAUNCH_CHAIN(2, kChG);
   else
-    RTPT_LAUNCH_CHAIN(3);
+    RTPT_LAUNCH_CHAIN(3, kChG);
 #undef RTPT_LAUNCH_CHAIN
 }
 

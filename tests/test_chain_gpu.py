@@ -64,6 +64,22 @@ def test_sliding_window_variant_equals_separate_passes(hip_lib, monkeypatch, g):
                     assert np.array_equal(pa, pb)
 
 
+@pytest.mark.parametrize("g", [2, 3])
+def test_rows_per_step_of_the_first_pair(hip_lib, monkeypatch, g):
+    """the chain (1,2) runs two rows per level and step on tall frames and three otherwise (chain_g(), atrous_chain.hip):
+    RTPT_CHAIN_G1 pins either, and both give the bits of the separate passes at every frame shape"""
+    monkeypatch.setenv("RTPT_CHAIN_G1", str(g))
+    keys = [(), ("J",), ("D", "E"), ()]
+    for (w, h) in ((1, 1), (63, 5), (65, 7), (130, 33), (333, 170), (1000, 800)):
+        for n in (2, 3, 5):
+            for exact in (0, 1):
+                a, _ = _frames(hip_lib, w, h, n, exact, keys)
+                b, _ = _frames(hip_lib, w, h, n, exact | hip_lib.FLAG_NO_FILTER_FUSION, keys)
+                for f, ((ia, pa), (ib, pb)) in enumerate(zip(a, b)):
+                    assert np.array_equal(bits(ia), bits(ib)), (w, h, n, exact, f)
+                    assert np.array_equal(pa, pb)
+
+
 @pytest.mark.parametrize("exact", [0, 1])
 def test_chain_equals_separate_passes_4k(hip_lib, exact):
     """BASELINE configs[2] at its size: 3840x2160, 4 segments, N = 5, three frames"""
