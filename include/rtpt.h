@@ -362,6 +362,10 @@ const char* rtpt_kernel_name(rtpt_kernel_id k);
  * against the oracle: op 0 log, 1 sin(2*pi*u), 2 cos(2*pi*u), 3 sqrt, 4 1/x, 5 exp (filter
  * fast path), 6 pcg step float.  in/out are host arrays of n floats (u32 bits for op 6). */
 int rtpt_selftest_math(rtpt_ctx* ctx, int op, const float* in, float* out, size_t n);
+/* the product's correctly-rounded sqrt (op 3) and reciprocal (op 4) are shorter instruction sequences than the compiler's
+ * IEEE expansions (csrc/rtpt_math.hpp): this runs ALL 2^32 binary32 patterns through both on the device and returns how
+ * many results differ in any bit (the contract is 0) and the first few offending patterns.  ~0.1 s. */
+int rtpt_selftest_exhaustive(rtpt_ctx* ctx, int op, uint64_t* mismatches, uint32_t first_bad[4]);
 /* closest-hit of arbitrary rays through the product's traversal (parity vs the oracle's brute
  * force): rays = n x {ox,oy,oz,dx,dy,dz}; out_id[n] = primitive id+1 or 0; out_t[n] may be NULL */
 int rtpt_selftest_trace(rtpt_ctx* ctx, const float* rays, size_t n, uint32_t* out_id, float* out_t);

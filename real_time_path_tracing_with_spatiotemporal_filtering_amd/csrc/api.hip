@@ -1715,6 +1715,28 @@ int rtpt_selftest_math(rtpt_ctx* c, int op, const float* in, float* out, size_t 
   return RTPT_OK;
 }
 
+int rtpt_selftest_exhaustive(rtpt_ctx* c, int op, uint64_t* mismatches, uint32_t first_bad[4]) {
+  if (!c || !mismatches) return fail(RTPT_E_INVALID, "NULL argument");
+  if (op != 3 && op != 4) return fail(RTPT_E_INVALID, "rtpt_selftest_exhaustive: op must be 3 (sqrt) or 4 (1/x)");
+  HIP_TRY(hipSetDevice(c->device));
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc(&d, 5 * sizeof(unsigned long long)));
+  unsigned long long h[5] = {0, 0, 0, 0, 0};
+  hipError_t e = hipMemsetAsync(d, 0, sizeof h, c->stream);
+  if (e == hipSuccess) {
+    rt::launch_selftest_exhaustive(op, d, c->stream);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(RTPT_E_DEVICE, std::string("selftest_exhaustive: ") + hipGetErrorString(e));
+  *mismatches = h[0];
+  if (first_bad)
+    for (int i = 0; i < 4; i++) first_bad[i] = static_cast<uint32_t>(h[1 + i]);
+  return RTPT_OK;
+}
+
 int rtpt_selftest_trace(rtpt_ctx* c, const float* rays, size_t n, uint32_t* out_id, float* out_t) {
   if (!c || !rays || !out_id) return fail(RTPT_E_INVALID, "NULL argument");
   if (!c->n_tris) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");

@@ -29,6 +29,8 @@
 #include "device_common.hpp"
 #include "lds_dma.hpp"
 
+#include <type_traits>
+
 namespace rt {
 namespace {
 
@@ -52,7 +54,10 @@ __device__ __forceinline__ int posmod(int n, int r) {
   return m < 0 ? m + r : m;
 }
 
-template <int L, bool FINAL, bool EXACT, int G>
+// K0: the first stride as a compile-time constant (0: read a.k).  With the strides known, a tap's LDS address is its row
+// base plus an immediate: the generic form spends 40 of its 157 VALU per wave and step on tap addresses, and the kernel is
+// bound by VALU issue.  The shipping pairs (1,2) and (3,4) are instantiated with K0 = 1 and 3.
+template <int L, bool FINAL, bool EXACT, int G, int K0>
 __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int W = a.g.W, H = a.g.H;
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
 
   // ---- geometry of the chain (all wave-uniform)
   int s[L], E[L], R[L], lag[L];
-  for (int l = 0; l < L; l++) s[l] = a.k + l;  // main.cpp:1259-1260: waveletIteration = k, tap offset i*k (:135)
+  for (int l = 0; l < L; l++) s[l] = (K0 ? K0 : a.k) + l;  // main.cpp:1259-1260: waveletIteration = k, tap offset i*k (:135)
   E[L - 1] = 0;
   for (int l = L - 2; l >= 0; l--) E[l] = E[l + 1] + s[l + 1];
   for (int l = 0; l < L; l++) R[l] = 2 * s[l] + 2 * G;  // ring l = input of level l
@@ -195,8 +200,9 @@ __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
       int sm = slot_s + (ym - y), sp = slot_s + (yp - y);
       if (sm < 0) sm += Rs;
       if (sp >= Rs) sp -= Rs;
-      const int rows3[3] = {sm * src_stride, slot_s * src_stride, sp * src_stride};
-      const int cc = rows3[1] + csrc;
+      // tap (i, jj) of this row: cell rowb[jj + 1] + (i + 1) * stride (rowb already stands one stride left of the pixel)
+      const int rowb[3] = {sm * src_stride + csrc - sl, slot_s * src_stride + csrc - sl, sp * src_stride + csrc - sl};
+      const int cc = rowb[1] + sl;
       const float4 cp4 = scol[cc];
       const f3 cp = xyz(cp4);
       const float dp = cp4.w;
@@ -204,41 +210,56 @@ __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
       const float* prow = pairw + idp * NP;
       f3 num{0.f, 0.f, 0.f};
       float den = 0.f;
+      auto taps = [&](auto stride_tag) {
+        constexpr int SC = decltype(stride_tag)::value;  // this level's stride if the kernel knows it, else 0
+        const int st = SC ? SC : sl;
 #pragma unroll
-      for (int i = -1; i < 2; i++) {  // :132 (x offset outer: the reference's accumulation order)
+        for (int i = -1; i < 2; i++) {  // :132 (x offset outer: the reference's accumulation order)
 #pragma unroll
-        for (int jj = -1; jj < 2; jj++) {  // :133
-          float w;
-          f3 cq;
-          if (i == 0 && jj == 0) {
-            cq = cp;
-            w = prow[idp];  // centre tap: q == p, both exponentials are exactly 1
-          } else {
-            const int qi = rows3[jj + 1] + csrc + i * sl;
-            const float4 cq4 = scol[qi];
-            cq = xyz(cq4);
-            const float dq = cq4.w;
-            const float wn = prow[sids[qi]];  // :62 via the id-pair table
-            const f3 dc = cp - cq;
-            if (EXACT) {
-              const float wd = exact::exp_(-__builtin_fabsf(dp - dq) / a.sigma_z);  // :67-68
-              const float wl = exact::exp_(-exact::length(dc) / a.sigma_l);         // :73
-              w = (wn * wd) * wl;                                                   // :77
+          for (int jj = -1; jj < 2; jj++) {  // :133
+            float w;
+            f3 cq;
+            if (i == 0 && jj == 0) {
+              cq = cp;
+              w = prow[idp];  // centre tap: q == p, both exponentials are exactly 1
             } else {
-              const float e = fmaf_(__builtin_fabsf(dp - dq), a.cz, fast::sqrt_(exact::dot(dc, dc)) * a.cl);
-              w = wn * __builtin_amdgcn_exp2f(e);
+              const int qi = rowb[jj + 1] + (i + 1) * st;
+              const float4 cq4 = scol[qi];
+              cq = xyz(cq4);
+              const float dq = cq4.w;
+              const float wn = prow[sids[qi]];  // :62 via the id-pair table
+              const f3 dc = cp - cq;
+              if (EXACT) {
+                const float wd = exact::exp_(-__builtin_fabsf(dp - dq) / a.sigma_z);  // :67-68
+                const float wl = exact::exp_(-exact::length(dc) / a.sigma_l);         // :73
+                w = (wn * wd) * wl;                                                   // :77
+              } else {
+                const float e = fmaf_(__builtin_fabsf(dp - dq), a.cz, fast::sqrt_(exact::dot(dc, dc)) * a.cl);
+                w = wn * __builtin_amdgcn_exp2f(e);
+              }
+            }
+            if (EXACT) {
+              const float hw_ = h9 * w;
+              num = f3{fmaf_(hw_, cq.x, num.x), fmaf_(hw_, cq.y, num.y), fmaf_(hw_, cq.z, num.z)};  // :146
+              den = den + hw_;                                                                       // :147
+            } else {
+              num = f3{fmaf_(w, cq.x, num.x), fmaf_(w, cq.y, num.y), fmaf_(w, cq.z, num.z)};
+              den = den + w;
             }
           }
-          if (EXACT) {
-            const float hw_ = h9 * w;
-            num = f3{fmaf_(hw_, cq.x, num.x), fmaf_(hw_, cq.y, num.y), fmaf_(hw_, cq.z, num.z)};  // :146
-            den = den + hw_;                                                                       // :147
-          } else {
-            num = f3{fmaf_(w, cq.x, num.x), fmaf_(w, cq.y, num.y), fmaf_(w, cq.z, num.z)};
-            den = den + w;
-          }
         }
-      }
+        // the two (three) instantiations differ only in constants; left alone, the optimiser sinks them back into ONE body
+        // with the stride in a register.  A distinct statement at the end of each keeps them apart.
+        if (SC) asm volatile("; taps of the level with stride %0" ::"n"(SC));
+      };
+      if (K0 == 0)
+        taps(std::integral_constant<int, 0>{});
+      else if (lw == 0)
+        taps(std::integral_constant<int, K0>{});
+      else if (L < 3 || lw == 1)
+        taps(std::integral_constant<int, K0 ? K0 + 1 : 0>{});
+      else
+        taps(std::integral_constant<int, K0 ? K0 + 2 : 0>{});
       f3 filtered;
       if (EXACT)
         filtered = f3{num.x / den, num.y / den, num.z / den};  // :150
@@ -627,31 +648,39 @@ static int chain_variant() {  // read per launch (a getenv, ~0.2 us): tests swit
   return e ? std::atoi(e) : 0;
 }
 
+static bool chain_generic() {  // read per launch: tests switch it inside one process
+  const char* e = std::getenv("RTPT_CHAIN_GENERIC");
+  return e && std::atoi(e) != 0;
+}
+
 int atrous_chain_strip_width(int k0, int levels) {
   int e0 = 0;
   for (int l = 1; l < levels; l++) e0 += k0 + l;
   return kChCols - 2 * e0;
 }
 
-template <int L, int G>
+template <int L, int G, int K0>
 static hipError_t chain_attrs() {
   constexpr int kMax = 160 * 1024;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, false, false, G>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, false, true, G>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, true, false, G>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, true, true, G>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, false, false, G, K0>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, false, true, G, K0>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, true, false, G, K0>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain<L, true, true, G, K0>), hipFuncAttributeMaxDynamicSharedMemorySize, kMax);
   return e;
 }
 hipError_t prepare_device_atrous_chain() {
-  hipError_t e = chain_attrs<2, kChG>();
-  if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 2>());
+  hipError_t e = chain_attrs<2, kChG, 0>();
+  if (e == hipSuccess) e = (chain_attrs<2, kChG, 3>());  // the pair (3,4)
+  if (e == hipSuccess) e = (chain_attrs<2, kChG, 1>());
+  if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 2, 1>());  // the pair (1,2) on tall frames
+  if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 2, 0>());
   constexpr int kMaxLds = 160 * 1024;
 #define RTPT_SW_ATTR(GG)                                                                                                              \
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain_sw<false, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds); \
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain_sw<true, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
   RTPT_SW_ATTR(2) RTPT_SW_ATTR(3) RTPT_SW_ATTR(4) RTPT_SW_ATTR(6)
 #undef RTPT_SW_ATTR
-  if (e == hipSuccess) e = (chain_attrs<3, kChG>());
+  if (e == hipSuccess) e = (chain_attrs<3, kChG, 0>());
   return e;
 }
 
@@ -714,26 +743,36 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, hipS
 #undef RTPT_SW_LAUNCH
     return;
   }
-#define RTPT_LAUNCH_CHAIN(LV, GG)                                                              \
-  do {                                                                                         \
-    if (a.exact) {                                                                             \
-      if (final_pass)                                                                          \
-        hipLaunchKernelGGL((k_atrous_chain<LV, true, true, GG>), grid, block, lds, s, a);      \
-      else                                                                                     \
-        hipLaunchKernelGGL((k_atrous_chain<LV, false, true, GG>), grid, block, lds, s, a);     \
-    } else {                                                                                   \
-      if (final_pass)                                                                          \
-        hipLaunchKernelGGL((k_atrous_chain<LV, true, false, GG>), grid, block, lds, s, a);     \
-      else                                                                                     \
-        hipLaunchKernelGGL((k_atrous_chain<LV, false, false, GG>), grid, block, lds, s, a);    \
-    }                                                                                          \
+#define RTPT_LAUNCH_CHAIN(LV, GG, KK)                                                              \
+  do {                                                                                             \
+    if (a.exact) {                                                                                 \
+      if (final_pass)                                                                              \
+        hipLaunchKernelGGL((k_atrous_chain<LV, true, true, GG, KK>), grid, block, lds, s, a);      \
+      else                                                                                         \
+        hipLaunchKernelGGL((k_atrous_chain<LV, false, true, GG, KK>), grid, block, lds, s, a);     \
+    } else {                                                                                       \
+      if (final_pass)                                                                              \
+        hipLaunchKernelGGL((k_atrous_chain<LV, true, false, GG, KK>), grid, block, lds, s, a);     \
+      else                                                                                         \
+        hipLaunchKernelGGL((k_atrous_chain<LV, false, false, GG, KK>), grid, block, lds, s, a);    \
+    }                                                                                              \
   } while (0)
-  if (levels == 2 && g == 2 && kChG == 3)
-    RTPT_LAUNCH_CHAIN(2, 2);
+  // strides as compile-time constants for the pairs a default frame runs (N = 5: (1,2) and (3,4)); RTPT_CHAIN_GENERIC=1
+  // runs the generic instantiation for A/B and for the test that the two agree
+  const bool generic = chain_generic();
+  if (levels == 2 && a.k == 1 && !generic) {
+    if (g == 2 && kChG == 3)
+      RTPT_LAUNCH_CHAIN(2, 2, 1);
+    else
+      RTPT_LAUNCH_CHAIN(2, kChG, 1);
+  } else if (levels == 2 && a.k == 3 && !generic)
+    RTPT_LAUNCH_CHAIN(2, kChG, 3);
+  else if (levels == 2 && g == 2 && kChG == 3)
+    RTPT_LAUNCH_CHAIN(2, 2, 0);
   else if (levels == 2)
-    RTPT_LAUNCH_CHAIN(2, kChG);
+    RTPT_LAUNCH_CHAIN(2, kChG, 0);
   else
-    RTPT_LAUNCH_CHAIN(3, kChG);
+    RTPT_LAUNCH_CHAIN(3, kChG, 0);
 #undef RTPT_LAUNCH_CHAIN
 }
 

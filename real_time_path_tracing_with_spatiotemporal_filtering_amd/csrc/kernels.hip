@@ -1009,6 +1009,22 @@ __global__ void k_selftest_math(int op, const float* in, float* out, size_t n) {
   out[i] = r;
 }
 
+// every binary32 pattern through exact::sqrt_ (op 3) / exact::rcp_ (op 4) against hipcc's IEEE expansion of the same
+// operation: out[0] = patterns whose results differ in any bit, out[1..4] = the first few of them
+__global__ void k_selftest_exhaustive(int op, unsigned long long* out) {
+  const uint64_t base = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 64u;
+  for (uint32_t k = 0; k < 64u; k++) {
+    const uint32_t b = static_cast<uint32_t>(base + k);
+    const float x = u2f(b);
+    const float got = op == 3 ? exact::sqrt_(x) : exact::rcp_(x);
+    const float want = op == 3 ? __builtin_sqrtf(x) : 1.0f / x;
+    if (f2u(got) != f2u(want)) {
+      const unsigned long long n = atomicAdd(out, 1ull);
+      if (n < 4) out[1 + n] = b;
+    }
+  }
+}
+
 template <bool BVH>
 __global__ __launch_bounds__(kThreads) void k_selftest_trace(SceneView sc, const float* rays, size_t n, float tmax,
                                                              uint32_t* out_id, float* out_t) {
@@ -1106,6 +1122,9 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
 void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(k_selftest_math, dim3((n + 255) / 256), dim3(256), 0, s, op, in, out, n);
+}
+void launch_selftest_exhaustive(int op, unsigned long long* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_selftest_exhaustive, dim3((1u << 26) / 256u), dim3(256), 0, s, op, out);  // 2^26 threads x 64 patterns
 }
 void launch_selftest_trace(const SceneView& scene, const float* rays, size_t n, float tmax, uint32_t* out_id,
                            float* out_t, hipStream_t s) {

@@ -43,8 +43,40 @@ RT_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
 namespace exact {
 
-RT_HD float sqrt_(float x) { return __builtin_sqrtf(x); }  // correctly rounded (hipcc default)
-RT_HD float rcp_(float x) { return 1.0f / x; }             // correctly rounded division
+#if defined(__HIP_DEVICE_COMPILE__)
+// Correctly rounded square root and reciprocal, cheaper than hipcc's IEEE expansions.  Every kernel of the frame is bound by
+// VALU issue (profiles/r03_valu_issue_micro.txt) and the expansions are long because they serve every input: sqrt scales
+// its argument into and out of the normal range and selects by class (16 VALU + v_sqrt_f32, 24.4 ns per wave64 operation
+// and SIMD), 1/x is the full division (v_div_scale x2, v_rcp, 6 fma, v_div_fmas, v_div_fixup: 19.3 ns).  The sequences
+// below give the IEEE result bit for bit on the inputs a frame produces and hand everything else to hipcc's sequence under
+// a branch — which inputs are which was settled by running all 2^32 patterns (scripts/micro/exact_ops.hip), and
+// rtpt_selftest_exhaustive re-checks the shipped functions against hipcc's over all 2^32 patterns on the GPU in use:
+//   sqrt: +-0 and 2^-102 <= x < inf:  y = v_rsq_f32(max(x, 2^-102)); s = x*y; h = y/2; s + (x - s*s)*h      (7.9 ns)
+//   1/x:  exponent field 1..252 (2^-126 <= |x| < 2^126):  r = v_rcp_f32(x); r + (1 - x*r)*r                  (7.4 ns)
+// (NaN results keep hipcc's bit patterns because NaN inputs take hipcc's path.)
+__device__ __forceinline__ float sqrt_(float x) {
+  const float lo = 1.97215226305252951e-31f;  // 2^-102: below it the residual x - s*s leaves the normal range
+  const float t = __builtin_fmaxf(x, lo);
+  // t == x: lo <= x <= +inf (false for NaN, negatives, zeros, small x); the class test flips +inf out and the zeros in
+  const bool direct = (t == x) != __builtin_amdgcn_classf(x, 0x260);  // 0x260 = +inf | +0 | -0
+  const float y = __builtin_amdgcn_rsqf(t);
+  const float s = x * y, h = 0.5f * y;
+  float r = fmaf_(fmaf_(-s, s, x), h, s);
+  if (__builtin_expect(!direct, 0)) r = __builtin_sqrtf(x);
+  return r;
+}
+__device__ __forceinline__ float rcp_(float x) {
+  const uint32_t b = f2u(x);
+  const bool direct = (b + b) - 0x01000000u < 0xfc000000u;  // exponent field 1..252: x, 1/x and the residual are all normal
+  float r = __builtin_amdgcn_rcpf(x);
+  r = fmaf_(fmaf_(-x, r, 1.0f), r, r);
+  if (__builtin_expect(!direct, 0)) r = 1.0f / x;
+  return r;
+}
+#else
+inline float sqrt_(float x) { return __builtin_sqrtf(x); }  // correctly rounded
+inline float rcp_(float x) { return 1.0f / x; }             // correctly rounded division
+#endif
 
 RT_HD float dot(f3 a, f3 b) { return fmaf_(a.z, b.z, fmaf_(a.y, b.y, a.x * b.x)); }
 RT_HD f3 cross(f3 a, f3 b) {
@@ -52,7 +84,7 @@ RT_HD f3 cross(f3 a, f3 b) {
 }
 RT_HD float length(f3 a) { return sqrt_(dot(a, a)); }
 RT_HD f3 normalize(f3 a) {
-  float inv = 1.0f / sqrt_(dot(a, a));
+  float inv = rcp_(sqrt_(dot(a, a)));
   return a * inv;
 }
 

@@ -81,16 +81,25 @@ void run(const char* name, float* out, long long* clk) {
   for (int wps : {1, 2, 4, 8}) {  // waves per SIMD: blocks of up to 1024 threads, two per CU for 8
     const int threads = wps == 8 ? 1024 : 64 * 4 * wps, blocks = wps == 8 ? 2 * cus : cus;
     const int waves = blocks * threads / 64;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float ms = 0.f;
     for (int rep = 0; rep < 3; rep++) {
+      hipEventRecord(e0, 0);
       hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), 0, 0, out, clk, iters, 1.0001f, 1e-9f);
+      hipEventRecord(e1, 0);
       hipDeviceSynchronize();
+      hipEventElapsedTime(&ms, e0, e1);
     }
+    // wall-clock view: nanoseconds one SIMD spends per wave64 instruction (launch overhead included: ~2 % at these lengths)
+    const double ns_per_simd = double(ms) * 1e6 / (double(iters) * REP * wps);
     std::vector<long long> h(waves);
     hipMemcpy(h.data(), clk, waves * sizeof(long long), hipMemcpyDeviceToHost);
     double sum = 0;
     for (long long v : h) sum += double(v);
     const double per_wave = sum / waves / (double(iters) * REP);  // shader cycles per instruction as one wave sees it
-    printf("%-28s waves/SIMD %d  shader cycles per instruction: per wave %.2f, per SIMD %.2f\n", name, wps, per_wave, per_wave / wps);
+    printf("%-28s waves/SIMD %d  shader cycles per instruction: per wave %.2f, per SIMD %.2f | wall: %.3f ns per instruction and SIMD (kernel %.1f us)\n", name, wps, per_wave, per_wave / wps, ns_per_simd, ms * 1e3);
   }
 }
 

@@ -52,6 +52,26 @@ def test_contract_math_bit_exact(hip_lib, oracle, op, lo, hi):
     assert np.array_equal(bits(got), bits(want))
 
 
+@pytest.mark.parametrize("op", [3, 4])
+def test_short_sqrt_and_reciprocal_are_ieee_on_every_pattern(hip_lib, oracle, op):
+    """exact::sqrt_ / exact::rcp_ (rtpt_math.hpp) are shorter than the compiler's IEEE expansions; the library runs all 2^32
+    binary32 patterns through both on the device: no result may differ in any bit.  The special values also go against the
+    oracle's libm (the CPU side of the contract)."""
+    with hip_lib.Context(hip_lib.config_default(64, 64)) as ctx:
+        bad, first = ctx.selftest_exhaustive(op)
+        assert bad == 0, [hex(v) for v in first]
+        pats = np.array([0x00000000, 0x80000000, 0x00000001, 0x007fffff, 0x00800000, 0x0c7fffff, 0x0c800000, 0x0c800001,
+                         0x3f800000, 0x3f800001, 0x3fffffff, 0x40000000, 0x7e7fffff, 0x7e800000, 0x7effffff, 0x7f000000,
+                         0x7f7fffff, 0x7f800000, 0x3f7fffff, 0x00ffffff, 0x01000000], np.uint32)
+        x = np.concatenate([pats, pats[2:] | np.uint32(0x80000000)]).view(np.float32)
+        if op == 3:
+            x = x[: len(pats)]  # negative arguments give NaN on both sides; its sign bit is libm's / the GPU's own
+        got = ctx.selftest_math(op, x)
+    with np.errstate(all="ignore"):
+        want = oracle.math_array(op, x)
+    assert np.array_equal(bits(got), bits(want)), (x[bits(got) != bits(want)], got[bits(got) != bits(want)])
+
+
 def test_pcg_stream_bit_exact(hip_lib, oracle):
     states = np.random.default_rng(1).integers(0, 1 << 32, 1 << 18, dtype=np.uint64).astype(np.uint32)
     with hip_lib.Context(hip_lib.config_default(64, 64)) as ctx:
