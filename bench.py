@@ -38,6 +38,10 @@ WORKLOADS = {
     "instanced": dict(width=3840, height=2160, max_segments=8, iterations=5, instanced=True),
 }
 PREWARM_SECONDS = 0.3
+# VALU issue, measured on this part (scripts/micro/valu_rate.hip -> profiles/r03_valu_issue_micro.txt, wall clock at 8 waves
+# per SIMD): the fastest wave64 VALU instruction occupies a SIMD for 1.06 ns (v_xor_b32; v_mul_f32 1.12, a dependent
+# v_fma_f32 1.16), a transcendental (v_rcp / v_sqrt / v_rsq / v_exp) for 3.42 ns.  1,024 SIMDs.
+VALU_NS, TRANS_NS, N_SIMDS = 1.06, 3.42, 1024
 HOST_SECONDS = [0.0]
 HIST_BYTES = [0]
 PRESENT_BYTES = [0]
@@ -357,15 +361,25 @@ def main():
         # the filter iterations k < N: chained pairs by default, single launches with RTPT_FLAG_NO_FILTER_FUSION
         rk = "k_atrous_chain" if "k_atrous_chain" in kr else "k_atrous"
         at = kr.get(rk, {})
-        traffic, traffic_source = None, None
+        traffic, traffic_source, valu_tab = None, None, {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and world == 1:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(args.workload, {}).get(rk)
                 traffic_source = tj.get("_source")
+                valu_tab = tj.get("valu", {}).get(args.workload, {})
             except Exception:
                 traffic = None
+        # every kernel of the frame is bound by instruction issue, not by HBM: next to the HBM fractions, the share of
+        # each launch that its VALU instructions (SQ_INSTS_VALU / _TRANS_F32 per launch, the same committed PMC run as
+        # `traffic`) occupy the SIMDs for at the measured issue rates above
+        for k, v in kr.items():
+            c = valu_tab.get(k) or valu_tab.get({"k_gbuffer_gradient": "k_gbuffer"}.get(k, ""))  # the fused launch is k_gbuffer<fused>
+            if c and v.get("avg_us"):
+                issue_us = ((c["insts"] - c["trans"]) * VALU_NS + c["trans"] * TRANS_NS) * 1e-3 / N_SIMDS
+                v["valu_issue"] = {"insts_per_launch": int(c["insts"]), "transcendental": int(c["trans"]),
+                                   "issue_us": round(issue_us, 1), "frac_of_launch": round(issue_us / v["avg_us"], 3)}
         achieved = at.get("algorithmic_GBps")
         result = {
             "metric": "Mray/s (closest-hit queries / whole-frame time: G-buffer + gradient + trace + a-trous)",
@@ -408,6 +422,7 @@ def main():
                          "frac_traffic": round(traffic / (at["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                          if traffic and at.get("avg_us") else None,
                          "traffic_source": traffic_source,
+                         "valu_issue": at.get("valu_issue"),
                          "frac_vs_separate_passes_at_peak": round(at["replaced_pass_bytes"] / (at["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                          if at.get("replaced_pass_bytes") and at.get("avg_us") else None},
             "kernels": kr,

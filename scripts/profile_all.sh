@@ -38,7 +38,8 @@ import json, sys, datetime
 out, commit = sys.argv[1], sys.argv[2]
 t = {"_note": "HBM-side bytes per launch from rocprofv3 --pmc (separate passes): FETCH_SIZE*1024*2 (gfx950 tallies 128-B read "
               "requests at 64 B, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE*1024, averaged over the launches of each kernel; "
-              "inputs: the pmc_<workload>_pass*_counter_collection.csv files next to this one, folded by scripts/summarize_pmc.py",
+              "inputs: the pmc_<workload>_pass*_counter_collection.csv files next to this one, folded by scripts/summarize_pmc.py; "
+              "valu: SQ_INSTS_VALU and SQ_INSTS_VALU_TRANS_F32 per launch (wave64 instructions) from the same passes",
      "_source": {"commit": commit, "captured": datetime.date.today().isoformat(), "tool": "scripts/profile_all.sh"}}
 for wl in ("4k", "1080p"):
     try:
@@ -46,6 +47,8 @@ for wl in ("4k", "1080p"):
     except Exception:
         continue
     t[wl] = {k: int(v["hbm_traffic_bytes"]) for k, v in s.items() if "hbm_traffic_bytes" in v}
+    t.setdefault("valu", {})[wl] = {k: {"insts": int(v["SQ_INSTS_VALU"]), "trans": int(v.get("SQ_INSTS_VALU_TRANS_F32", 0))}
+                                    for k, v in s.items() if "SQ_INSTS_VALU" in v}
 json.dump(t, open(f"{out}/traffic.json", "w"), indent=1)
 print(json.dumps(t))
 PY
