@@ -428,6 +428,10 @@ template <int CWp, bool FINAL, bool EXACT, bool NRM = false, int R = 1, bool EXT
 __global__ __launch_bounds__(kShThreads)
 #if RTPT_COMB_MIN_WAVES
 __attribute__((amdgpu_waves_per_eu(RTPT_COMB_MIN_WAVES)))
+#else
+// the per-pixel-normal final pass sits at the edge of six waves per SIMD (79-81 VGPRs as the surrounding code changes;
+// 142-147 us with six waves, 169-176 us with five at 4K): pin it.  Every other instantiation keeps what it gets.
+__attribute__((amdgpu_waves_per_eu(FINAL && NRM && R == 1 && !EXTA && !VAR && !EXACT ? 6 : 1)))
 #endif
 void k_atrous_comb_sh(AtrousArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
