@@ -366,6 +366,12 @@ int rtpt_selftest_math(rtpt_ctx* ctx, int op, const float* in, float* out, size_
  * IEEE expansions (csrc/rtpt_math.hpp): this runs ALL 2^32 binary32 patterns through both on the device and returns how
  * many results differ in any bit (the contract is 0) and the first few offending patterns.  ~0.1 s. */
 int rtpt_selftest_exhaustive(rtpt_ctx* ctx, int op, uint64_t* mismatches, uint32_t first_bad[4]);
+/* the product's division (csrc/rtpt_math.hpp, exact::div_) against the compiler's IEEE division, on the device.  mode 0:
+ * passes [first_pass, first_pass + n_passes) of the 256-pass enumeration of ALL 2^23 x 2^23 pairs of binary32 significands
+ * (~0.15 s per pass; all 256 is the proof that the short sequence is correctly rounded for operands of ordinary magnitude);
+ * mode 1: n_passes x 2^33 operand pairs of arbitrary bits, pass numbers seeding the generator (range test + long path).
+ * *mismatches = results that differ in any bit (two NaNs count as equal); first_bad = the bits of one offending (a, b). */
+int rtpt_selftest_div(rtpt_ctx* ctx, int mode, uint32_t first_pass, uint32_t n_passes, uint64_t* mismatches, uint32_t first_bad[2]);
 /* closest-hit of arbitrary rays through the product's traversal (parity vs the oracle's brute
  * force): rays = n x {ox,oy,oz,dx,dy,dz}; out_id[n] = primitive id+1 or 0; out_t[n] may be NULL */
 int rtpt_selftest_trace(rtpt_ctx* ctx, const float* rays, size_t n, uint32_t* out_id, float* out_t);

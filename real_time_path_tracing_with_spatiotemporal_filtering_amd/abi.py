@@ -94,7 +94,7 @@ SYMBOLS = [
     "rtpt_plane_ptr", "rtpt_plane_bytes", "rtpt_set_external_history", "rtpt_stream_wait", "rtpt_scene_upload", "rtpt_gbuffer", "rtpt_temporal_gradient",
     "rtpt_raytrace", "rtpt_temporal_filter", "rtpt_end_frame", "rtpt_sync", "rtpt_readback", "rtpt_set_plane",
     "rtpt_reset_counters", "rtpt_set_count_rows", "rtpt_enable_debug", "rtpt_timing_enable", "rtpt_timing_collect", "rtpt_kernel_name",
-    "rtpt_selftest_math", "rtpt_selftest_exhaustive", "rtpt_selftest_trace", "rtpt_util_look_at", "rtpt_util_perspective", "rtpt_util_load_obj", "rtpt_util_bvh_check",
+    "rtpt_selftest_math", "rtpt_selftest_exhaustive", "rtpt_selftest_div", "rtpt_selftest_trace", "rtpt_util_look_at", "rtpt_util_perspective", "rtpt_util_load_obj", "rtpt_util_bvh_check",
     "rtpt_scene_set_materials", "rtpt_util_load_obj_materials", "rtpt_util_bvh_refit_check", "rtpt_set_external_guides",
     "rtpt_present", "rtpt_debug_bvh_check", "rtpt_present_target",
 ]
@@ -147,6 +147,7 @@ def load() -> C.CDLL:
         "rtpt_timing_collect": [vp, C.POINTER(C.c_double * K_COUNT), C.POINTER(u32 * K_COUNT)],
         "rtpt_selftest_math": [vp, C.c_int, vp, vp, sz],
         "rtpt_selftest_exhaustive": [vp, C.c_int, vp, vp],
+        "rtpt_selftest_div": [vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp],
         "rtpt_selftest_trace": [vp, vp, sz, vp, vp],
         "rtpt_util_load_obj": [C.c_char_p, vp, C.POINTER(u32), vp, C.POINTER(u32)],
         "rtpt_util_bvh_check": [vp, u32, C.POINTER(C.c_uint64 * 8)],
@@ -406,6 +407,13 @@ class Context:
         n = C.c_uint64(0)
         first = np.zeros(4, np.uint32)
         _check(self._lib.rtpt_selftest_exhaustive(self._h, op, C.byref(n), _ptr(first)))
+        return int(n.value), first
+
+    def selftest_div(self, mode: int, first_pass: int, n_passes: int):
+        """(mismatches, bits of one offending (a, b)) of exact::div_ against the compiler's division; see rtpt.h"""
+        n = C.c_uint64(0)
+        first = np.zeros(2, np.uint32)
+        _check(self._lib.rtpt_selftest_div(self._h, mode, first_pass, n_passes, C.byref(n), _ptr(first)))
         return int(n.value), first
 
     def selftest_trace(self, rays: np.ndarray):

@@ -1737,6 +1737,33 @@ int rtpt_selftest_exhaustive(rtpt_ctx* c, int op, uint64_t* mismatches, uint32_t
   return RTPT_OK;
 }
 
+int rtpt_selftest_div(rtpt_ctx* c, int mode, uint32_t first_pass, uint32_t n_passes, uint64_t* mismatches, uint32_t first_bad[2]) {
+  if (!c || !mismatches) return fail(RTPT_E_INVALID, "NULL argument");
+  if (mode != 0 && mode != 1) return fail(RTPT_E_INVALID, "rtpt_selftest_div: mode must be 0 (significand pairs) or 1 (arbitrary bits)");
+  if (mode == 0 && (first_pass >= 256u || n_passes > 256u - first_pass))
+    return fail(RTPT_E_INVALID, "rtpt_selftest_div: the enumeration has 256 passes");
+  HIP_TRY(hipSetDevice(c->device));
+  unsigned long long* d = nullptr;
+  HIP_TRY(hipMalloc(&d, 3 * sizeof(unsigned long long)));
+  unsigned long long h[3] = {0, 0, 0};
+  hipError_t e = hipMemsetAsync(d, 0, sizeof h, c->stream);
+  for (uint32_t p = 0; e == hipSuccess && p < n_passes; p++) {
+    rt::launch_selftest_div(mode, first_pass + p, d, c->stream);
+    e = hipGetLastError();
+    if (e == hipSuccess && (p & 7u) == 7u) e = hipStreamSynchronize(c->stream);  // ~0.15 s per pass: keep the queue short
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(RTPT_E_DEVICE, std::string("selftest_div: ") + hipGetErrorString(e));
+  *mismatches = h[0];
+  if (first_bad) {
+    first_bad[0] = static_cast<uint32_t>(h[1]);
+    first_bad[1] = static_cast<uint32_t>(h[2]);
+  }
+  return RTPT_OK;
+}
+
 int rtpt_selftest_trace(rtpt_ctx* c, const float* rays, size_t n, uint32_t* out_id, float* out_t) {
   if (!c || !rays || !out_id) return fail(RTPT_E_INVALID, "NULL argument");
   if (!c->n_tris) return fail(RTPT_E_NO_SCENE, "rtpt_scene_upload has not been called");

@@ -18,11 +18,11 @@ __device__ __forceinline__ f3 xyz(float4 v) { return f3{v.x, v.y, v.z}; }
 __device__ __forceinline__ float tri_area(f3 a, f3 b, f3 c) { return exact::length(exact::cross(b - a, c - a)) * 0.5f; }
 __device__ __forceinline__ f3 bary_coords(f3 p, f3 a, f3 b, f3 c) {
   float at = tri_area(a, b, c);
-  return f3{tri_area(p, b, c) / at, tri_area(a, p, c) / at, tri_area(a, b, p) / at};
+  return f3{exact::div_(tri_area(p, b, c), at), exact::div_(tri_area(a, p, c), at), exact::div_(tri_area(a, b, p), at)};
 }
 // the same with the triangle's own area supplied (at == tri_area(a, b, c) bit for bit: a per-triangle table)
 __device__ __forceinline__ f3 bary_coords_at(f3 p, f3 a, f3 b, f3 c, float at) {
-  return f3{tri_area(p, b, c) / at, tri_area(a, p, c) / at, tri_area(a, b, p) / at};
+  return f3{exact::div_(tri_area(p, b, c), at), exact::div_(tri_area(a, p, c), at), exact::div_(tri_area(a, b, p), at)};
 }
 __device__ __forceinline__ f3 bary_mix(f3 bc, f3 a, f3 b, f3 c) {
   return f3{fmaf_(bc.z, c.x, fmaf_(bc.y, b.x, bc.x * a.x)), fmaf_(bc.z, c.y, fmaf_(bc.y, b.y, bc.x * a.y)),
@@ -42,7 +42,7 @@ __device__ __forceinline__ void reproject_pixel(int W, int H, const float* PVpre
   const f3 wpp = bary_mix(bc, va, vb, vc);
   const float clx = exact::mat_row_point(PVprev, 0, wpp), cly = exact::mat_row_point(PVprev, 1, wpp),
               clw = exact::mat_row_point(PVprev, 3, wpp);
-  const float ndx = clx / clw, ndy = cly / clw;
+  const float ndx = exact::div_(clx, clw), ndy = exact::div_(cly, clw);
   ppx = exact::f2i(fmaf_(ndx, 0.5f, 0.5f) * static_cast<float>(W));
   ppy = exact::f2i(fmaf_(ndy, 0.5f, 0.5f) * static_cast<float>(H));
 }

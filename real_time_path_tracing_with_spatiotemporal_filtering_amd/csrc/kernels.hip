@@ -23,6 +23,27 @@ struct HitRec {
   float u, v, ad;  // scaled barycentrics of the best hit, u NEGATED: b1 = -u/ad, b2 = v/ad (tri_test)
 };
 
+// which of the divisions of the tracing kernels use exact::div_ (rtpt_math.hpp).  Neither, as shipped: the tracing kernels
+// sit at their 64-VGPR budget (8 waves per SIMD), the short sequence keeps the refined reciprocal live next to the operands
+// of the long path, and what the fewer instructions bring (K2 at 4K 368.7 -> 364.9 us with both) the spills take back on the
+// BVH kernel (3.34 -> 3.41 ms).  profiles/r03_div_ab.csv; scripts/ab_libs.sh with -DRTPT_SHORT_DIV_TH=1 -DRTPT_SHORT_DIV_SHADE=1.
+#ifndef RTPT_SHORT_DIV_TH
+#define RTPT_SHORT_DIV_TH 0
+#endif
+#ifndef RTPT_SHORT_DIV_SHADE
+#define RTPT_SHORT_DIV_SHADE 0
+#endif
+#if RTPT_SHORT_DIV_TH
+#define RTPT_DIV_TH(a, b) exact::div_((a), (b))
+#else
+#define RTPT_DIV_TH(a, b) ((a) / (b))
+#endif
+#if RTPT_SHORT_DIV_SHADE
+#define RTPT_DIV_SH(a, b) exact::div_((a), (b))
+#else
+#define RTPT_DIV_SH(a, b) ((a) / (b))
+#endif
+
 // Scalar-triple-product form of Moller-Trumbore, plane normal n = e1 x e2 precomputed per triangle,
 // division deferred until a candidate passes the inside tests:
 //   det = -d.n,  tt = (o-v0).n,  c = (o-v0) x d,  u = e2.c,  v = -e1.c        (21 flops instead of 27)
@@ -50,7 +71,7 @@ __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float
   // no "ad > 0" term: with ad == 0 only u == v == 0 passes, th is then +inf (tt > 0), and +inf never beats h.t
   const bool ok = (u <= 0.0f) && (v >= 0.0f) && (v - u <= ad) && (tt < 0.0f);
   if (ok) {
-    const float th = (-tt) / ad;
+    const float th = RTPT_DIV_TH(-tt, ad);
 #else
   float det = -exact::dot(d, n);
   float tt = exact::dot(tv, n);
@@ -66,7 +87,7 @@ __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float
   // no "ad > 0" term: with ad == 0 only u == v == 0 passes, th is then +inf (tt > 0), and +inf never beats h.t
   bool ok = (u >= 0.0f) && (v >= 0.0f) && (u + v <= ad) && (tt > 0.0f);
   if (ok) {
-    float th = tt / ad;
+    float th = RTPT_DIV_TH(tt, ad);
     u = -u;  // HitRec keeps -u
 #endif
     bool better = th < h.t;
@@ -101,7 +122,7 @@ __device__ __forceinline__ void tri_pair_test(f3 o, f3 d, float4 r0, float4 r1, 
     const float v = u2f(f2u(exact::dot(e1, c)) ^ sm);
     const float ad = __builtin_fabsf(dn);
     if ((u <= 0.0f) && (v >= 0.0f) && (v - u <= ad) && (tt < 0.0f)) {
-      const float th = (-tt) / ad;
+      const float th = RTPT_DIV_TH(-tt, ad);
       if (th < h.t) {
         h.t = th;
         h.id1 = id1;
@@ -119,7 +140,7 @@ __device__ __forceinline__ void tri_pair_test(f3 o, f3 d, float4 r0, float4 r1, 
     const float v = u2f(f2u(e2c) ^ sm);  // e1_B . c
     const float ad = __builtin_fabsf(dn);
     if ((u <= 0.0f) && (v >= 0.0f) && (v - u <= ad) && (tt < 0.0f)) {
-      const float th = (-tt) / ad;
+      const float th = RTPT_DIV_TH(-tt, ad);
       if (th < h.t) {
         h.t = th;
         h.id1 = id1 + 1;
@@ -488,6 +509,8 @@ __device__ __forceinline__ float gradient_lambda(uint32_t id, f3 wp, const float
   f3 prv = phong(wpp, nrm, cam, light_prev, color_prev);      // :161 (current normal!)
   f3 tg = cur - prv;
   float delta = glsl_max(exact::length(cur), exact::length(prv));  // :166
+  // (hipcc's division on purpose: with the light at rest the numerator is +0 for every pixel, which exact::div_ would hand
+  // to the long path after paying for the short one)
   return glsl_min(1.0f, exact::length(tg) / delta);                // :167
 }
 
@@ -546,13 +569,13 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
   if (a.normals) a.normals[i] = a.normal_tab[h.id1];
   f3 wp{0.f, 0.f, 0.f};
   if (h.id1) {
-    float b1 = -h.u / h.ad, b2 = h.v / h.ad;
+    float b1 = RTPT_DIV_SH(-h.u, h.ad), b2 = RTPT_DIV_SH(h.v, h.ad);
     float b0 = 1.0f - b1 - b2;
     const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
     wp = bary_point(xyz(s[0]), xyz(s[1]), xyz(s[2]), b0, b1, b2);
     a.worldpos[i] = make_float4(wp.x, wp.y, wp.z, 1.0f);
     float cz = exact::mat_row_point(a.PV, 2, wp), cw = exact::mat_row_point(a.PV, 3, wp);
-    a.depth[i] = cz / cw;
+    a.depth[i] = exact::div_(cz, cw);
   } else {
     a.worldpos[i] = make_float4(0.f, 0.f, 0.f, 1.0f);  // clear colour main.cpp:1420
     a.depth[i] = 1.0f;                                  // clear depth  main.cpp:1421
@@ -594,7 +617,7 @@ __device__ __forceinline__ bool ray_hits_light(f3 o, f3 d, f3 c, float r2) {
   // addition and the correctly-rounded division are monotonic, so t1 <= t2 whenever neither is NaN: t1 > 0 implies
   // t2 > 0, and the disjunction IS "t2 > 0" (NaN operands make both comparisons false either way; 2a == 0 gives +-inf /
   // NaN with the same signs).  One division less per path segment.
-  float t2 = (-b + sq) / (2.0f * a);
+  float t2 = RTPT_DIV_SH(-b + sq, 2.0f * a);
   return t2 > 0.0f;
 }
 
@@ -629,7 +652,7 @@ __device__ __forceinline__ bool shade_segment(const PathtraceArgs& a, const HitR
   }
   const float4* s = a.scene.shade + 3 * static_cast<size_t>(h.id1 - 1);
   float4 s0 = s[0], s1 = s[1], s2 = s[2];
-  float b1 = -h.u / h.ad, b2 = h.v / h.ad;
+  float b1 = RTPT_DIV_SH(-h.u, h.ad), b2 = RTPT_DIV_SH(h.v, h.ad);
   float b0 = 1.0f - b1 - b2;                                       // :134
   f3 pos = bary_point(xyz(s0), xyz(s1), xyz(s2), b0, b1, b2);      // :137
   f3 n{s0.w, s1.w, s2.w};                                          // :150 (precomputed per triangle)
@@ -783,8 +806,8 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
       exact::sincos2pi(u2, sn, cs);
       float cx = fmaf_(a.jitter, rad * cs, static_cast<float>(px0) + 0.5f);  // :314
       float cy = fmaf_(a.jitter, rad * sn, static_cast<float>(py0) + 0.5f);
-      float ux = fmaf_(2.0f, cx, -fw) / fh;     // :315
-      float uy = -(fmaf_(2.0f, cy, -fh) / fh);  // :316
+      float ux = RTPT_DIV_SH(fmaf_(2.0f, cx, -fw), fh);     // :315
+      float uy = -RTPT_DIV_SH(fmaf_(2.0f, cy, -fh), fh);  // :316
       d = exact::normalize(f3{a.slope * ux, a.slope * uy, -1.0f});  // :319-320
       o = ld3(a.cam);
       acc = f3{1.f, 1.f, 1.f};  // :201
@@ -1025,6 +1048,41 @@ __global__ void k_selftest_exhaustive(int op, unsigned long long* out) {
   }
 }
 
+// exact::div_ against hipcc's division.  mode 0: slice `pass` of 256 of the enumeration of all 2^23 x 2^23 significand pairs
+// (thread = one b, 2^15 values of a); mode 1: 2^33 operand pairs of arbitrary bits (every exponent, sign, zero, infinity,
+// NaN and denormal class gets hit: the long path and the range test) from a counter-based generator
+__global__ void k_selftest_div(int mode, uint32_t pass, unsigned long long* out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 2^23-1
+  unsigned bad = 0;
+  uint32_t fa = 0, fb = 0;
+  if (mode == 0) {
+    const float b = u2f(0x3f800000u | t);
+    for (uint32_t i = 0; i < (1u << 15); i++) {
+      const uint32_t ma = (pass << 15) + i;
+      const float a = u2f(0x3f800000u | ma);
+      if (f2u(exact::div_(a, b)) != f2u(a / b)) { bad++; fa = f2u(a); fb = f2u(b); }
+    }
+  } else {
+    uint32_t st = exact::rng_seed(t, pass, 0x9e3779b9u, 1u);
+    for (uint32_t i = 0; i < (1u << 10); i++) {
+      st = st * 747796405u + 2891336453u;
+      uint32_t ua = ((st >> ((st >> 28) + 4u)) ^ st) * 277803737u;
+      ua ^= ua >> 22;
+      st = st * 747796405u + 2891336453u;
+      uint32_t ub = ((st >> ((st >> 28) + 4u)) ^ st) * 277803737u;
+      ub ^= ub >> 22;
+      if (i & 1u) ub = (ub & 0x807fffffu) | (ua & 0x7f800000u);  // every other pair: same exponent (quotients near 1)
+      const float a = u2f(ua), b = u2f(ub);
+      const uint32_t got = f2u(exact::div_(a, b)), want = f2u(a / b);
+      if (got != want && !((got & 0x7fffffffu) > 0x7f800000u && (want & 0x7fffffffu) > 0x7f800000u)) { bad++; fa = ua; fb = ub; }
+    }
+  }
+  if (bad && atomicAdd(out, static_cast<unsigned long long>(bad)) == 0) {
+    out[1] = fa;
+    out[2] = fb;
+  }
+}
+
 template <bool BVH>
 __global__ __launch_bounds__(kThreads) void k_selftest_trace(SceneView sc, const float* rays, size_t n, float tmax,
                                                              uint32_t* out_id, float* out_t) {
@@ -1125,6 +1183,9 @@ void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStre
 }
 void launch_selftest_exhaustive(int op, unsigned long long* out, hipStream_t s) {
   hipLaunchKernelGGL(k_selftest_exhaustive, dim3((1u << 26) / 256u), dim3(256), 0, s, op, out);  // 2^26 threads x 64 patterns
+}
+void launch_selftest_div(int mode, uint32_t pass, unsigned long long* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_selftest_div, dim3((1u << 23) / 256u), dim3(256), 0, s, mode, pass, out);
 }
 void launch_selftest_trace(const SceneView& scene, const float* rays, size_t n, float tmax, uint32_t* out_id,
                            float* out_t, hipStream_t s) {

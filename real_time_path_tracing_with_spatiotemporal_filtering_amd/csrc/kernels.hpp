@@ -277,6 +277,7 @@ void launch_stamp_depth(const FrameGeom& g, float4* color, const float* depth, h
 void launch_present(const FrameGeom& g, const float4* image, uint32_t* dst, hipStream_t s);
 void launch_selftest_math(int op, const float* in, float* out, size_t n, hipStream_t s);
 void launch_selftest_exhaustive(int op, unsigned long long* out, hipStream_t s);
+void launch_selftest_div(int mode, uint32_t pass, unsigned long long* out, hipStream_t s);
 void launch_selftest_trace(const SceneView& scene, const float* rays, size_t n, float tmax, uint32_t* out_id,
                            float* out_t, hipStream_t s);
 

@@ -72,6 +72,24 @@ def test_short_sqrt_and_reciprocal_are_ieee_on_every_pattern(hip_lib, oracle, op
     assert np.array_equal(bits(got), bits(want)), (x[bits(got) != bits(want)], got[bits(got) != bits(want)])
 
 
+def test_short_division_is_ieee(hip_lib):
+    """exact::div_ (rtpt_math.hpp): reciprocal + one residual correction instead of the compiler's division.  The proof is an
+    enumeration of all 2^23 x 2^23 significand pairs (scripts/micro/exact_div.hip, profiles/r03_exact_div_exhaustive.txt: 0
+    mismatches); here eight of its 256 slices re-run on the shipped function (RTPT_SLOW_TESTS=1: all 256, ~40 s), plus 2^34
+    operand pairs of arbitrary bits for the range test and the long path"""
+    import os
+    with hip_lib.Context(hip_lib.config_default(64, 64)) as ctx:
+        if os.environ.get("RTPT_SLOW_TESTS") == "1":
+            bad, first = ctx.selftest_div(0, 0, 256)
+            assert bad == 0, [hex(v) for v in first]
+        else:
+            for p in (0, 37, 90, 127, 128, 171, 222, 255):
+                bad, first = ctx.selftest_div(0, p, 1)
+                assert bad == 0, (p, [hex(v) for v in first])
+        bad, first = ctx.selftest_div(1, 0, 2)
+        assert bad == 0, [hex(v) for v in first]
+
+
 def test_pcg_stream_bit_exact(hip_lib, oracle):
     states = np.random.default_rng(1).integers(0, 1 << 32, 1 << 18, dtype=np.uint64).astype(np.uint32)
     with hip_lib.Context(hip_lib.config_default(64, 64)) as ctx:
