@@ -101,6 +101,7 @@ struct rtpt_ctx {
   rt::BvhGrid bvh_grid{};
   int bvh_depth = 0;
   bool tris_paired = false;  // every (2q, 2q+1) is a fan pair: same v0, v2_A == v1_B bitwise (kernels.hip tri_pair_test)
+  bool leaf_pairs = false;   // ... and the BVH was built over those pairs (bvh.hpp build_bvh(pairs))
   bool no_pairing = false;   // RTPT_NO_TRI_PAIRS=1: A/B switch
   std::vector<float> host_tris;  // flattened world-space triangles, kept for small scenes (screen bounds)
   // animated model matrix (main.cpp:1469 recomputes ubo.model every frame; it is the identity there): the scene as
@@ -320,6 +321,7 @@ rt::SceneView scene_view(const rtpt_ctx* c) {
   s.n_tris = c->n_tris;
   s.use_bvh = c->use_bvh ? 1u : 0u;
   s.paired = (c->tris_paired && !c->no_pairing) ? 1u : 0u;
+  s.leaf_pairs = c->leaf_pairs ? 1u : 0u;
   s.stack_depth = static_cast<uint32_t>(c->bvh_depth + 2 < 8 ? 8 : c->bvh_depth + 2);
   s.stack_lds = std::min<uint32_t>(s.stack_depth, static_cast<uint32_t>(c->bvh_stack_lds));
   s.stack_spill = static_cast<uint32_t*>(c->stack_spill.ptr);
@@ -728,8 +730,17 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
           o[2] = v[2];
         }
       }
+  // fan pairs (a, b, c), (a, c, d): the posed records are computed from these vertices with one arithmetic, so bitwise
+  // equality here is bitwise equality of v0 and of e2_A / e1_B on the device, whatever the model matrix
+  bool paired_all = total >= 2 && total % 2 == 0;
+  for (uint32_t q = 0; paired_all && q < total / 2; q++) {
+    const float* ta = tris.data() + 18 * static_cast<size_t>(q);
+    const float* tb = ta + 9;
+    paired_all = std::memcmp(ta, tb, 12) == 0 && std::memcmp(ta + 6, tb + 3, 12) == 0;
+  }
+  const bool leaf_pairs = paired_all && !c->no_pairing;
   rt::Bvh bvh;  // built aside: a failed upload leaves the context's scene (and the topology a later refit uses) untouched
-  rt::build_bvh(tris.data(), total, bvh);
+  rt::build_bvh(tris.data(), total, bvh, 1e-5f, leaf_pairs);
   if (bvh.max_depth >= rt::kBvhMaxDepth) return fail(RTPT_E_INVALID, "BVH deeper than the traversal stack");
   if (bvh.leaf_order.size() != total) return fail(RTPT_E_INVALID, "internal: BVH lost triangles");
 
@@ -802,14 +813,8 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
     c->host_tris = tris;
   else
     c->host_tris.clear();
-  // fan pairs (a, b, c), (a, c, d): the posed records are computed from these vertices with one arithmetic, so bitwise
-  // equality here is bitwise equality of v0 and of e2_A / e1_B on the device, whatever the model matrix
-  c->tris_paired = total >= 2 && total % 2 == 0 && total <= static_cast<uint32_t>(rt::kCullMaxTris);
-  for (uint32_t q = 0; c->tris_paired && q < total / 2; q++) {
-    const float* ta = tris.data() + 18 * static_cast<size_t>(q);
-    const float* tb = ta + 9;
-    c->tris_paired = std::memcmp(ta, tb, 12) == 0 && std::memcmp(ta + 6, tb + 3, 12) == 0;
-  }
+  c->tris_paired = paired_all && total <= static_cast<uint32_t>(rt::kCullMaxTris);  // the brute-force loops
+  c->leaf_pairs = leaf_pairs;                                                        // the tree that was just built
   c->obj_tris.swap(tris);
   c->bvh_host = std::move(bvh);  // only now: the upload succeeded
   for (int i = 0; i < 16; i++) c->model[i] = (i % 5 == 0) ? 1.0f : 0.0f;

@@ -39,7 +39,8 @@ struct Box {
 struct Prim {
   Box box;
   float c[3];
-  uint32_t id;
+  uint32_t id;  // first triangle
+  uint32_t w;   // triangles this primitive stands for: 1, or 2 (id, id + 1) when the scene is built over fan pairs
 };
 
 struct Child {
@@ -62,10 +63,11 @@ struct Builder {
     Child c;
     c.box.reset();
     c.idx = static_cast<uint32_t>(out->leaf_order.size());
-    c.cnt = hi - lo;
+    c.cnt = 0;
     for (uint32_t i = lo; i < hi; i++) {
       c.box.grow(prims[i].box);
-      out->leaf_order.push_back(prims[i].id);
+      for (uint32_t k = 0; k < prims[i].w; k++) out->leaf_order.push_back(prims[i].id + k);
+      c.cnt += prims[i].w;
     }
     return c;
   }
@@ -73,8 +75,9 @@ struct Builder {
   // returns the descriptor of the subtree over prims[lo,hi)
   Child build(uint32_t lo, uint32_t hi, int depth) {
     out->max_depth = std::max(out->max_depth, depth);
-    uint32_t n = hi - lo;
-    if (n <= static_cast<uint32_t>(kBvhMinLeaf)) return make_leaf(lo, hi);
+    const uint32_t w = prims[lo].w;  // the same for every primitive of a build
+    uint32_t n = (hi - lo) * w;      // triangles
+    if (hi - lo == 1 || n <= static_cast<uint32_t>(kBvhMinLeaf)) return make_leaf(lo, hi);
     const bool may_leaf = n <= static_cast<uint32_t>(kBvhMaxLeaf);  // SAH decides below
 
     Box cb, bb;
@@ -105,7 +108,7 @@ struct Builder {
         for (uint32_t i = lo; i < hi; i++) {
           int b = std::min(kBins - 1, static_cast<int>((prims[i].c[a] - cb.mn[a]) * scale));
           bins[b].grow(prims[i].box);
-          cnt[b]++;
+          cnt[b] += w;
         }
         float right_area[kBins];
         uint32_t right_cnt[kBins];
@@ -159,7 +162,7 @@ struct Builder {
           axis = a;
         }
       }
-      mid = lo + n / 2;
+      mid = lo + (hi - lo) / 2;
       std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi,
                        [axis](const Prim& x, const Prim& y) {
                          return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.id < y.id);
@@ -196,21 +199,23 @@ struct Builder {
 
 }  // namespace
 
-void build_bvh(const float* tris, uint32_t n, Bvh& out, float pad_rel) {
+void build_bvh(const float* tris, uint32_t n, Bvh& out, float pad_rel, bool pairs) {
   out.nodes.clear();
   out.leaf_order.clear();
   out.max_depth = 0;
   Builder b;
   b.out = &out;
-  b.prims.resize(n);
+  const uint32_t w = (pairs && n >= 2 && n % 2 == 0) ? 2u : 1u;
+  b.prims.resize(n / w);
   Box scene;
   scene.reset();
-  for (uint32_t i = 0; i < n; i++) {
+  for (uint32_t i = 0; i < n / w; i++) {
     Prim& p = b.prims[i];
     p.box.reset();
-    for (int k = 0; k < 3; k++) p.box.grow(tris + 9 * static_cast<size_t>(i) + 3 * k);
+    for (uint32_t k = 0; k < 3 * w; k++) p.box.grow(tris + 9 * static_cast<size_t>(i) * w + 3 * k);
     for (int a = 0; a < 3; a++) p.c[a] = 0.5f * (p.box.mn[a] + p.box.mx[a]);
-    p.id = i;
+    p.id = i * w;
+    p.w = w;
     scene.grow(p.box);
   }
   for (int a = 0; a < 3; a++) {
@@ -232,7 +237,7 @@ void build_bvh(const float* tris, uint32_t n, Bvh& out, float pad_rel) {
   if (n <= static_cast<uint32_t>(kBvhMaxLeaf)) {
     // single-leaf scene: root pair = {leaf, absent}
     out.nodes.emplace_back();
-    Child l = b.make_leaf(0, n);
+    Child l = b.make_leaf(0, n / w);
     Child r;
     r.box.reset();
     r.idx = kBvhEmpty;
@@ -244,7 +249,7 @@ void build_bvh(const float* tris, uint32_t n, Bvh& out, float pad_rel) {
     b.write_pair(0, l, r);
     return;
   }
-  Child root = b.build(0, n, 0);
+  Child root = b.build(0, n / w, 0);
   (void)root;  // n > kBvhMaxLeaf: the root is interior and is node 0 by construction
 }
 

@@ -69,7 +69,10 @@ BvhGrid pack_quantised_nodes(const Bvh& bvh, std::vector<BvhNodeQ>& out);
 // tris: n x 9 floats (v0,v1,v2 world space).  Boxes are padded by `pad_rel` x scene diagonal so
 // that the conservative slab test can never reject a triangle the shared ray-triangle routine
 // would accept (closest hit = min over (t, id) must not depend on the structure, D4).
-void build_bvh(const float* tris, uint32_t n, Bvh& out, float pad_rel = 1e-5f);
+// pairs: triangles (2q, 2q+1) are built as ONE primitive each (the two halves of a fan-triangulated quad, which the caller
+// has checked): they land in the same leaf, next to each other and in this order, leaves hold 2 or 4 triangles, and the
+// traversal tests them with the shared-edge pair test.  n must be even.
+void build_bvh(const float* tris, uint32_t n, Bvh& out, float pad_rel = 1e-5f, bool pairs = false);
 
 // Same topology and leaf order, new vertex positions (an animated `model` matrix, main.cpp:1469): recomputes every
 // child box bottom-up from the moved triangles, the scene bounds and the padding.  The tree stays valid for any motion;

@@ -151,6 +151,57 @@ __device__ __forceinline__ void tri_pair_test(f3 o, f3 d, float4 r0, float4 r1, 
     }
   }
 }
+
+// the same for a BVH leaf: leaves are met in traversal order, so equal distances keep the lower id (tri_test<true>'s rule),
+// and the two ids come from the leaf's id list
+__device__ __forceinline__ void tri_pair_test_leaf(f3 o, f3 d, float4 r0, float4 r1, float4 r2, float4 q1, float4 q2, uint32_t id1,
+                                                   uint32_t id1b, HitRec& h) {
+  const f3 v0{r0.x, r0.y, r0.z}, e1{r0.w, r1.x, r1.y}, e2{r1.z, r1.w, r2.x}, n{r2.y, r2.z, r2.w};
+  const f3 e2b{q1.z, q1.w, q2.x}, nb{q2.y, q2.z, q2.w};  // B: e1_B == e2 (bitwise), v0_B == v0
+  const f3 tv = o - v0;
+  const f3 c = exact::cross(tv, d);
+  const float e2c = exact::dot(e2, c);
+  {
+    const float dn = exact::dot(d, n);
+    const uint32_t sm = f2u(dn) & 0x80000000u;
+    const float tt = u2f(f2u(exact::dot(tv, n)) ^ sm);
+    const float u = u2f(f2u(e2c) ^ sm);
+    const float v = u2f(f2u(exact::dot(e1, c)) ^ sm);
+    const float ad = __builtin_fabsf(dn);
+    if ((u <= 0.0f) && (v >= 0.0f) && (v - u <= ad) && (tt < 0.0f)) {
+      const float th = RTPT_DIV_TH(-tt, ad);
+      bool better = th < h.t;
+      better = better || (th == h.t && h.id1 != 0 && id1 < h.id1);
+      if (better) {
+        h.t = th;
+        h.id1 = id1;
+        h.u = u;
+        h.v = v;
+        h.ad = ad;
+      }
+    }
+  }
+  {
+    const float dn = exact::dot(d, nb);
+    const uint32_t sm = f2u(dn) & 0x80000000u;
+    const float tt = u2f(f2u(exact::dot(tv, nb)) ^ sm);
+    const float u = u2f(f2u(exact::dot(e2b, c)) ^ sm);
+    const float v = u2f(f2u(e2c) ^ sm);  // e1_B . c
+    const float ad = __builtin_fabsf(dn);
+    if ((u <= 0.0f) && (v >= 0.0f) && (v - u <= ad) && (tt < 0.0f)) {
+      const float th = RTPT_DIV_TH(-tt, ad);
+      bool better = th < h.t;
+      better = better || (th == h.t && h.id1 != 0 && id1b < h.id1);
+      if (better) {
+        h.t = th;
+        h.id1 = id1b;
+        h.u = u;
+        h.v = v;
+        h.ad = ad;
+      }
+    }
+  }
+}
 #endif
 
 // Small scenes (<= 64 triangles, the Cornell box has 32): every lane of the wave tests the same
@@ -268,6 +319,7 @@ constexpr uint32_t kSentinel = 0xFFFFFFFEu;
 #define RTPT_LEAF_BATCH 2  // 1: 3.72 ms, 2: 3.65 ms, 4: 4.79 ms (registers) on the 1.15M-triangle trace
 #endif
 
+template <bool PAIRS>  // the tree was built over fan pairs (bvh.hpp): a leaf is one or two of them (A, B, A, B)
 __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d, HitRec& h, uint32_t* stack,
                                                int tid, int nt = kThreads) {
   // A ray with a NaN component cannot hit anything (every comparison of tri_test fails, D7) — but min/max drop
@@ -310,6 +362,17 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
   };
   auto test_leaf = [&](uint32_t ref) {
     const uint32_t first = (ref & ~kLeafBit) >> 2, cnt = (ref & 3u) + 1u;
+#if RTPT_TRI_XOR_SIGN
+    if (PAIRS) {
+      for (uint32_t j = 0; j < cnt; j += 2) {
+        const float4* r = sc.isect_leaf + 3 * static_cast<size_t>(first + j);
+        const float4 a0 = r[0], a1 = r[1], a2 = r[2], b1 = r[4], b2 = r[5];
+        const uint32_t ia = sc.leaf_ids[first + j], ib = sc.leaf_ids[first + j + 1];
+        tri_pair_test_leaf(o, d, a0, a1, a2, b1, b2, ia + 1, ib + 1, h);
+      }
+      return;
+    }
+#endif
 #if RTPT_LEAF_BATCH > 1
     // fetch the records of RTPT_LEAF_BATCH triangles before testing any of them: one memory round trip per
     // batch instead of one per triangle (indices past the leaf are clamped to its last triangle and skipped)
@@ -394,11 +457,12 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
 #endif
 }
 
-template <bool BVH>
+template <int BVH>
 __device__ __forceinline__ void closest_hit(const SceneView& sc, f3 o, f3 d, HitRec& h, uint32_t* stack, int tid,
                                             int nt = kThreads) {
+  // BVH: 0 brute force, 1 BVH over triangles, 2 BVH over fan pairs (SceneView::leaf_pairs) — a kernel holds one leaf routine
   if (BVH)
-    closest_hit_bvh(sc, o, d, h, stack, tid, nt);
+    closest_hit_bvh<BVH == 2>(sc, o, d, h, stack, tid, nt);
   else
     closest_hit_brute(sc, o, d, h);
 }
@@ -542,7 +606,7 @@ __global__ void k_ray_tables(int W, int H, float p00, float p11, float* dvx, flo
   }
 }
 
-template <bool BVH>
+template <int BVH>
 __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
   extern __shared__ uint32_t stack[];  // BVH: stack_depth x 256 entries (dynamic); unused otherwise
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
@@ -744,7 +808,7 @@ struct PathState {  // SoA in LDS, one slot per thread
 #ifndef RTPT_PT_CENTER_OUT
 #define RTPT_PT_CENTER_OUT 1
 #endif
-template <bool BVH, bool COMPACT>
+template <int BVH, bool COMPACT>
 __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
   // dynamic LDS, two tenants that are never live together: the BVH node stack (stack_depth x 256 entries, only
   // inside closest_hit) and the compaction exchange buffer (only between the barriers of the compaction step).
@@ -912,7 +976,7 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
 #ifndef RTPT_PT_BVH_WAVES
 #define RTPT_PT_BVH_WAVES 8
 #endif
-template <bool BVH, bool COMPACT>
+template <int BVH, bool COMPACT>
 __global__ __launch_bounds__(kPtThreads)
 #if RTPT_PT_BVH_WAVES
 __attribute__((amdgpu_waves_per_eu(RTPT_PT_BVH_WAVES, RTPT_PT_BVH_WAVES)))
@@ -929,7 +993,7 @@ void k_pathtrace_small(PathtraceArgs a) {
   pathtrace_tile<false, COMPACT>(a);
 }
 
-template <bool BVH>
+template <int BVH>
 __global__ __launch_bounds__(kPtThreads) void k_pathtrace_queue(PathtraceArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t stack[];
   PathState& st = *reinterpret_cast<PathState*>(stack);
@@ -1083,7 +1147,7 @@ __global__ void k_selftest_div(int mode, uint32_t pass, unsigned long long* out)
   }
 }
 
-template <bool BVH>
+template <int BVH>
 __global__ __launch_bounds__(kThreads) void k_selftest_trace(SceneView sc, const float* rays, size_t n, float tmax,
                                                              uint32_t* out_id, float* out_t) {
   extern __shared__ uint32_t stack[];  // BVH: stack_depth x 256 entries (dynamic); unused otherwise
@@ -1115,10 +1179,12 @@ void launch_ray_tables(int W, int H, float p00, float p11, float* dvx, float* dv
 }
 void launch_gbuffer(const GbufferArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;
-  if (a.scene.use_bvh)
-    hipLaunchKernelGGL(k_gbuffer<true>, grid_for(a.g), dim3(kBlockX, kBlockY), a.scene.stack_lds * kThreads * 4, s, a);
+  if (a.scene.use_bvh && a.scene.leaf_pairs)
+    hipLaunchKernelGGL(k_gbuffer<2>, grid_for(a.g), dim3(kBlockX, kBlockY), a.scene.stack_lds * kThreads * 4, s, a);
+  else if (a.scene.use_bvh)
+    hipLaunchKernelGGL(k_gbuffer<1>, grid_for(a.g), dim3(kBlockX, kBlockY), a.scene.stack_lds * kThreads * 4, s, a);
   else
-    hipLaunchKernelGGL(k_gbuffer<false>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
+    hipLaunchKernelGGL(k_gbuffer<0>, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
 }
 void launch_gradient(const GradientArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;
@@ -1145,13 +1211,17 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
   b.q_out_count = split ? a.queue_count : nullptr;
   if (split) (void)hipMemsetAsync(a.queue_count, 0, 2 * kPathQueues * sizeof(uint32_t), s);
   if (a.compact) {
-    if (a.scene.use_bvh)
-      hipLaunchKernelGGL((k_pathtrace<true, true>), grid, block, dyn, s, b);
+    if (a.scene.use_bvh && a.scene.leaf_pairs)
+      hipLaunchKernelGGL((k_pathtrace<2, true>), grid, block, dyn, s, b);
+    else if (a.scene.use_bvh)
+      hipLaunchKernelGGL((k_pathtrace<1, true>), grid, block, dyn, s, b);
     else
       hipLaunchKernelGGL((k_pathtrace_small<true>), grid, block, dyn, s, b);
   } else {
-    if (a.scene.use_bvh)
-      hipLaunchKernelGGL((k_pathtrace<true, false>), grid, block, dyn, s, b);
+    if (a.scene.use_bvh && a.scene.leaf_pairs)
+      hipLaunchKernelGGL((k_pathtrace<2, false>), grid, block, dyn, s, b);
+    else if (a.scene.use_bvh)
+      hipLaunchKernelGGL((k_pathtrace<1, false>), grid, block, dyn, s, b);
     else
       hipLaunchKernelGGL((k_pathtrace_small<false>), grid, block, dyn, s, b);
   }
@@ -1170,10 +1240,12 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
     c.q_out = more ? a.queue[cur ^ 1] : nullptr;
     c.q_out_count = more ? a.queue_count + (cur ^ 1) * kPathQueues : nullptr;
     if (more) (void)hipMemsetAsync(a.queue_count + (cur ^ 1) * kPathQueues, 0, kPathQueues * sizeof(uint32_t), s);
-    if (a.scene.use_bvh)
-      hipLaunchKernelGGL((k_pathtrace_queue<true>), qgrid, block, dyn_queue, s, c);
+    if (a.scene.use_bvh && a.scene.leaf_pairs)
+      hipLaunchKernelGGL((k_pathtrace_queue<2>), qgrid, block, dyn_queue, s, c);
+    else if (a.scene.use_bvh)
+      hipLaunchKernelGGL((k_pathtrace_queue<1>), qgrid, block, dyn_queue, s, c);
     else
-      hipLaunchKernelGGL((k_pathtrace_queue<false>), qgrid, block, dyn_queue, s, c);
+      hipLaunchKernelGGL((k_pathtrace_queue<0>), qgrid, block, dyn_queue, s, c);
     if (end >= a.max_segments) break;
   }
 }
@@ -1191,10 +1263,12 @@ void launch_selftest_trace(const SceneView& scene, const float* rays, size_t n, 
                            float* out_t, hipStream_t s) {
   if (!n) return;
   dim3 grid((n + kThreads - 1) / kThreads), block(kThreads);
-  if (scene.use_bvh)
-    hipLaunchKernelGGL(k_selftest_trace<true>, grid, block, scene.stack_lds * kThreads * 4, s, scene, rays, n, tmax, out_id, out_t);
+  if (scene.use_bvh && scene.leaf_pairs)
+    hipLaunchKernelGGL(k_selftest_trace<2>, grid, block, scene.stack_lds * kThreads * 4, s, scene, rays, n, tmax, out_id, out_t);
+  else if (scene.use_bvh)
+    hipLaunchKernelGGL(k_selftest_trace<1>, grid, block, scene.stack_lds * kThreads * 4, s, scene, rays, n, tmax, out_id, out_t);
   else
-    hipLaunchKernelGGL(k_selftest_trace<false>, grid, block, 0, s, scene, rays, n, tmax, out_id, out_t);
+    hipLaunchKernelGGL(k_selftest_trace<0>, grid, block, 0, s, scene, rays, n, tmax, out_id, out_t);
 }
 
 }  // namespace rt

@@ -22,6 +22,7 @@ struct SceneView {
   uint32_t n_tris;
   uint32_t use_bvh;  // 0: brute force over isect_id, 1: BVH traversal
   uint32_t paired;   // brute force only: triangles (2q, 2q+1) share v0 and the edge v2_A == v1_B bitwise (fan-triangulated faces)
+  uint32_t leaf_pairs;  // BVH: built over such pairs (bvh.hpp): every leaf holds whole pairs, A right before B
   uint32_t stack_depth;  // BVH traversal stack entries per lane (tree depth + 2)
   // The first stack_lds entries of a lane's stack live in LDS (what sets the workgroups per CU: the 1.15M-triangle
   // tree is 28 deep, 30 KB per workgroup = 5 per CU, and its trace is that sensitive to occupancy: 2 / 3 / 4 / 5

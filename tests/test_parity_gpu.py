@@ -796,6 +796,16 @@ def test_bvh_million_triangle_rays(hip_lib, oracle, cornell):
         finally:
             del os.environ["RTPT_BVH_STACK_LDS"]
         assert np.array_equal(ids2, ids) and np.array_equal(bits(ts2), bits(ts)), levels
+    # the lattice is made of fan pairs, so the tree above was built over pairs and its leaves ran the shared-edge pair test
+    # (bvh.hpp build_bvh(pairs)); RTPT_NO_TRI_PAIRS=1 builds over triangles and tests them one by one: same hits
+    os.environ["RTPT_NO_TRI_PAIRS"] = "1"
+    try:
+        with hip_lib.Context(hip_lib.config_default(64, 64)) as ctx:
+            ctx.scene_upload(vx, ti, xf)
+            ids3, ts3 = ctx.selftest_trace(rays)
+    finally:
+        del os.environ["RTPT_NO_TRI_PAIRS"]
+    assert np.array_equal(ids3, ids) and np.array_equal(bits(ts3), bits(ts))
 
 
 def test_bvh_stack_spill_whole_frames(hip_lib, cornell, monkeypatch):
