@@ -421,6 +421,9 @@ constexpr int kShThreads = 64 * kShWaves;
 // 2^(k-1), passed as a.stride) run in this kernel too — the same comb staging with 2R halo rows per workgroup and 2R*s
 // halo columns per segment, and the arithmetic of k_atrous_ext (h kept per tap, correctly-rounded final division), so
 // the two are bit-identical.  25 taps are 25 LDS reads here instead of 75 global loads per pixel.
+#ifndef RTPT_FINAL_WAVES
+#define RTPT_FINAL_WAVES 1  // id-pair final pass: waves per SIMD to squeeze the registers for (A/B: 4 by itself)
+#endif
 #ifndef RTPT_COMB_MIN_WAVES
 #define RTPT_COMB_MIN_WAVES 0
 #endif
@@ -431,7 +434,7 @@ __attribute__((amdgpu_waves_per_eu(RTPT_COMB_MIN_WAVES)))
 #else
 // the per-pixel-normal final pass sits at the edge of six waves per SIMD (79-81 VGPRs as the surrounding code changes;
 // 142-147 us with six waves, 169-176 us with five at 4K): pin it.  Every other instantiation keeps what it gets.
-__attribute__((amdgpu_waves_per_eu(FINAL && NRM && R == 1 && !EXTA && !VAR && !EXACT ? 6 : 1)))
+__attribute__((amdgpu_waves_per_eu(FINAL && NRM && R == 1 && !EXTA && !VAR && !EXACT ? 6 : (FINAL && !NRM && R == 1 && !EXTA && !VAR && !EXACT ? RTPT_FINAL_WAVES : 1))))
 #endif
 void k_atrous_comb_sh(AtrousArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
