@@ -346,9 +346,13 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
   const int lds_levels = static_cast<int>(sc.stack_lds);
   const size_t spill_stride = static_cast<size_t>(gridDim.x) * gridDim.y * nt;
   uint32_t* const spill = sc.stack_spill + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * nt + tid;
+  // the LDS half through an LDS-typed pointer: a generic one lets the compiler fold the two halves of a pop into one
+  // flat_load_dword of a selected address
+  using lds_u32 = __attribute__((address_space(3))) uint32_t;
+  lds_u32* const stack_lds = (lds_u32*)stack;
   auto push = [&](uint32_t v) {
     if (sp < lds_levels)
-      stack[sp * nt + tid] = v;
+      stack_lds[sp * nt + tid] = v;
     else
       spill[static_cast<size_t>(sp - lds_levels) * spill_stride] = v;
     sp++;
@@ -356,7 +360,12 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
   auto pop = [&]() -> uint32_t {
     if (sp > 0) {
       sp--;
-      return sp < lds_levels ? stack[sp * nt + tid] : spill[static_cast<size_t>(sp - lds_levels) * spill_stride];
+      // always an LDS read (slot 0 when the entry is in the global half), then the rare global read under its own branch;
+      // as one conditional expression over generic pointers the two became ONE flat_load_dword of a selected address,
+      // and every pop went through the vector-memory pipe
+      uint32_t v = stack_lds[(sp < lds_levels ? sp : 0) * nt + tid];
+      if (__builtin_expect(sp >= lds_levels, 0)) v = spill[static_cast<size_t>(sp - lds_levels) * spill_stride];
+      return v;
     }
     return kSentinel;
   };
