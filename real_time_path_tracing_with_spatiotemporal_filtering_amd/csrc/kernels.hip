@@ -374,9 +374,10 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
 #if RTPT_TRI_XOR_SIGN
     if (PAIRS) {
       for (uint32_t j = 0; j < cnt; j += 2) {
-        const float4* r = sc.isect_leaf + 3 * static_cast<size_t>(first + j);
+        const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sc.isect_leaf) + (first + j) * 48u);
         const float4 a0 = r[0], a1 = r[1], a2 = r[2], b1 = r[4], b2 = r[5];
-        const uint32_t ia = sc.leaf_ids[first + j], ib = sc.leaf_ids[first + j + 1];
+        const uint32_t* pid = reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(sc.leaf_ids) + (first + j) * 4u);
+        const uint32_t ia = pid[0], ib = pid[1];
         tri_pair_test_leaf(o, d, a0, a1, a2, b1, b2, ia + 1, ib + 1, h);
       }
       return;
@@ -409,7 +410,9 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
 #endif
   };
   auto node_step = [&]() {
-    const uint4* np = reinterpret_cast<const uint4*>(sc.nodes + cur);
+    // base + 32-bit byte offset (a tree has < 2^27 nodes): the loads take the scalar base and a 32-bit vector offset instead
+    // of a 64-bit address computed per step
+    const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(sc.nodes) + (cur << 5));
     const uint4 a = np[0], b = np[1];
     const uint32_t cl = b.z, cr = b.w;
     const float tb = h.t;
