@@ -319,13 +319,82 @@ constexpr uint32_t kSentinel = 0xFFFFFFFEu;
 #define RTPT_LEAF_BATCH 2  // 1: 3.72 ms, 2: 3.65 ms, 4: 4.79 ms (registers) on the 1.15M-triangle trace
 #endif
 
+// Counting build (-DRTPT_BVH_COUNT=1, scripts/bvh_count.py; never the shipped library): where the traversal's idle lanes are.
+// Per call of closest_hit_bvh and wave: trips of the node loop / of the leaf loop, the lanes active in each trip, and the
+// longest lane's trips — summed per bucket (0 = K0's primary rays, 1 + s = path segment s) into g_bvh_count[bucket][8]:
+//   {node trips, node lane-trips, leaf trips, leaf lane-trips, max node trips of a lane, max leaf trips of a lane, calls, lanes}
+#ifndef RTPT_BVH_COUNT
+#define RTPT_BVH_COUNT 0
+#endif
+#if RTPT_BVH_COUNT
+constexpr int kCountBuckets = 16;
+__device__ unsigned long long g_bvh_count[kCountBuckets][8];
+#define RTPT_COUNT_TRIP(slot)                                                                   \
+  do {                                                                                          \
+    const unsigned long long m_ = __ballot(1);                                                  \
+    if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(m_))) {                    \
+      cnt_w[slot] += 1u;                                                                        \
+      cnt_w[slot + 1] += static_cast<uint32_t>(__builtin_popcountll(m_));                       \
+    }                                                                                           \
+  } while (0)
+#else
+#define RTPT_COUNT_TRIP(slot) do {} while (0)
+#endif
+
+// Timeline build (-DRTPT_TILE_TIMELINE=1, scripts/tile_timeline.py; never the shipped library): start and end of every
+// workgroup of the last launch of a kernel on the 100 MHz wall clock, and where it ran (HW_ID, XCC_ID).
+#ifndef RTPT_TILE_TIMELINE
+#define RTPT_TILE_TIMELINE 0
+#endif
+#if RTPT_TILE_TIMELINE
+constexpr uint32_t kTimelineMax = 1u << 16;
+__device__ unsigned long long g_timeline[2][kTimelineMax][3];  // [kernel: 0 K0, 1 K2][workgroup]{start, end, hw}
+struct TimelineScope {
+  unsigned long long t0;
+  uint32_t k, b;
+  __device__ TimelineScope(uint32_t kernel, uint32_t block) : t0(wall_clock64()), k(kernel), b(block) {}
+  __device__ ~TimelineScope() {
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0 && b < kTimelineMax) {
+      g_timeline[k][b][0] = t0;
+      g_timeline[k][b][1] = wall_clock64();
+      g_timeline[k][b][2] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11))) << 32) |
+                            __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
+  }
+};
+#endif
+
 template <bool PAIRS>  // the tree was built over fan pairs (bvh.hpp): a leaf is one or two of them (A, B, A, B)
 __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d, HitRec& h, uint32_t* stack,
-                                               int tid, int nt = kThreads) {
+                                               int tid, int nt = kThreads, int bucket = 0) {
+  if (__builtin_isunordered(o.x, d.x) || __builtin_isunordered(o.y, d.y) || __builtin_isunordered(o.z, d.z)) return;  // see below
+#if RTPT_BVH_COUNT
+  __shared__ uint32_t cnt_all[16][8];
+  uint32_t* const cnt_w = cnt_all[(tid >> 6) & 15];
+  uint32_t my_nodes = 0, my_leaves = 0;
+  {
+    const unsigned long long m_ = __ballot(1);
+    if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(m_))) {
+      for (int i = 0; i < 6; i++) cnt_w[i] = 0;
+      cnt_w[6] = 1u;
+      cnt_w[7] = static_cast<uint32_t>(__builtin_popcountll(m_));
+    }
+  }
+  struct Flush {
+    uint32_t* w; uint32_t* n; uint32_t* l; int b;
+    __device__ ~Flush() {
+      atomicMax(&w[4], *n);
+      atomicMax(&w[5], *l);
+      const unsigned long long m_ = __ballot(1);
+      if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(m_)))
+        for (int i = 0; i < 8; i++) atomicAdd(&g_bvh_count[b & (kCountBuckets - 1)][i], static_cast<unsigned long long>(w[i]));
+    }
+  } flush_{cnt_w, &my_nodes, &my_leaves, bucket};
+#endif
   // A ray with a NaN component cannot hit anything (every comparison of tri_test fails, D7) — but min/max drop
   // NaNs, so every box would "pass" and that one lane would walk all of the scene: on the 1.15M-triangle lattice
-  // single frames took 38-47 ms instead of 6.3 because of a handful of such paths.
-  if (__builtin_isunordered(o.x, d.x) || __builtin_isunordered(o.y, d.y) || __builtin_isunordered(o.z, d.z)) return;
+  // single frames took 38-47 ms instead of 6.3 because of a handful of such paths (the test at the top of the function).
   // A direction component that is exactly 0 (axis-parallel rays do occur: d = (0,0,1) was measured) would make
   // that axis' slab distances inf - inf = NaN, which min/max drop: the axis stops culling and the ray visits
   // every node ahead of it (34 755 node visits for one ray, 45 ms for the frame).  With |d| clamped to 1e-20 the
@@ -374,6 +443,10 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
 #if RTPT_TRI_XOR_SIGN
     if (PAIRS) {
       for (uint32_t j = 0; j < cnt; j += 2) {
+#if RTPT_BVH_COUNT
+        RTPT_COUNT_TRIP(2);
+        my_leaves++;
+#endif
         const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sc.isect_leaf) + (first + j) * 48u);
         const float4 a0 = r[0], a1 = r[1], a2 = r[2], b1 = r[4], b2 = r[5];
         const uint32_t* pid = reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(sc.leaf_ids) + (first + j) * 4u);
@@ -410,6 +483,10 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
 #endif
   };
   auto node_step = [&]() {
+#if RTPT_BVH_COUNT
+    RTPT_COUNT_TRIP(0);
+    my_nodes++;
+#endif
     // base + 32-bit byte offset (a tree has < 2^27 nodes): the loads take the scalar base and a 32-bit vector offset instead
     // of a 64-bit address computed per step
     const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(sc.nodes) + (cur << 5));
@@ -471,10 +548,10 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
 
 template <int BVH>
 __device__ __forceinline__ void closest_hit(const SceneView& sc, f3 o, f3 d, HitRec& h, uint32_t* stack, int tid,
-                                            int nt = kThreads) {
+                                            int nt = kThreads, int bucket = 0) {
   // BVH: 0 brute force, 1 BVH over triangles, 2 BVH over fan pairs (SceneView::leaf_pairs) — a kernel holds one leaf routine
   if (BVH)
-    closest_hit_bvh<BVH == 2>(sc, o, d, h, stack, tid, nt);
+    closest_hit_bvh<BVH == 2>(sc, o, d, h, stack, tid, nt, bucket);
   else
     closest_hit_brute(sc, o, d, h);
 }
@@ -621,6 +698,9 @@ __global__ void k_ray_tables(int W, int H, float p00, float p11, float* dvx, flo
 template <int BVH>
 __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
   extern __shared__ uint32_t stack[];  // BVH: stack_depth x 256 entries (dynamic); unused otherwise
+#if RTPT_TILE_TIMELINE
+  TimelineScope tl_(0, blockIdx.y * gridDim.x + blockIdx.x);
+#endif
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
   const int x = blockIdx.x * kBlockX + threadIdx.x;
   const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
@@ -841,6 +921,9 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   const uint32_t lane = threadIdx.x;
   if (tid == 0) block_rays = 0;
+#if RTPT_TILE_TIMELINE
+  TimelineScope tl_(1, blockIdx.y * gridDim.x + blockIdx.x);
+#endif
 #if RTPT_PT_CENTER_OUT
   // workgroups are dispatched in the order of their linear index; tiles are taken column by column from the middle of
   // the frame outwards, so the last ones dispatched — the tail of the launch — are the outermost columns, where (camera
@@ -894,7 +977,7 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
         if (!BVH && a.cull && seg == 0)
           closest_hit_brute_set(a.scene, cand, o, d, h);
         else
-          closest_hit<BVH>(a.scene, o, d, h, stack, tid, kPtThreads);  // :208-222
+          closest_hit<BVH>(a.scene, o, d, h, stack, tid, kPtThreads, 1 + static_cast<int>(seg));  // :208-222
         const int x = tile_x0 + static_cast<int>(pix & 63u), y = tile_y0 + static_cast<int>(pix >> 6);
         if (y >= a.count_y0 && y < a.count_y1) rays++;
         const size_t gi = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
@@ -1038,7 +1121,7 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace_queue(PathtraceArgs a)
     for (uint32_t seg = a.seg_begin; seg < a.seg_end; seg++) {
       if (alive) {
         HitRec h{a.tmax, 0u, 0.f, 0.f, 1.f};
-        closest_hit<BVH>(a.scene, o, d, h, stack, tid, kPtThreads);  // :208-222
+        closest_hit<BVH>(a.scene, o, d, h, stack, tid, kPtThreads, 1 + static_cast<int>(seg));  // :208-222
         const int x = static_cast<int>(pix & 0xFFFFu), y = static_cast<int>(pix >> 16);
         if (y >= a.count_y0 && y < a.count_y1) rays++;
         if (shade_segment(a, h, seg, light_c, o, d, acc, rng)) {
@@ -1173,6 +1256,26 @@ __global__ __launch_bounds__(kThreads) void k_selftest_trace(SceneView sc, const
 }
 
 }  // namespace
+
+#if RTPT_TILE_TIMELINE
+// timeline build only: {start, end, hw} of the first n workgroups of the last K0 (kernel 0) / K2 (kernel 1) launch
+extern "C" __attribute__((visibility("default"))) int rtpt_debug_timeline(int kernel, unsigned long long* out, uint32_t n) {
+  if (kernel < 0 || kernel > 1 || n > kTimelineMax) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 3 * n,
+                             sizeof(unsigned long long) * 3 * kTimelineMax * kernel) == hipSuccess ? 0 : -1;
+}
+#endif
+#if RTPT_BVH_COUNT
+// counting build only: read (and clear) the traversal counters
+extern "C" __attribute__((visibility("default"))) int rtpt_debug_bvh_counters(unsigned long long* out, int clear) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_count), sizeof(unsigned long long) * kCountBuckets * 8) != hipSuccess) return -1;
+  if (clear) {
+    static unsigned long long zero[kCountBuckets * 8];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_count), zero, sizeof zero) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 void launch_scene_prepare(const ScenePrepArgs& a, hipStream_t s) {
   if (!a.n_tris) return;

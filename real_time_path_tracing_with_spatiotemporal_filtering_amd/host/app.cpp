@@ -372,8 +372,19 @@ void* PathTracingApplication::presentImage(RankState* rs, int idx) {
   return p;
 }
 
-// vkAcquireNextImageKHR's role (main.cpp:1310-1316): image idx may be written again once the gather that read it — two
-// frames ago — is done; then the rows are named to the final filter pass, which stores them in swapchain format itself
+// vkAcquireNextImageKHR's role (main.cpp:1310-1316), at the top of the frame: what the gather of two frames ago read may be
+// written again only once that gather is done.  For rgba8 that is swapchain image idx (the fused final pass stores into
+// it); for f32 it is the colour buffer itself — the PREVIOUS plane a rank sent from at frame f is IMAGE again at frame
+// f + 2 and rtpt_raytrace overwrites it, so the wait has to stand before the trace, not before the blit (round-3 advice:
+// with redundant halo rows and a camera at rest nothing else couples the ranks, and a rank could run frames ahead of the
+// presenting rank's receive).  app.py::_acquire is the same rule.
+void PathTracingApplication::acquirePresent() {
+  if (!opt_.present || !multi()) return;
+  const int idx = static_cast<int>(frameCount & 1);
+  if (presentDone_[idx]) host_stream_wait_event(stream_, presentDone_[idx]);
+}
+
+// the rows of swapchain image idx are named to the final filter pass, which stores them in swapchain format itself
 void PathTracingApplication::armPresent() {
   if (opt_.present != 1) return;
   const int idx = static_cast<int>(frameCount & 1);
@@ -381,7 +392,6 @@ void PathTracingApplication::armPresent() {
     check(rtpt_present_target(ctx_, presentImage(nullptr, idx), 0, opt_.height), "rtpt_present_target");
     return;
   }
-  if (presentDone_[idx]) host_stream_wait_event(stream_, presentDone_[idx]);
   const size_t row_bytes = static_cast<size_t>(opt_.width) * 4;
   for (auto& rs : ranks_) {
     const Rows own = rs.plan.own();
@@ -451,8 +461,7 @@ void PathTracingApplication::presentFrame() {
   }
   const bool rgba8 = opt_.present == 1;
   const size_t px_bytes = rgba8 ? 4 : 16, row_bytes = W * px_bytes;
-  // f32: the root's image and the strip buffers the others send from are written again two frames later: same acquire
-  if (!rgba8 && presentDone_[idx]) host_stream_wait_event(stream_, presentDone_[idx]);
+  // (the image and, for f32, the strip buffers the others send from were acquired at the top of the frame: acquirePresent)
   std::vector<const char*> mine(ranks_.size());
   for (size_t i = 0; i < ranks_.size(); i++) {
     RankState& rs = ranks_[i];
@@ -514,6 +523,7 @@ std::vector<unsigned char> PathTracingApplication::readPresented() {
 }
 
 void PathTracingApplication::drawScene(const std::string& keys) {
+  acquirePresent();
   updateScene(keys);
   drawVisbilityBuffer();
   computeTemporalGradient();

@@ -101,6 +101,7 @@ class PathTracingApplication {
   void* presentStream_ = nullptr;
   void* presentDone_[2] = {nullptr, nullptr}; // recorded behind the gather that read swapchain image i
   void presentFrame();                        // main.cpp:1338-1361
+  void acquirePresent();
   void armPresent();                          // acquire this frame's image, name its rows to the final pass (rtpt_present_target)
   void* presentImage(RankState* rs, int idx); // allocate on first use
   std::vector<RankState> ranks_;

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Where the BVH traversal's idle lanes are: runs frames of the 1.15 M-triangle workload on the COUNTING build of the
+library (scripts/build_variant.sh count -DRTPT_BVH_COUNT=1) and prints, per bucket (K0's primary rays, path segment s),
+the lane utilisation of the node loop and of the leaf loop and what bounds it.
+
+    RTPT_LIB_PATH=real_time_path_tracing_with_spatiotemporal_filtering_amd/variants/librtpt_count.so \
+        python scripts/bvh_count.py [--frames 2] [--width 3840 --height 2160] [--out profiles/xyz.json]
+
+Per call of closest_hit_bvh and wave the kernel counts the trips of the node loop and of the leaf loop, the lanes active in
+each trip and the longest lane's trips (kernels.hip, RTPT_BVH_COUNT).  From the sums:
+    util        = lane-trips / (64 x trips)                    what SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) sees
+    length_cap  = lane-trips / (64 x sum of the longest lane)  the bound set by unequal work inside a wave
+                                                                (and by partly filled waves): no reordering of one
+                                                                wave's loop can beat it
+    phase       = sum of the longest lane / trips              < 1: the while-while form makes the wave take more trips
+                                                                than its longest lane needs
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=2)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--segments", type=int, default=8)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi, scenes
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE, make_app
+    lib = abi.load()
+    try:
+        fn = lib.rtpt_debug_bvh_counters
+    except AttributeError:
+        sys.exit("this library was not built with -DRTPT_BVH_COUNT=1 (set RTPT_LIB_PATH to the counting variant)")
+    fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    xyz, idx = abi.load_obj(DEFAULT_SCENE)
+    vx, ti, xf, cam, zfar = scenes.instanced_cornell(xyz, idx)
+    app = make_app(args.width, args.height, max_segments=args.segments, iterations=5, mesh=(vx, ti), instance_xforms=xf,
+                   cameraOrigin=cam, z_far=zfar, lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
+    app.drawScene(())  # frame 0 (no history yet)
+    app.backend.ctx.sync()
+    buf = (C.c_ulonglong * (16 * 8))()
+    fn(buf, 1)
+    for _ in range(args.frames):
+        app.drawScene(())
+    app.backend.ctx.sync()
+    assert fn(buf, 0) == 0
+    names = ["K0 primary"] + [f"segment {s}" for s in range(15)]
+    res = {"_note": __doc__.split("\n\n")[2], "frames": args.frames, "width": args.width, "height": args.height, "buckets": {}}
+    tot = [0] * 8
+    print(f"{'bucket':12s} {'rays':>11s} {'nodes/ray':>9s} {'leaf/ray':>8s} | node util  cap  phase | leaf util  cap  phase | share of trips")
+    rows = []
+    for b in range(16):
+        c = [int(buf[b * 8 + i]) for i in range(8)]
+        if not c[6]:
+            continue
+        rows.append((b, c))
+        if b >= 1:
+            tot = [x + y for x, y in zip(tot, c)]
+    all_trips = sum(c[0] + c[2] for _, c in rows) or 1
+    rows.append((-1, tot))
+    for b, c in rows:
+        nt, nl, lt, ll, mn, ml, calls, lanes = c
+        e = {
+            "rays": lanes // args.frames, "waves": calls // args.frames,
+            "node_visits_per_ray": nl / max(1, lanes), "leaf_tests_per_ray": ll / max(1, lanes),
+            "node": {"util": nl / max(1, 64 * nt), "length_cap": nl / max(1, 64 * mn), "phase": mn / max(1, nt)},
+            "leaf": {"util": ll / max(1, 64 * lt), "length_cap": ll / max(1, 64 * ml), "phase": ml / max(1, lt)},
+            "entry_fill": lanes / max(1, 64 * calls),
+            "share_of_trips": (nt + lt) / all_trips,
+        }
+        name = names[b] if b >= 0 else "K2 total"
+        res["buckets"][name] = e
+        print(f"{name:12s} {e['rays']:11d} {e['node_visits_per_ray']:9.1f} {e['leaf_tests_per_ray']:8.2f} | "
+              f"{e['node']['util']:9.3f} {e['node']['length_cap']:5.3f} {e['node']['phase']:5.3f} | "
+              f"{e['leaf']['util']:9.3f} {e['leaf']['length_cap']:5.3f} {e['leaf']['phase']:5.3f} | {e['share_of_trips']:.3f}  fill {e['entry_fill']:.3f}")
+    if args.out:
+        json.dump(res, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
