@@ -315,6 +315,9 @@ constexpr uint32_t kSentinel = 0xFFFFFFFEu;
 #ifndef RTPT_BVH_SPECULATE
 #define RTPT_BVH_SPECULATE 0
 #endif
+#ifndef RTPT_BVH_LEAF_RATIO
+#define RTPT_BVH_LEAF_RATIO 0
+#endif
 #ifndef RTPT_LEAF_BATCH
 #define RTPT_LEAF_BATCH 2  // 1: 3.72 ms, 2: 3.65 ms, 4: 4.79 ms (registers) on the 1.15M-triangle trace
 #endif
@@ -536,6 +539,25 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
     }
   }
 #else
+#if RTPT_BVH_LEAF_RATIO
+  // while-while with an early hand-over: the node loop stops not only when every lane holds a leaf (or is done) but as
+  // soon as the lanes waiting with a leaf outnumber the lanes still walking RTPT_BVH_LEAF_RATIO to one — the few walkers
+  // sit out one leaf test instead of the many waiting out the walkers' remaining steps
+  while (cur != kSentinel) {
+    while (true) {
+      const bool walk = !(cur & kLeafBit);
+      const unsigned long long mw = __ballot(walk);
+      if (!mw) break;
+      const unsigned long long ml = __ballot(!walk && cur != kSentinel);
+      if (__builtin_popcountll(ml) >= RTPT_BVH_LEAF_RATIO * __builtin_popcountll(mw)) break;
+      if (walk) node_step();
+    }
+    if ((cur & kLeafBit) && cur != kSentinel) {  // a leaf
+      test_leaf(cur);
+      cur = pop();
+    }
+  }
+#else
   while (cur != kSentinel) {
     while (!(cur & kLeafBit)) node_step();  // interior (kSentinel has bit 31 set)
     if (cur != kSentinel) {  // a leaf
@@ -543,6 +565,7 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
       cur = pop();
     }
   }
+#endif
 #endif
 }
 

@@ -1,5 +1,6 @@
 // app.cpp — see app.hpp.  Every method cites the reference lines it stands for.
 #include "app.hpp"
+#include "scene_gen.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -41,7 +42,7 @@ void PathTracingApplication::initVulkan() {
   identity(ubo.model);
   const float center[3] = {0.0f, 1.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
   rtpt_util_look_at(cameraOrigin, center, up, ubo.view);
-  rtpt_util_perspective(kFov * 2, static_cast<float>(opt_.width) / static_cast<float>(opt_.height), 0.1f, 10.0f, ubo.proj);
+  rtpt_util_perspective(kFov * 2, static_cast<float>(opt_.width) / static_cast<float>(opt_.height), 0.1f, zFar_, ubo.proj);
   ubo.proj[5] *= -1;
   std::memcpy(ubo.modelPrev, ubo.model, sizeof ubo.model);
   std::memcpy(ubo.viewPrev, ubo.view, sizeof ubo.view);
@@ -67,6 +68,39 @@ void PathTracingApplication::loadMesh() {
     triMaterial.resize(ntm);
     check(rtpt_util_load_obj_materials(opt_.scene.c_str(), triMaterial.data(), &ntm, objMaterials.data(), &nm), "loadMesh");
   }
+  // configs[4]: tessellated quads on a lattice of instances (scene_gen.hpp); camera, light and far plane frame the lattice
+  if (opt_.tessellate > 1) {
+    if (!objMaterials.empty()) throw std::runtime_error("--tessellate does not carry a material library over");
+    if (!tessellate_quads(objVertices, objIndices, opt_.tessellate, objVertices, objIndices))
+      throw std::runtime_error("--tessellate needs a mesh of fan-triangulated quads");
+  }
+  instanceXforms_.clear();
+  if (opt_.lattice[0] > 0) {
+    instanceXforms_ = lattice_xforms(opt_.lattice[0], opt_.lattice[1], opt_.lattice[2], opt_.pitch);
+    const LatticeView v = lattice_view(opt_.lattice[0], opt_.lattice[1], opt_.lattice[2], opt_.pitch);
+    std::memcpy(cameraOrigin, v.camera, sizeof cameraOrigin);
+    std::memcpy(lightPos, v.light, sizeof lightPos);
+    zFar_ = v.z_far;
+  }
+}
+
+void PathTracingApplication::sceneBounds() {
+  scene_bounds(objVertices, objIndices, instanceXforms_.empty() ? nullptr : instanceXforms_.data(),
+               static_cast<uint32_t>(instanceXforms_.size() / 12), sceneMin_, sceneMax_);
+}
+
+void PathTracingApplication::dumpScene(const std::string& path) {
+  std::ofstream f(path, std::ios::binary);
+  const uint32_t head[3] = {static_cast<uint32_t>(objVertices.size() / 3), static_cast<uint32_t>(objIndices.size() / 3),
+                            static_cast<uint32_t>(instanceXforms_.size() / 12)};
+  f.write(reinterpret_cast<const char*>(head), sizeof head);
+  f.write(reinterpret_cast<const char*>(objVertices.data()), static_cast<std::streamsize>(objVertices.size() * 4));
+  f.write(reinterpret_cast<const char*>(objIndices.data()), static_cast<std::streamsize>(objIndices.size() * 4));
+  f.write(reinterpret_cast<const char*>(instanceXforms_.data()), static_cast<std::streamsize>(instanceXforms_.size() * 4));
+  f.write(reinterpret_cast<const char*>(cameraOrigin), sizeof cameraOrigin);
+  f.write(reinterpret_cast<const char*>(lightPos), sizeof lightPos);
+  f.write(reinterpret_cast<const char*>(&zFar_), sizeof zFar_);
+  if (!f) throw std::runtime_error("cannot write " + path);
 }
 
 void PathTracingApplication::createBuffers() {
@@ -121,25 +155,20 @@ void PathTracingApplication::createBuffers() {
 
 void PathTracingApplication::buildAccelerationStructure() {
   // world-space bounds of the scene: strips bound the reprojection reach with them (strips.hpp)
-  for (int a = 0; a < 3; a++) {
-    sceneMin_[a] = 1e30f;
-    sceneMax_[a] = -1e30f;
-  }
-  for (uint32_t i : objIndices)
-    for (int a = 0; a < 3; a++) {
-      sceneMin_[a] = std::min(sceneMin_[a], objVertices[3 * static_cast<size_t>(i) + a]);
-      sceneMax_[a] = std::max(sceneMax_[a], objVertices[3 * static_cast<size_t>(i) + a]);
-    }
+  sceneBounds();
   auto materials = [&](rtpt_ctx* ctx) {
     if (!objMaterials.empty())
       check(rtpt_scene_set_materials(ctx, triMaterial.data(), static_cast<uint32_t>(triMaterial.size()), objMaterials.data(),
                                      static_cast<uint32_t>(objMaterials.size())),
             "rtpt_scene_set_materials");
   };
+  // main.cpp:728-741: the instance list (one identity transform in the reference; the lattice of configs[4] here)
+  const float* xf = instanceXforms_.empty() ? nullptr : instanceXforms_.data();
+  const uint32_t n_inst = static_cast<uint32_t>(instanceXforms_.size() / 12);
   if (multi()) {
     for (auto& rs : ranks_) {
       check(rtpt_scene_upload(rs.ctx, objVertices.data(), static_cast<uint32_t>(objVertices.size() / 3), objIndices.data(),
-                              static_cast<uint32_t>(objIndices.size() / 3), nullptr, 0),
+                              static_cast<uint32_t>(objIndices.size() / 3), xf, n_inst),
             "buildAccelerationStructure");
       materials(rs.ctx);
     }
@@ -147,7 +176,7 @@ void PathTracingApplication::buildAccelerationStructure() {
   }
   for (int i = 0; i < opt_.frames_in_flight; i++) {
     check(rtpt_scene_upload(ctxs_[i], objVertices.data(), static_cast<uint32_t>(objVertices.size() / 3), objIndices.data(),
-                            static_cast<uint32_t>(objIndices.size() / 3), nullptr, 0),
+                            static_cast<uint32_t>(objIndices.size() / 3), xf, n_inst),
           "buildAccelerationStructure");
     materials(ctxs_[i]);
   }
@@ -167,7 +196,7 @@ void PathTracingApplication::updateUBO() {
   identity(ubo.model);
   const float center[3] = {cameraOrigin[0], cameraOrigin[1], cameraOrigin[2] - 6.0f}, up[3] = {0.0f, 1.0f, 0.0f};
   rtpt_util_look_at(cameraOrigin, center, up, ubo.view);
-  rtpt_util_perspective(kFov * 2, static_cast<float>(opt_.width) / static_cast<float>(opt_.height), 0.1f, 10.0f, ubo.proj);
+  rtpt_util_perspective(kFov * 2, static_cast<float>(opt_.width) / static_cast<float>(opt_.height), 0.1f, zFar_, ubo.proj);
   ubo.proj[5] *= -1;
 }
 
@@ -574,20 +603,12 @@ void PathTracingApplication::freeRessources() {
 
 std::string PathTracingApplication::planJson(int frames, const std::vector<std::string>& script) {
   loadMesh();
-  for (int a = 0; a < 3; a++) {
-    sceneMin_[a] = 1e30f;
-    sceneMax_[a] = -1e30f;
-  }
-  for (uint32_t i : objIndices)
-    for (int a = 0; a < 3; a++) {
-      sceneMin_[a] = std::min(sceneMin_[a], objVertices[3 * static_cast<size_t>(i) + a]);
-      sceneMax_[a] = std::max(sceneMax_[a], objVertices[3 * static_cast<size_t>(i) + a]);
-    }
+  sceneBounds();
   // uploadBuffers (main.cpp:481-489) + initializeSceneConstants, as in initVulkan, without any device work
   identity(ubo.model);
   const float center[3] = {0.0f, 1.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
   rtpt_util_look_at(cameraOrigin, center, up, ubo.view);
-  rtpt_util_perspective(kFov * 2, static_cast<float>(opt_.width) / static_cast<float>(opt_.height), 0.1f, 10.0f, ubo.proj);
+  rtpt_util_perspective(kFov * 2, static_cast<float>(opt_.width) / static_cast<float>(opt_.height), 0.1f, zFar_, ubo.proj);
   ubo.proj[5] *= -1;
   std::memcpy(ubo.modelPrev, ubo.model, sizeof ubo.model);
   std::memcpy(ubo.viewPrev, ubo.view, sizeof ubo.view);

@@ -21,6 +21,12 @@ struct Options {
   uint32_t flags = 0;
   int frames_in_flight = 1;             // 2: even/odd frames in two contexts on two streams (rtpt_stream_wait)
   std::string scene;                    // scenes/CornellBox-Original-Merged.obj (main.cpp:417)
+  // BASELINE.json configs[4] (scene_gen.hpp): every quad of the OBJ tessellated n x n, the mesh instanced on
+  // a lattice of translations (the reference's own instance list is one identity transform, main.cpp:728-741); the camera,
+  // the light and the far plane then frame the lattice.  --lattice 10x10x10 --tessellate 6 = 1,152,000 triangles
+  int tessellate = 1;
+  int lattice[3] = {0, 0, 0};           // 0: no instancing (one identity instance)
+  float pitch = 2.5f;
   // row strips across GPUs (new work, the reference is single-device)
   int ranks = 1;                        // strips the frame is split into
   int rank = -1;                        // >= 0: this process is that rank (one GPU per process, RCCL between them);
@@ -73,6 +79,10 @@ class PathTracingApplication {
   // rank's final pass can reach — as one JSON object; what the CPU tests compare with the Python mirror
   std::string planJson(int frames, const std::vector<std::string>& script);
   void writePFM(const std::string& path);      // linear RGB, bottom-up rows as PFM prescribes
+  // host-only: the mesh and the instance transforms as rtpt_scene_upload receives them, raw little-endian:
+  // u32 n_verts, n_tris, n_instances; float xyz[3 n_verts]; u32 idx[3 n_tris]; float xforms[12 n_instances]; float camera[3],
+  // light[3], z_far
+  void dumpScene(const std::string& path);
   void sync();
 
   uint32_t frameCount = 0;                     // main.cpp:259
@@ -107,7 +117,10 @@ class PathTracingApplication {
   std::vector<RankState> ranks_;
   Transport* transport_ = nullptr;
   void* stream_ = nullptr;
-  float sceneMin_[3] = {0, 0, 0}, sceneMax_[3] = {0, 0, 0};
+  double sceneMin_[3] = {0, 0, 0}, sceneMax_[3] = {0, 0, 0};  // world-space bounds of the POSED, INSTANCED scene
+  std::vector<float> instanceXforms_;          // 3x4 row-major per instance; empty: one identity instance (main.cpp:728-741)
+  float zFar_ = 10.0f;                         // main.cpp:483
+  void sceneBounds();
   bool multi() const { return opt_.ranks > 1; }
   bool cameraStatic() const;
   void exchangeHalo(int k);

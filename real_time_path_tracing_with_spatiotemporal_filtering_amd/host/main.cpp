@@ -18,6 +18,7 @@ static void usage(const char* argv0) {
   std::printf(
       "usage: %s [--width W] [--height H] [--frames N] [--segments S] [--iterations K]\n"
       "          [--scene file.obj] [--script \"keys0,keys1,...\"] [--dump out.pfm] [--exact-filter]\n"
+      "          [--tessellate n] [--lattice NXxNYxNZ [--pitch P]] [--dump-scene out.bin]\n"
       "          [--frames-in-flight 1|2]\n"
       "          [--ranks R [--rank r --rccl-id-file F [--rccl-nonce N] [--rccl-timeout S]] [--halo redundant|exchange] [--device D]]\n"
       "          [--present none|rgba8|f32 [--dump-present out.raw]]\n"
@@ -29,6 +30,9 @@ static void usage(const char* argv0) {
       "  launcher's pid); an id file of another launch is ignored; the communicator bring-up gives up after S seconds (120)\n"
       "  --present: the swapchain blit of every frame (main.cpp:1338-1361): rgba8 converts to B8G8R8A8_UNORM, and with --ranks the\n"
       "  strips are gathered on rank 0 (rgba8: in that format, f32: as float rows); --dump-present writes rank 0's last image raw\n"
+      "  --tessellate n splits every quad of the OBJ into n x n cells; --lattice instances the mesh on a lattice of translations and\n"
+      "  frames it (camera, light, far plane): --lattice 10x10x10 --tessellate 6 is BASELINE.json configs[4], 1,152,000 triangles;\n"
+      "  --dump-scene writes what rtpt_scene_upload receives (with --plan-only: no GPU needed)\n"
       "  keys per frame are the reference's GLFW keys: WASDQE move the camera, IJKLUO the light\n"
       "  defaults are the reference's constants: 1000x800, 32 segments, 9 iterations (main.cpp:52-55)\n",
       argv0);
@@ -38,7 +42,7 @@ int main(int argc, char** argv) {
   rtpt_host::Options opt;
   int frames = 3;
   bool plan_only = false;
-  std::string dump, dump_present, script_arg;
+  std::string dump, dump_present, dump_scene, script_arg;
   opt.rccl_nonce = static_cast<uint64_t>(::getppid());
   // scene path relative to this binary: <pkg>/scenes/...
   std::string self(argv[0]);
@@ -59,6 +63,16 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--iterations")) opt.maxWaveletIteration = std::atoi(need("--iterations"));
     else if (!std::strcmp(argv[i], "--scene")) opt.scene = need("--scene");
     else if (!std::strcmp(argv[i], "--script")) script_arg = need("--script");
+    else if (!std::strcmp(argv[i], "--tessellate")) opt.tessellate = std::atoi(need("--tessellate"));
+    else if (!std::strcmp(argv[i], "--pitch")) opt.pitch = static_cast<float>(std::atof(need("--pitch")));
+    else if (!std::strcmp(argv[i], "--dump-scene")) dump_scene = need("--dump-scene");
+    else if (!std::strcmp(argv[i], "--lattice")) {
+      if (std::sscanf(need("--lattice"), "%dx%dx%d", &opt.lattice[0], &opt.lattice[1], &opt.lattice[2]) != 3 || opt.lattice[0] < 1 ||
+          opt.lattice[1] < 1 || opt.lattice[2] < 1) {
+        std::fprintf(stderr, "--lattice takes NXxNYxNZ, e.g. 10x10x10\n");
+        return 2;
+      }
+    }
     else if (!std::strcmp(argv[i], "--dump")) dump = need("--dump");
     else if (!std::strcmp(argv[i], "--exact-filter")) opt.flags |= RTPT_FLAG_EXACT_FILTER;
     else if (!std::strcmp(argv[i], "--frames-in-flight")) opt.frames_in_flight = std::atoi(need("--frames-in-flight"));
@@ -89,10 +103,15 @@ int main(int argc, char** argv) {
   try {
     rtpt_host::PathTracingApplication app(opt);
     if (plan_only) {  // host-only: no GPU is touched
+      if (!dump_scene.empty()) {  // the scene as uploaded, before any scripted key moves the camera
+        app.loadMesh();
+        app.dumpScene(dump_scene);
+      }
       std::printf("%s\n", app.planJson(frames, script).c_str());
       return 0;
     }
     app.initVulkan();
+    if (!dump_scene.empty()) app.dumpScene(dump_scene);
     app.sync();
     auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < frames; f++) app.drawScene(static_cast<size_t>(f) < script.size() ? script[static_cast<size_t>(f)] : "");

@@ -86,7 +86,7 @@ M4 mul(const M4& a, const M4& b) {
 }
 }  // namespace
 
-Rows reprojection_rows(const rtpt_ubo& ubo, int width, int height, Rows rows, const float bmin[3], const float bmax[3], float z_near,
+Rows reprojection_rows(const rtpt_ubo& ubo, int width, int height, Rows rows, const double bmin[3], const double bmax[3], float z_near,
                        int pad) {
   // a model matrix that changed since the previous frame: the shader's previous position is not M_prev M^-1 p (it takes
   // the current point's area ratios against the previous triangle, temporalFiltering.comp.glsl:223-233) and nothing

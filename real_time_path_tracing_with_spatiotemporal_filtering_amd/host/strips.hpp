@@ -55,7 +55,7 @@ struct StripPlan {
 
 // previous-frame rows the final pass of frame rows `rows` can fetch history from; see strips.py:reprojection_rows for
 // the argument (extremes of a function monotone along x, y and view depth are at the 8 corners of the box)
-Rows reprojection_rows(const rtpt_ubo& ubo, int width, int height, Rows rows, const float bounds_min[3], const float bounds_max[3],
+Rows reprojection_rows(const rtpt_ubo& ubo, int width, int height, Rows rows, const double bounds_min[3], const double bounds_max[3],
                        float z_near, int pad = 2);
 
 struct HistoryOp {

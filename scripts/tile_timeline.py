@@ -42,7 +42,7 @@ def main():
         vx, ti, xf, cam, zfar = scenes.instanced_cornell(xyz, idx)
         extra = dict(mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar, lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
     app = make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"], rank=r, world=n,
-                   mode="redundant", **extra)
+                   mode="redundant", torch_planes=False, **extra)
     for _ in range(args.frames):
         app.drawScene(())
     app.backend.ctx.sync()

@@ -226,3 +226,90 @@ def test_cpp_strip_plan_and_history_bands_equal_the_python_mirror(app_binary, ha
         moved_any |= plan["frames"][f]["moved"]
         app.frameCount += 1
     assert moved_any
+
+
+def _lattice_args(lattice, tess):
+    return ["--lattice", "x".join(map(str, lattice)), "--tessellate", str(tess)]
+
+
+def test_cpp_lattice_scene_and_its_strip_plan_equal_the_python_mirror(app_binary, tmp_path):
+    """host-only (no GPU): BASELINE configs[4]'s scene as the C++ host builds it (host/scene_gen.cpp: tessellated quads on a
+    lattice of instances, main.cpp:728-741 being the instance list it extends) is, bit for bit, what scenes.py hands to
+    rtpt_scene_upload — vertices, indices, transforms, camera, light, far plane — and the history bands of its strips, bounded
+    with the POSED, INSTANCED scene box, are the Python mirror's."""
+    from test_host_logic import Recorder
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi, scenes
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE, PathTracingApplication
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripPlan, reprojection_rows
+    abi.load()
+    W, H, N, R = 320, 180, 5, 4
+    lattice, tess = (3, 4, 2), 3
+    keys = ["", "E", "E", "D", "QS", ""]
+    dump = tmp_path / "scene.bin"
+    out = subprocess.run([app_binary, "--plan-only", "--width", str(W), "--height", str(H), "--iterations", str(N), "--ranks", str(R),
+                          "--frames", str(len(keys)), "--script", ",".join(keys), "--dump-scene", str(dump)] + _lattice_args(lattice, tess),
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    xyz, idx = abi.load_obj(DEFAULT_SCENE)
+    vx, ti, xf, cam, zfar = scenes.instanced_cornell(xyz, idx, lattice=lattice, tess=tess)
+    raw = np.fromfile(dump, np.uint8)
+    nv, nt, ni = raw[:12].view(np.uint32)
+    assert (nv, nt, ni) == (len(vx), len(ti), len(xf)) and nt == 32 * tess * tess
+    o = 12
+    got_vx = raw[o:o + 12 * nv].view(np.float32).reshape(-1, 3); o += 12 * nv
+    got_ti = raw[o:o + 12 * nt].view(np.uint32).reshape(-1, 3); o += 12 * nt
+    got_xf = raw[o:o + 48 * ni].view(np.float32).reshape(-1, 12); o += 48 * ni
+    tail = raw[o:o + 28].view(np.float32)
+    assert np.array_equal(bits(got_vx), bits(vx)) and np.array_equal(got_ti, ti) and np.array_equal(bits(got_xf), bits(xf))
+    light = np.array((1.0, float(cam[1]), float(cam[2]) - 8.0), np.float32)   # bench.py's light for this scene
+    assert np.array_equal(bits(tail[:3]), bits(np.array(cam, np.float32))) and np.array_equal(bits(tail[3:6]), bits(light))
+    assert tail[6] == np.float32(zfar)
+    plan = json.loads(out.stdout)
+    app = PathTracingApplication(Recorder(), W, H, N, cameraOrigin=cam, z_far=zfar, lightPos=light)
+    app.objVertices, app.objIndices = vx, ti
+    app.buildAccelerationStructure(xf)
+    moved_any = False
+    for f, k in enumerate(keys):
+        app.updateScene(tuple(k))
+        needs = [list(reprojection_rows(app.ubo, W, H, StripPlan.bounds(H, R, r), app.sceneBounds, app.z_near)) for r in range(R)]
+        assert plan["frames"][f]["needs"] == needs, (f, k)
+        moved_any |= plan["frames"][f]["moved"]
+        app.frameCount += 1
+    assert moved_any
+    # the full-size scene: counts only (1,152,000 triangles x 10^3 instances is what rtpt_scene_upload flattens)
+    out = subprocess.run([app_binary, "--plan-only", "--frames", "1", "--dump-scene", str(dump)] + _lattice_args((10, 10, 10), 6),
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    nv, nt, ni = np.fromfile(dump, np.uint32, 3)
+    assert nt * ni == 1_152_000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,halo", [(1, "redundant"), (3, "redundant"), (3, "exchange")])
+def test_cpp_host_runs_the_lattice_scene_like_the_python_host(app_binary, hip_lib, tmp_path, ranks, halo):
+    """configs[4]'s scene class through the C++ host (BVH traversal over fan pairs, per-pixel-normal filter, instance
+    transforms through rtpt_scene_upload), one context and in-process strips, camera moving: the Python host's frame bit for
+    bit.  (The 1.15 M-triangle size runs in test_fullsize_gpu.py.)"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi, scenes
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE, make_app
+    W, H, SEG, N = 192, 120, 4, 5
+    lattice, tess = (3, 3, 2), 2
+    keys = ["", "", "E", "D", "J"]
+    pfm = tmp_path / "out.pfm"
+    cmd = [app_binary, "--width", str(W), "--height", str(H), "--segments", str(SEG), "--iterations", str(N), "--frames", str(len(keys)),
+           "--script", ",".join(keys), "--dump", str(pfm)] + _lattice_args(lattice, tess)
+    if ranks > 1:
+        cmd += ["--ranks", str(ranks), "--halo", halo]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    stats = json.loads(out.stdout.strip().splitlines()[-1])
+    xyz, idx = abi.load_obj(DEFAULT_SCENE)
+    vx, ti, xf, cam, zfar = scenes.instanced_cornell(xyz, idx, lattice=lattice, tess=tess)
+    app = make_app(W, H, max_segments=SEG, iterations=N, mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar,
+                   lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
+    for k in keys:
+        app.drawScene(tuple(k))
+    want = app.backend.ctx.readback(hip_lib.PLANE_IMAGE)
+    got = read_pfm(pfm)
+    assert np.array_equal(bits(got), bits(np.ascontiguousarray(want[..., :3])))
+    assert stats["rays"] == app.backend.ctx.raycount()
