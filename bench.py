@@ -38,6 +38,7 @@ WORKLOADS = {
     "instanced": dict(width=3840, height=2160, max_segments=8, iterations=5, instanced=True),
 }
 PREWARM_SECONDS = 0.3
+_INSTANCED = {}  # the configs[4] scene, built once per process
 # VALU issue, measured on this part (scripts/micro/valu_rate.hip -> profiles/r03_valu_issue_micro.txt, wall clock at 8 waves
 # per SIMD): the fastest wave64 VALU instruction occupies a SIMD for 1.06 ns (v_xor_b32; v_mul_f32 1.12, a dependent
 # v_fma_f32 1.16), a transcendental (v_rcp / v_sqrt / v_rsq / v_exp) for 3.42 ns.  1,024 SIMDs.
@@ -72,9 +73,11 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE, make_app
     extra = {}
     if wl.get("instanced"):
-        from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi, scenes
-        xyz, idx = abi.load_obj(DEFAULT_SCENE)
-        vx, ti, xf, cam, zfar = scenes.instanced_cornell(xyz, idx)
+        if "scene" not in _INSTANCED:
+            from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi, scenes
+            xyz, idx = abi.load_obj(DEFAULT_SCENE)
+            _INSTANCED["scene"] = scenes.instanced_cornell(xyz, idx)
+        vx, ti, xf, cam, zfar = _INSTANCED["scene"]
         extra = dict(mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar,
                      lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
     app = make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"],
@@ -109,8 +112,8 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
     # The same loop fills the context's pool of timing events (created on first use; on some boxes
     # hipEventCreate is slow enough that creating them inside the timed region cost +0.2 ms per step).
     # sample the per-kernel events: bracketing every launch costs ~6 % of the frame (the driver's --steps 20 run of
-    # round 1 paid that); at least 4 sampled frames per run
-    timing_period = 8 if steps >= 32 else (4 if steps >= 16 else (2 if steps >= 8 else 1))
+    # round 1 paid that); every 8th frame in long runs, and never fewer than 8 sampled frames (or all of them) in short ones
+    timing_period = max(1, min(8, steps // 8))
     if args.prewarm_seconds > 0:
         ctx.timing_enable(timing_period if collect_kernels else 0)
         t_wake = time.perf_counter()
@@ -198,6 +201,23 @@ def kernel_report(kern, wl, plan, steps):
     return out
 
 
+def traversal_report():
+    """north_star: "L2-hit/occupancy on the traversal kernel": a committed PMC measurement (profiles/traversal.json,
+    scripts/pmc_traversal.sh; counters cannot be collected inside a bench run), named by the commit it was taken at"""
+    try:
+        tv = json.load(open(os.path.join(ROOT, "profiles", "traversal.json")))
+        kp = tv.get("k_pathtrace", {})
+        return {"kernel": "k_pathtrace<BVH> (tile kernel + queue windows)",
+                "l2_hit_rate": round(kp.get("l2_hit_rate", 0), 4),
+                "occupancy_waves_per_simd": round(kp.get("waves_per_simd", 0), 2), "occupancy_max": 8,
+                "valu_busy": round(kp.get("valu_busy", 0), 3),
+                "lane_utilisation": round(kp.get("lane_utilisation", 0), 3),
+                "committed_measurement": True,
+                "source": "profiles/traversal.json @ " + str(tv.get("_source"))}
+    except Exception:
+        return None
+
+
 def cpu_baseline(workload: str, budget_s=12.0):
     """the CPU oracle in a CHILD process (a fresh interpreter: no torch, no HIP runtime, none of their threads): the
     checker's worker threads never share a process with the GPU legs that ran before it"""
@@ -219,34 +239,58 @@ def _cpu_baseline_child(wl, budget_s=12.0):
     cores = min(cores, 16)  # the one-GPU box's CPU share
     O.set_threads(cores)
     xyz, idx = O.load_obj(DEFAULT_SCENE)
-    tris = O.flatten(xyz, idx)
     W, H, N = wl["width"], wl["height"], wl["iterations"]
-    app = O.OracleApp(W, H, tris, max_segments=wl["max_segments"], iterations=N)
-    app.update_scene()
     import numpy as np
+    if wl.get("instanced"):
+        # BASELINE configs[4]: the oracle's closest hit is brute force over all 1,152,000 triangles (hit ids
+        # independent of any BVH), ~13 G triangle tests for one 3840-pixel row of 8-segment paths — the bounded sample is ONE
+        # row, every pass on it (the filter's taps above and below read untraced rows: a timing sample, not an image)
+        from real_time_path_tracing_with_spatiotemporal_filtering_amd import scenes
+        vx, ti, xf, cam, zfar = scenes.instanced_cornell(xyz, idx)
+        tris = O.flatten(vx, ti, xf)
+        app = O.OracleApp(W, H, tris, max_segments=wl["max_segments"], iterations=N, camera=cam, z_far=zfar,
+                          light=(1.0, float(cam[1]), float(cam[2]) - 8.0))
+    else:
+        tris = O.flatten(xyz, idx)
+        app = O.OracleApp(W, H, tris, max_segments=wl["max_segments"], iterations=N)
+    app.update_scene()
     lut = O.lut(tris, np.array(app.ubo.model[:], np.float32))
+    banded = not wl.get("instanced")
 
-    def band_frame(rows):
-        y0 = H // 2 - rows // 2
+    def band_frame(rows, y0=None):
+        y0 = H // 2 - rows // 2 if y0 is None else y0
         y1 = y0 + rows
-        g0, g1 = max(0, y0 - N * (N + 1) // 2), min(H, y1 + N * (N + 1) // 2)
+        halo = N * (N + 1) // 2 if banded else 0
+        g0, g1 = max(0, y0 - halo), min(H, y1 + halo)
         t0 = time.perf_counter()
         vis, wp, depth = O.gbuffer(app.cfg, tris, app.ubo, g0, g1)
         O.temporal_gradient(app.cfg, app.pc, vis, wp, lut, lut, y0, y1)
         img, rays, _ = O.raytrace(app.cfg, app.pc, tris, g0, g1, want_hit_id=False)
-        own_rays = None
         app.pc.maxWaveletIteration = N
         cur = img
         for k in range(1, N + 1):
             app.pc.waveletIteration = k
-            rem = sum(range(k + 1, N + 1))
+            rem = sum(range(k + 1, N + 1)) if banded else 0
             cur = O.atrous(app.cfg, app.pc, app.ubo, cur, depth, vis, lut, lut, wp, None,
                            max(0, y0 - rem), min(H, y1 + rem))
         dt = time.perf_counter() - t0
-        # rays of the band rows only (the halo rows are overhead of banding, as on a strip rank)
-        _, own_rays, _ = O.raytrace(app.cfg, app.pc, tris, y0, y1, want_hit_id=False)
-        return dt, own_rays
+        if banded:  # rays of the band rows only (the halo rows are overhead of banding, as on a strip rank)
+            _, rays, _ = O.raytrace(app.cfg, app.pc, tris, y0, y1, want_hit_id=False)
+        return dt, rays
 
+    if not banded:
+        # 16 rows x 240 columns = one row's worth of pixels, a row per thread, through the lattice's fourth layer of boxes
+        rows, cols = 16, W // 16
+        y0, x0 = H // 2 - H // 16, W // 2 - cols // 2
+        O.set_columns(x0, x0 + cols)
+        dt, rays = band_frame(rows, y0)
+        O.set_columns()
+        return {
+            "value": round(rays / dt / 1e6, 5), "unit": "Mray/s", "cores": cores, "kind": "port", "one_thread": None,
+            "sample": f"{rows} x {cols} pixels at ({x0}, {y0}) of the {W}x{H} frame: {rays} closest-hit queries, each a brute force over "
+                      f"{len(tris)} triangles, all passes on those pixels, {dt:.1f} s of oracle/rtpt_oracle.c with {cores} threads",
+            "ms_per_frame_extrapolated": round(dt / (rows * cols) * W * H * 1e3, 1),
+        }
     rows = 16
     dt, rays = band_frame(rows)
     while dt < budget_s / 2 and rows < H:
@@ -378,7 +422,8 @@ def main():
             c = valu_tab.get(k) or valu_tab.get({"k_gbuffer_gradient": "k_gbuffer"}.get(k, ""))  # the fused launch is k_gbuffer<fused>
             if c and v.get("avg_us"):
                 issue_us = ((c["insts"] - c["trans"]) * VALU_NS + c["trans"] * TRANS_NS) * 1e-3 / N_SIMDS
-                v["valu_issue"] = {"insts_per_launch": int(c["insts"]), "transcendental": int(c["trans"]),
+                v["valu_issue"] = {"committed_measurement": True, "source": "profiles/traffic.json @ " + str(traffic_source),
+                                   "insts_per_launch": int(c["insts"]), "transcendental": int(c["trans"]),
                                    "issue_us": round(issue_us, 1), "frac_of_launch": round(issue_us / v["avg_us"], 3)}
         achieved = at.get("algorithmic_GBps")
         result = {
@@ -428,19 +473,7 @@ def main():
             "kernels": kr,
         }
         if wl.get("instanced"):
-            # north_star: "L2-hit/occupancy on the traversal kernel": a committed PMC measurement (profiles/traversal.json,
-            # scripts/pmc_traversal.sh; counters cannot be collected inside this run), named by the commit it was taken at
-            try:
-                tv = json.load(open(os.path.join(ROOT, "profiles", "traversal.json")))
-                kp = tv.get("k_pathtrace", {})
-                result["traversal"] = {"kernel": "k_pathtrace<BVH> (tile kernel + queue windows)",
-                                       "l2_hit_rate": round(kp.get("l2_hit_rate", 0), 4),
-                                       "occupancy_waves_per_simd": round(kp.get("waves_per_simd", 0), 2), "occupancy_max": 8,
-                                       "valu_busy": round(kp.get("valu_busy", 0), 3),
-                                       "lane_utilisation": round(kp.get("lane_utilisation", 0), 3),
-                                       "source": "profiles/traversal.json @ " + str(tv.get("_source"))}
-            except Exception:
-                result["traversal"] = None
+            result["traversal"] = traversal_report()
         pt = kr.get("k_pathtrace")
         if pt:
             result["pathtrace_kernel_mray_s"] = round(rays / args.steps / (pt["avg_us"] * 1e-6) / 1e6, 1)
@@ -497,7 +530,23 @@ def main():
                                   in_flight=2)
         result["also"]["cornell-1080p-1spp-4seg-5atrous"]["two_frames_in_flight"] = {
             "value": round(r4 / e4 / 1e6, 2), "ms_per_step": round(e4 / args.steps * 1e3, 4)}
-    if world == 1 and rank == 0 and not args.no_cpu_baseline and not wl.get("instanced"):
+    if world == 1 and rank == 0 and not args.no_secondary and args.workload == "4k":
+        # BASELINE.json configs[4] beside the headline (its defining 8-GPU deployment is the driver's to launch: --workload
+        # instanced --gpus 8): the 1,152,000-triangle lattice on this one GPU, per-kernel durations, the traversal's committed
+        # PMC figures, and the CPU oracle on a bounded pixel sample of the same frame
+        wi = WORKLOADS["instanced"]
+        si, wu = min(args.steps, 40), min(args.warmup, 5)
+        e7, r7, k7, p7, tf7 = run_gpu(wi, args, 0, 1, si, wu, torch, None)
+        kr7 = kernel_report(k7, wi, p7, tf7)
+        inst = {"value": round(r7 / e7 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e7 / si * 1e3, 4), "steps": si, "warmup": wu,
+                "triangles": 1152000, "max_segments": wi["max_segments"], "rays_per_frame": round(r7 / si, 1), "kernels": kr7,
+                "traversal": traversal_report()}
+        if kr7.get("k_pathtrace"):
+            inst["pathtrace_kernel_mray_s"] = round(r7 / si / (kr7["k_pathtrace"]["avg_us"] * 1e-6) / 1e6, 1)
+        if not args.no_cpu_baseline:
+            inst["cpu_baseline"] = cpu_baseline("instanced")
+        result.setdefault("also", {})["instanced-4k-1spp-8seg-5atrous"] = inst
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.workload)
     if dist is not None:
         dist.barrier()

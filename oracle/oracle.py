@@ -110,6 +110,11 @@ def set_threads(n: int) -> None:
     lib().oracle_set_threads(C.c_int(n))
 
 
+def set_columns(x0: int = 0, x1: int = 0) -> None:
+    """restrict the per-pixel passes to columns [x0, x1) — timing samples only; set_columns() restores every column"""
+    lib().oracle_set_columns(C.c_int(x0), C.c_int(x1))
+
+
 def math_array(op: int, x: np.ndarray) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.float32)
     out = np.empty_like(x)

@@ -26,6 +26,16 @@
  * path runs, so the thread count cannot change a result. */
 static int g_threads = 1;
 void oracle_set_threads(int n) { g_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
+/* Column window of the per-pixel passes (G-buffer, gradient, trace, moments, a-trous): pixels outside [x0, x1) are left
+ * untouched.  Default: every column.  bench.py's cpu_baseline uses it to time a bounded pixel sample of BASELINE configs[4],
+ * where one closest-hit query is a brute force over 1,152,000 triangles and a whole row would take minutes. */
+static int g_col0 = 0, g_col1 = 0x7fffffff;
+void oracle_set_columns(int x0, int x1) {
+  g_col0 = x0 < 0 ? 0 : x0;
+  g_col1 = x1 <= g_col0 ? 0x7fffffff : x1;
+}
+static inline int col_lo(void) { return g_col0; }
+static inline int col_hi(int w) { return g_col1 < w ? g_col1 : w; }
 int oracle_get_threads(void) { return g_threads; }
 
 /* Crash attribution for the test processes (tests/conftest.py installs it for -m gpu runs): Python's faulthandler
@@ -85,6 +95,7 @@ static void* range_worker(void* p) {
 
 static void run_ranges(int64_t begin, int64_t end, int64_t chunk, range_fn fn, void* ctx) {
   if (end <= begin) return;
+  if ((end - begin + chunk - 1) / chunk < g_threads) chunk = 1; /* few rows: one per thread (chunking never changes a result) */
   int64_t n_chunks = (end - begin + chunk - 1) / chunk;
   int nt = g_threads < n_chunks ? g_threads : (int)n_chunks;
   if (nt <= 1) {
@@ -386,7 +397,7 @@ static void gbuffer_rows(const oracle_config* cfg, const float* tris, uint32_t n
   const float p00 = ubo->proj[0], p11 = ubo->proj[5];
   const float fw = (float)W, fh = (float)H;
   for (int y = (int)y0; y < (int)y1; y++)
-    for (int x = 0; x < W; x++) {
+    for (int x = col_lo(); x < col_hi(W); x++) {
       /* pixel-centre sample: ndc = (2(x+.5) - W)/W ; view-space direction (ndc.x/P00, ndc.y/P11, -1) */
       float nx = dm_fma(2.0f, (float)x + 0.5f, -fw) / fw;
       float ny = dm_fma(2.0f, (float)y + 0.5f, -fh) / fh;
@@ -478,7 +489,7 @@ static void temporal_gradient_rows(const oracle_config* cfg, const oracle_push_c
   vec3 lc = v3(pc->currentCameraColor[0], pc->currentCameraColor[1], pc->currentCameraColor[2]);
   vec3 lcp = v3(pc->previousCameraColor[0], pc->previousCameraColor[1], pc->previousCameraColor[2]);
   for (int y = (int)y0; y < (int)y1; y++)
-    for (int x = 0; x < W; x++) {
+    for (int x = col_lo(); x < col_hi(W); x++) {
       uint64_t i = (uint64_t)y * W + x;
       float* g = grad + 4 * i;
       g[0] = g[1] = g[2] = g[3] = 0.0f; /* :119 */
@@ -578,7 +589,7 @@ static void raytrace_mat_rows(const oracle_config* cfg, const oracle_push_consta
   const float fw = (float)W, fh = (float)H;
   uint64_t rays_total = 0;
   for (int y = (int)y0; y < (int)y1; y++)
-    for (int x = 0; x < W; x++) {
+    for (int x = col_lo(); x < col_hi(W); x++) {
       uint32_t rng = oracle_rng_seed((uint32_t)x, (uint32_t)y, pc->frameNumber, pc->sample_batch); /* :297 */
       vec3 sum = v3(0.f, 0.f, 0.f);
       uint32_t first_id = 0;
@@ -709,7 +720,7 @@ static void moments_rows(const oracle_config* cfg, const oracle_push_constants* 
   float PVp[16];
   mat4_mul(ubo->projPrev, ubo->viewPrev, PVp);
   for (int y = (int)y0; y < (int)y1; y++)
-    for (int x = 0; x < W; x++) {
+    for (int x = col_lo(); x < col_hi(W); x++) {
       uint64_t ip = (uint64_t)y * W + x;
       uint32_t id = vis[ip];
       float lum = luminance(v3(traced[4 * ip], traced[4 * ip + 1], traced[4 * ip + 2]));
@@ -837,7 +848,7 @@ static void atrous_var_rows(const oracle_config* cfg, const oracle_push_constant
   const float h = 1.0f / 9.0f;                    /* :145 */
   const float one_minus_alpha = 1.0f - cfg->alpha; /* :254 */
   for (int y = (int)y0; y < (int)y1; y++)
-    for (int x = 0; x < W; x++) {
+    for (int x = col_lo(); x < col_hi(W); x++) {
       uint64_t ip = (uint64_t)y * W + x;
       vec3 cp = v3(in[4 * ip], in[4 * ip + 1], in[4 * ip + 2]); /* :122 */
       float dp = depth[ip];                                    /* :123 */

@@ -71,6 +71,8 @@ void oracle_config_default(oracle_config* cfg, uint32_t width, uint32_t height);
 /* number of worker threads for the row loops (plain pthreads, created and joined per call); 1 = scalar */
 void oracle_set_threads(int n);
 int oracle_get_threads(void);
+/* restrict the per-pixel passes to columns [x0, x1) (x1 <= x0: every column again); timing samples only */
+void oracle_set_columns(int x0, int x1);
 /* test processes only: print the faulting NATIVE thread's frames on SIGSEGV/SIGBUS/SIGABRT, then chain */
 void oracle_install_crash_trace(void);
 

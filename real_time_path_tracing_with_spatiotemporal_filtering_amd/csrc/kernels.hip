@@ -352,6 +352,8 @@ __device__ unsigned long long g_bvh_count[kCountBuckets][8];
 #if RTPT_TILE_TIMELINE
 constexpr uint32_t kTimelineMax = 1u << 16;
 __device__ unsigned long long g_timeline[2][kTimelineMax][3];  // [kernel: 0 K0, 1 K2][workgroup]{start, end, hw}
+__device__ uint32_t g_tile_order[kTimelineMax];  // experiment: K2 workgroup b takes tile g_tile_order[b] (by * gx + bx); see rtpt_debug_tile_order
+__device__ uint32_t g_tile_order_n;              // 0: the built-in order
 struct TimelineScope {
   unsigned long long t0;
   uint32_t k, b;
@@ -944,17 +946,24 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
   const uint32_t lane = threadIdx.x;
   if (tid == 0) block_rays = 0;
-#if RTPT_TILE_TIMELINE
-  TimelineScope tl_(1, blockIdx.y * gridDim.x + blockIdx.x);
-#endif
 #if RTPT_PT_CENTER_OUT
   // workgroups are dispatched in the order of their linear index; tiles are taken column by column from the middle of
   // the frame outwards, so the last ones dispatched — the tail of the launch — are the outermost columns, where (camera
   // facing the scene) the paths are short.  A frame of a few thousand tiles is only ~2 generations of workgroups.
   const uint32_t lin_ = blockIdx.y * gridDim.x + blockIdx.x, col_ = lin_ / gridDim.y;
-  const uint32_t bx_ = (col_ & 1u) ? (gridDim.x - 1u) / 2u + (col_ + 1u) / 2u : (gridDim.x - 1u) / 2u - col_ / 2u, by_ = lin_ % gridDim.y;
+  uint32_t bx_ = (col_ & 1u) ? (gridDim.x - 1u) / 2u + (col_ + 1u) / 2u : (gridDim.x - 1u) / 2u - col_ / 2u, by_ = lin_ % gridDim.y;
+#if RTPT_TILE_TIMELINE
+  if (g_tile_order_n == gridDim.x * gridDim.y) {
+    const uint32_t t_ = g_tile_order[lin_];
+    bx_ = t_ % gridDim.x;
+    by_ = t_ / gridDim.x;
+  }
+#endif
 #else
   const uint32_t bx_ = blockIdx.x, by_ = blockIdx.y;
+#endif
+#if RTPT_TILE_TIMELINE
+  TimelineScope tl_(1, by_ * gridDim.x + bx_);  // indexed by tile
 #endif
   const int tile_x0 = static_cast<int>(bx_) * kBlockX, tile_y0 = a.g.y0 + static_cast<int>(by_) * kPtRows;
   const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
@@ -1286,6 +1295,14 @@ extern "C" __attribute__((visibility("default"))) int rtpt_debug_timeline(int ke
   if (kernel < 0 || kernel > 1 || n > kTimelineMax) return -1;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 3 * n,
                              sizeof(unsigned long long) * 3 * kTimelineMax * kernel) == hipSuccess ? 0 : -1;
+}
+#endif
+#if RTPT_TILE_TIMELINE
+// timeline build only: the order in which K2's workgroups take their tiles (n = 0: back to the built-in order)
+extern "C" __attribute__((visibility("default"))) int rtpt_debug_tile_order(const uint32_t* order, uint32_t n) {
+  if (n > kTimelineMax) return -1;
+  if (n && hipMemcpyToSymbol(HIP_SYMBOL(g_tile_order), order, sizeof(uint32_t) * n) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tile_order_n), &n, sizeof n) == hipSuccess ? 0 : -1;
 }
 #endif
 #if RTPT_BVH_COUNT

@@ -161,6 +161,46 @@ def test_4k_eight_strips_equal_single_frame(hip_lib, mode):
     _strips_vs_single(W4K, H4K, 4, 5, 8, mode, 0, [(), ("E",), ("J",), ()])
 
 
+@pytest.mark.parametrize("mode", ["redundant", "exchange"])
+def test_million_triangle_4k_eight_strips_equal_single_frame(hip_lib, oracle, cornell, mode):
+    """BASELINE configs[4] as BASELINE defines it — the 1,152,000-triangle lattice at 3840x2160, 8 segments, on EIGHT row
+    strips: BVH traversal over fan pairs + per-pixel-normal filter + strip contexts + a camera move (history fetched across
+    strips) + a light move, against the single-context frame, every pixel bit for bit, both halo modes."""
+    from test_parity_gpu import _strips_vs_single
+    vx, ti, xf, cam, zfar = _instanced(oracle, cornell)
+    _strips_vs_single(W4K, H4K, 8, 5, 8, mode, 0, [(), ("E",), ("J",)], mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar,
+                      lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
+
+
+def test_million_triangle_4k_cpp_host_on_eight_strips_equals_python_host(hip_lib, oracle, cornell, tmp_path):
+    """The same configuration driven by the C++ host (north_star: "the host stays C++"): `rtpt_app --lattice 10x10x10
+    --tessellate 6 --ranks 8` builds the scene itself (host/scene_gen.cpp), runs eight in-process strip contexts with
+    redundant halo rows and, in the frames where the camera moved, swaps the history bands bounded with the posed, instanced
+    scene box (host/strips.cpp: reprojection_rows) — against the Python host's single context, bit for bit."""
+    import json
+    import subprocess
+    from test_cpp_host import APP, PKG, read_pfm
+    subprocess.check_call(["make", "-C", os.path.join(PKG, "host"), "-s"])
+    keys = ["", "E", "A"]
+    pfm = tmp_path / "out.pfm"
+    out = subprocess.run([APP, "--width", str(W4K), "--height", str(H4K), "--segments", "8", "--iterations", "5", "--frames", str(len(keys)),
+                          "--script", ",".join(keys), "--dump", str(pfm), "--lattice", "10x10x10", "--tessellate", "6", "--ranks", "8"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    stats = json.loads(out.stdout.strip().splitlines()[-1])
+    assert stats["bytes_sent"] > 0, "the camera moves did exchange history bands"
+    app = _make_instanced_app(hip_lib, _instanced(oracle, cornell), 0, debug=False)
+    try:
+        for k in keys:
+            app.drawScene(tuple(k))
+        want = app.backend.ctx.readback(hip_lib.PLANE_IMAGE)
+        assert stats["rays"] == app.backend.ctx.raycount()
+    finally:
+        app.backend.close()
+    got = read_pfm(pfm)
+    assert np.array_equal(bits(got), bits(np.ascontiguousarray(want[..., :3])))
+
+
 def test_two_contexts_are_independent(hip_lib, oracle, cornell):
     """rtpt.h: "distinct contexts are independent".  The CU count and the raised dynamic-LDS limit of the staged filter
     kernels are per-context / per-device state (they were process-global statics keyed on the first device).  Two

@@ -463,7 +463,7 @@ def test_spp_4(hip_lib, oracle, cornell):
 
 
 # ------------------------------------------------------------------------------ strips on one GPU
-def _strips_vs_single(w, h, seg, n, R, mode, flags, keys):
+def _strips_vs_single(w, h, seg, n, R, mode, flags, keys, **scene_kw):
     """R virtual ranks as separate contexts on one GPU against the single-context frame, bit for bit.  The helper plays
     the network: in exchange mode it copies the halo rows between contexts instead of RCCL, and in frames where the
     camera moved it assembles the previous frame from every rank's strip and registers it with
@@ -471,9 +471,10 @@ def _strips_vs_single(w, h, seg, n, R, mode, flags, keys):
     import torch
     from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
-    ranks = [make_app(w, h, max_segments=seg, iterations=n, rank=r, world=R, mode=mode, torch_planes=False, flags=flags)
+    # scene_kw: make_app's scene arguments (mesh, instance_xforms, cameraOrigin, z_far, lightPos) for scenes other than the OBJ
+    ranks = [make_app(w, h, max_segments=seg, iterations=n, rank=r, world=R, mode=mode, torch_planes=False, flags=flags, **scene_kw)
              for r in range(R)]
-    ref_app = make_app(w, h, max_segments=seg, iterations=n, flags=flags)
+    ref_app = make_app(w, h, max_segments=seg, iterations=n, flags=flags, **scene_kw)
     hist_dev = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(R)]
     guided = bool(flags & (abi.FLAG_EXT_VARIANCE | abi.FLAG_EXT_DISOCCLUSION))
     ids_dev = [torch.zeros((h, w), dtype=torch.int32, device="cuda") for _ in range(R)] if guided else None
