@@ -55,7 +55,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # speed-up figure, not a roofline fraction: it is kept as `replaced_pass_bytes` / `frac_vs_separate_passes_at_peak`).
 CHAIN_LEVELS = 2
 BYTES_PER_PX = {"k_atrous": 40, "k_atrous_final": 72, "k_atrous_chain": 40, "k_gradient": 36, "k_gbuffer": 24,
-                "k_gbuffer_gradient": 24 + 36, "k_pathtrace": 16, "k_present": 16 + 4}
+                "k_gbuffer_gradient": 24 + 36, "k_pathtrace": 16, "k_present": 16 + 4,
+                # K0 + K1 + K2 in one launch: G-buffer planes + gradient out (K1's inputs stay in registers), traced image out
+                "k_gbuffer_pathtrace": 24 + 16 + 16}
 # bytes the kernel as built MUST move per pixel (rgbd cells: depth rides in alpha, so 16 + 4 read and 16 written; the
 # chain reads its input once and writes its last level once).  Scenes without an id-pair table (> 63 triangles) run the
 # per-pixel-normal variant, which stages a 16-byte (normal, self weight) cell instead of the 4-byte id (+12 B/px; its
@@ -166,10 +168,11 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
 def kernel_report(kern, wl, plan, steps):
     """per-kernel average launch duration (HIP events on the launch stream) and algorithmic GB/s"""
     W = wl["width"]
-    steps = max(1, kern.get("k_pathtrace", (0.0, steps))[1])  # sampled frames = launches of the once-per-frame kernel
+    # sampled frames = launches of the once-per-frame kernel (K2 alone, or with K0 + K1 in its launch)
+    steps = max(1, kern.get("k_pathtrace", (0.0, 0))[1] + kern.get("k_gbuffer_pathtrace", (0.0, 0))[1]) if kern else max(1, steps)
     rows = {
         "k_gbuffer": plan.gbuffer_rows(), "k_gbuffer_gradient": plan.gbuffer_rows(), "k_gradient": plan.gradient_rows(),
-        "k_pathtrace": plan.raytrace_rows(),
+        "k_pathtrace": plan.raytrace_rows(), "k_gbuffer_pathtrace": plan.raytrace_rows(),
         "k_atrous_final": plan.filter_rows(wl["iterations"]), "k_present": plan.own,
     }
     out = {}
@@ -474,7 +477,7 @@ def main():
         }
         if wl.get("instanced"):
             result["traversal"] = traversal_report()
-        pt = kr.get("k_pathtrace")
+        pt = kr.get("k_pathtrace")  # the trace as a launch of its own (RTPT_NO_TRACE_FUSION=1): its Mray/s
         if pt:
             result["pathtrace_kernel_mray_s"] = round(rays / args.steps / (pt["avg_us"] * 1e-6) / 1e6, 1)
 
@@ -541,7 +544,7 @@ def main():
         inst = {"value": round(r7 / e7 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e7 / si * 1e3, 4), "steps": si, "warmup": wu,
                 "triangles": 1152000, "max_segments": wi["max_segments"], "rays_per_frame": round(r7 / si, 1), "kernels": kr7,
                 "traversal": traversal_report()}
-        if kr7.get("k_pathtrace"):
+        if kr7.get("k_pathtrace"):  # (absent when K0 + K1 share the launch)
             inst["pathtrace_kernel_mray_s"] = round(r7 / si / (kr7["k_pathtrace"]["avg_us"] * 1e-6) / 1e6, 1)
         if not args.no_cpu_baseline:
             inst["cpu_baseline"] = cpu_baseline("instanced")

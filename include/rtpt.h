@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RTPT_ABI_VERSION 3
+#define RTPT_ABI_VERSION 4
 
 /* ---- status codes -------------------------------------------------------------------- */
 #define RTPT_OK 0
@@ -352,7 +352,9 @@ typedef enum rtpt_kernel_id {
   RTPT_K_ATROUS_CHAIN_FINAL = 7, /* ... ending in the final pass */
   RTPT_K_GBUFFER_GRADIENT = 8,   /* K0 and K1 in one launch (rtpt_temporal_gradient right behind rtpt_gbuffer) */
   RTPT_K_PRESENT = 9,            /* rtpt_present: RGBA32F -> B8G8R8A8_UNORM */
-  RTPT_K_COUNT = 10
+  RTPT_K_GBUFFER_PATHTRACE = 10, /* K0, K1 and K2 in one launch (rtpt_raytrace right behind rtpt_gbuffer + rtpt_temporal_gradient,
+                                    the reference's own order, main.cpp:1105-1107): ABI version 4 */
+  RTPT_K_COUNT = 11
 } rtpt_kernel_id;
 int rtpt_timing_enable(rtpt_ctx* ctx, int enable);
 int rtpt_timing_collect(rtpt_ctx* ctx, double ms_sum[RTPT_K_COUNT], uint32_t launches[RTPT_K_COUNT]);

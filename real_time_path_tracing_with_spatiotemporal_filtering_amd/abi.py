@@ -34,9 +34,9 @@ DEBUG_HIT_ID, DEBUG_PREV_PIXEL = 0x1, 0x2
  PLANE_VARIANCE, PLANE_MOMENTS_PREV) = range(16)
 # rtpt_kernel_id
 (K_GBUFFER, K_LUT, K_GRADIENT, K_PATHTRACE, K_ATROUS, K_ATROUS_FINAL, K_ATROUS_CHAIN, K_ATROUS_CHAIN_FINAL,
- K_GBUFFER_GRADIENT, K_PRESENT, K_COUNT) = range(11)
+ K_GBUFFER_GRADIENT, K_PRESENT, K_GBUFFER_PATHTRACE, K_COUNT) = range(12)
 KERNEL_NAMES = ["k_gbuffer", "k_lut", "k_gradient", "k_pathtrace", "k_atrous", "k_atrous_final", "k_atrous_chain",
-                "k_atrous_chain_final", "k_gbuffer_gradient", "k_present"]
+                "k_atrous_chain_final", "k_gbuffer_gradient", "k_present", "k_gbuffer_pathtrace"]
 
 
 class RtptLibraryMissing(RuntimeError):

@@ -134,6 +134,9 @@ struct rtpt_ctx {
   // K0 recorded by rtpt_gbuffer: launched together with K1 when rtpt_temporal_gradient follows at once, alone otherwise
   rt::GbufferArgs pending_gb{};
   bool pending_gb_valid = false;
+  // recorded K0 (+ K1): rtpt_raytrace right behind them launches all three as one grid (kernels.hip: k_gbuffer_pathtrace);
+  // RTPT_NO_TRACE_FUSION=1 (read at rtpt_create) keeps K0 + K1 a launch of their own for A/B runs
+  bool fuse_trace = true;
   // K3 iterations recorded by rtpt_temporal_filter and not launched yet (see filter_flush)
   std::vector<FilterCall> pending;
   int chain_max = 2;        // iterations per chained launch (1 = never chain)
@@ -522,6 +525,7 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   // tuning knobs for A/B runs on the box (never needed for correctness: every setting computes the same pixels)
   if (const char* v = std::getenv("RTPT_NO_TRI_PAIRS")) c->no_pairing = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_HOST_REFIT")) c->host_refit = std::atoi(v) != 0;
+  if (const char* v = std::getenv("RTPT_NO_TRACE_FUSION")) c->fuse_trace = std::atoi(v) == 0;
   if (const char* v = std::getenv("RTPT_CHAIN_MAX")) c->chain_max = std::max(1, std::min(3, std::atoi(v)));
   if (const char* v = std::getenv("RTPT_CHAIN_FINAL")) c->chain_final = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_BVH_STACK_LDS")) c->bvh_stack_lds = std::max(1, std::atoi(v));
@@ -742,6 +746,9 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   rt::Bvh bvh;  // built aside: a failed upload leaves the context's scene (and the topology a later refit uses) untouched
   rt::build_bvh(tris.data(), total, bvh, 1e-5f, leaf_pairs);
   if (bvh.max_depth >= rt::kBvhMaxDepth) return fail(RTPT_E_INVALID, "BVH deeper than the traversal stack");
+  // the traversal addresses leaf records and nodes as base + 32-bit byte offset (48 bytes per triangle at most, 32 per node)
+  if (static_cast<uint64_t>(total) * 48u >= (1ull << 32) || bvh.nodes.size() >= (1ull << 27))
+    return fail(RTPT_E_INVALID, "scene too large for the traversal's 32-bit record offsets (more than 89,478,485 triangles)");
   if (bvh.leaf_order.size() != total) return fail(RTPT_E_INVALID, "internal: BVH lost triangles");
 
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -801,6 +808,7 @@ int rtpt_scene_upload(rtpt_ctx* c, const float* xyz, uint32_t n_verts, const uin
   sp.isect_id = static_cast<float4*>(c->isect_id.ptr);
   sp.isect_leaf = static_cast<float4*>(c->isect_leaf.ptr);
   sp.shade = static_cast<float4*>(c->shade.ptr);
+  sp.leaf_pairs = leaf_pairs ? 1u : 0u;
   rt::launch_scene_prepare(sp, c->stream);
   if ((rc = launch_check("scene_prepare"))) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));  // host staging vectors die at return
@@ -858,6 +866,7 @@ static int apply_model(rtpt_ctx* c, const float* model) {
     sp.isect_id = static_cast<float4*>(c->isect_id.ptr);
     sp.isect_leaf = static_cast<float4*>(c->isect_leaf.ptr);
     sp.shade = static_cast<float4*>(c->shade.ptr);
+    sp.leaf_pairs = c->leaf_pairs ? 1u : 0u;
     rt::launch_scene_prepare(sp, c->stream);
     int rcd = launch_check("device refit");
     if (rcd) return rcd;
@@ -907,6 +916,7 @@ static int apply_model(rtpt_ctx* c, const float* model) {
   sp.isect_id = static_cast<float4*>(c->isect_id.ptr);
   sp.isect_leaf = static_cast<float4*>(c->isect_leaf.ptr);
   sp.shade = static_cast<float4*>(c->shade.ptr);
+  sp.leaf_pairs = c->leaf_pairs ? 1u : 0u;
   rt::launch_scene_prepare(sp, c->stream);
   int rc = launch_check("scene_prepare");
   if (rc) return rc;
@@ -1080,10 +1090,10 @@ int gbuffer_flush(rtpt_ctx* c) {
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return fail(RTPT_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
   {
-    Timer tm(c, RTPT_K_GBUFFER);
+    Timer tm(c, c->pending_gb.grad_on ? RTPT_K_GBUFFER_GRADIENT : RTPT_K_GBUFFER);
     rt::launch_gbuffer(c->pending_gb, c->stream);
   }
-  return launch_check("gbuffer");
+  return launch_check(c->pending_gb.grad_on ? "gbuffer + temporal_gradient" : "gbuffer");
 }
 }  // namespace
 
@@ -1110,14 +1120,12 @@ int rtpt_temporal_gradient(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t 
     g.lut = static_cast<const float4*>(c->lut[c->lut_cur].ptr);
     g.lut_prev = static_cast<const float4*>(c->lut[c->lut_cur ^ 1].ptr);
     g.grad = static_cast<float4*>(c->gradient.ptr);
-    c->pending_gb_valid = false;
     int rcq = filter_flush(c, false);
     if (rcq) return rcq;
-    {
-      Timer tm(c, RTPT_K_GBUFFER_GRADIENT);
-      rt::launch_gbuffer(g, c->stream);
-    }
-    return launch_check("gbuffer + temporal_gradient");
+    // stays recorded: rtpt_raytrace normally follows at once (main.cpp:1107) and takes both passes into its launch; any other
+    // entry point launches them first (FLUSH_FILTER)
+    if (c->fuse_trace) return RTPT_OK;
+    return gbuffer_flush(c);
   }
   FLUSH_FILTER(c);
   rt::GradientArgs a;
@@ -1150,10 +1158,9 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   int rc = check_rows(c, y0, y1);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
-  FLUSH_FILTER(c);
+  if ((rc = filter_flush(c, false))) return rc;  // a recorded K0 (+ K1) stays recorded: it may join this launch (below)
   rt::PathtraceArgs a;
   a.g = geom(c, y0, y1);
-  if ((rc = ensure_stack_spill(c, frame_blocks(c)))) return rc;
   a.scene = scene_view(c);
   a.frame = pc->frameNumber;
   a.batch = pc->sample_batch;
@@ -1209,11 +1216,20 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   }
   c->final_swapped = false;
   c->image_alias = false;
-  {
-    Timer tm(c, RTPT_K_PATHTRACE);
-    rt::launch_pathtrace(a, c->stream);
+  // K0 (+ K1) recorded right before this call run inside this launch, behind the tracing tiles (kernels.hip: k_gbuffer_pathtrace)
+  const bool fused = c->pending_gb_valid && c->fuse_trace && rt::pathtrace_fuses_gbuffer(a, c->pending_gb);
+  if (!fused && (rc = gbuffer_flush(c))) return rc;
+  if ((rc = ensure_stack_spill(c, std::max<size_t>(frame_blocks(c), rt::pathtrace_grid_blocks(a, fused ? &c->pending_gb : nullptr))))) return rc;
+  a.scene = scene_view(c);
+  if (fused) {
+    c->pending_gb.scene = a.scene;  // the spill area may have moved since the G-buffer call was recorded
+    c->pending_gb_valid = false;
   }
-  return launch_check("raytrace");
+  {
+    Timer tm(c, fused ? RTPT_K_GBUFFER_PATHTRACE : RTPT_K_PATHTRACE);
+    rt::launch_pathtrace(a, fused ? &c->pending_gb : nullptr, c->stream);
+  }
+  return launch_check(fused ? "gbuffer + temporal_gradient + raytrace" : "raytrace");
 }
 
 // ------------------------------------------------------------------------------------------ K3
@@ -1691,6 +1707,7 @@ const char* rtpt_kernel_name(rtpt_kernel_id k) {
     case RTPT_K_ATROUS_CHAIN: return "k_atrous_chain";
     case RTPT_K_ATROUS_CHAIN_FINAL: return "k_atrous_chain_final";
     case RTPT_K_GBUFFER_GRADIENT: return "k_gbuffer_gradient";
+    case RTPT_K_GBUFFER_PATHTRACE: return "k_gbuffer_pathtrace";
     case RTPT_K_PRESENT: return "k_present";
     default: return "?";
   }
@@ -1908,8 +1925,8 @@ int rtpt_debug_bvh_check(rtpt_ctx* c, uint64_t stats[8]) {
         cb = sub[ref];
       }
       for (int a = 0; a < 3; a++) {
-        const float qlo = g[a] + static_cast<float>(nd.box[(side ? 6 : 0) + a]) * g[3 + a];
-        const float qhi = g[a] + static_cast<float>(nd.box[(side ? 9 : 3) + a]) * g[3 + a];
+        const float qlo = g[a] + static_cast<float>(nd.box[rt::bvh_box_lo(side, a)]) * g[3 + a];
+        const float qhi = g[a] + static_cast<float>(nd.box[rt::bvh_box_hi(side, a)]) * g[3 + a];
         if (!(qlo <= cb.mn[a] && qhi >= cb.mx[a])) stats[5]++;
         me.mn[a] = std::min(me.mn[a], cb.mn[a]);
         me.mx[a] = std::max(me.mx[a], cb.mx[a]);
@@ -1932,8 +1949,8 @@ int rtpt_debug_bvh_check(rtpt_ctx* c, uint64_t stats[8]) {
         if ((side ? q[ni].rref : q[ni].lref) == rt::kBvhEmpty) continue;
         for (int a = 0; a < 3; a++) {
           const float slack = 4.0f * g[3 + a] + 2.0f * pad;
-          const float qlo = g[a] + static_cast<float>(q[ni].box[(side ? 6 : 0) + a]) * g[3 + a];
-          const float qhi = g[a] + static_cast<float>(q[ni].box[(side ? 9 : 3) + a]) * g[3 + a];
+          const float qlo = g[a] + static_cast<float>(q[ni].box[rt::bvh_box_lo(side, a)]) * g[3 + a];
+          const float qhi = g[a] + static_cast<float>(q[ni].box[rt::bvh_box_hi(side, a)]) * g[3 + a];
           if (qlo < sc.mn[a] - slack || qhi > sc.mx[a] + slack) stats[6]++;
         }
       }
@@ -2021,8 +2038,8 @@ static int bvh_check_impl(const float* build_tris, const float* tris, uint32_t n
       for (int a = 0; a < 3; a++) {
         if (!(bmn[a] <= cb.mn[a] && bmx[a] >= cb.mx[a])) stats[5]++;
         // the device box: origin + q * cell, evaluated as the traversal's arithmetic implies (binary32)
-        const float qlo = g.origin[a] + static_cast<float>(q[ni].box[(side ? 6 : 0) + a]) * g.cell[a];
-        const float qhi = g.origin[a] + static_cast<float>(q[ni].box[(side ? 9 : 3) + a]) * g.cell[a];
+        const float qlo = g.origin[a] + static_cast<float>(q[ni].box[rt::bvh_box_lo(side, a)]) * g.cell[a];
+        const float qhi = g.origin[a] + static_cast<float>(q[ni].box[rt::bvh_box_hi(side, a)]) * g.cell[a];
         if (!(qlo <= bmn[a] && qhi >= bmx[a])) stats[6]++;
         me.mn[a] = std::min(me.mn[a], cb.mn[a]);
         me.mx[a] = std::max(me.mx[a], cb.mx[a]);

@@ -356,10 +356,10 @@ BvhGrid pack_quantised_nodes(const Bvh& bvh, std::vector<BvhNodeQ>& out) {
     BvhNodeQ& h = out[i];
     const bool le = n.lidx == kBvhEmpty, re = n.ridx == kBvhEmpty;
     for (int a = 0; a < 3; a++) {
-      h.box[a] = le ? 0 : qdown(n.lmin[a], a);
-      h.box[3 + a] = le ? 0 : qup(n.lmax[a], a);
-      h.box[6 + a] = re ? 0 : qdown(n.rmin[a], a);
-      h.box[9 + a] = re ? 0 : qup(n.rmax[a], a);
+      h.box[bvh_box_lo(0, a)] = le ? 0 : qdown(n.lmin[a], a);
+      h.box[bvh_box_hi(0, a)] = le ? 0 : qup(n.lmax[a], a);
+      h.box[bvh_box_lo(1, a)] = re ? 0 : qdown(n.rmin[a], a);
+      h.box[bvh_box_hi(1, a)] = re ? 0 : qup(n.rmax[a], a);
     }
     h.lref = ref(n.lidx, n.lcnt);
     h.rref = ref(n.ridx, n.rcnt);

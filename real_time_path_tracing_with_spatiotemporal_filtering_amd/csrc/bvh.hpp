@@ -54,9 +54,13 @@ struct Bvh {
 // triangle records stay binary32, so hits are unchanged.  (binary16 boxes were tried first: 11 bits of mantissa
 // inflate the leaves of the 1.15M-triangle lattice by ~30 % and the trace ran 3x SLOWER; the grid is 32x finer.)
 struct alignas(16) BvhNodeQ {
-  uint16_t box[12];  // lmin xyz, lmax xyz, rmin xyz, rmax xyz
+  // per child and axis one dword (min | max << 16): left x, y, z, right x, y, z.  The traversal rotates a dword by 16 where
+  // the ray runs against the axis, so that its low half is always the plane the ray meets first (kernels.hip: node_step)
+  uint16_t box[12];
   uint32_t lref, rref;
 };
+constexpr int bvh_box_lo(int side, int axis) { return side * 6 + 2 * axis; }
+constexpr int bvh_box_hi(int side, int axis) { return side * 6 + 2 * axis + 1; }
 static_assert(sizeof(BvhNodeQ) == 32, "quantised child-pair node is 32 bytes");
 
 struct BvhGrid {

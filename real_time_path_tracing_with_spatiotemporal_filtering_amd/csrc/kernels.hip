@@ -154,10 +154,9 @@ __device__ __forceinline__ void tri_pair_test(f3 o, f3 d, float4 r0, float4 r1, 
 
 // the same for a BVH leaf: leaves are met in traversal order, so equal distances keep the lower id (tri_test<true>'s rule),
 // and the two ids come from the leaf's id list
-__device__ __forceinline__ void tri_pair_test_leaf(f3 o, f3 d, float4 r0, float4 r1, float4 r2, float4 q1, float4 q2, uint32_t id1,
-                                                   uint32_t id1b, HitRec& h) {
-  const f3 v0{r0.x, r0.y, r0.z}, e1{r0.w, r1.x, r1.y}, e2{r1.z, r1.w, r2.x}, n{r2.y, r2.z, r2.w};
-  const f3 e2b{q1.z, q1.w, q2.x}, nb{q2.y, q2.z, q2.w};  // B: e1_B == e2 (bitwise), v0_B == v0
+__device__ __forceinline__ void tri_pair_test_leaf(f3 o, f3 d, float4 r0, float4 r1, float4 r2, f3 e2b, f3 nb, uint32_t id1, uint32_t id1b,
+                                                   HitRec& h) {
+  const f3 v0{r0.x, r0.y, r0.z}, e1{r0.w, r1.x, r1.y}, e2{r1.z, r1.w, r2.x}, n{r2.y, r2.z, r2.w};  // B: e1_B == e2 (bitwise), v0_B == v0
   const f3 tv = o - v0;
   const f3 c = exact::cross(tv, d);
   const float e2c = exact::dot(e2, c);
@@ -279,21 +278,6 @@ __device__ __forceinline__ void closest_hit_brute_set(const SceneView& sc, unsig
   }
 }
 
-// slab test; the box corners arrive as 16-bit grid indices converted to float (bvh.hpp): inv carries the cell
-// size and oi the grid origin, so the distances are ordinary ray parameters
-__device__ __forceinline__ bool slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, f3 inv, f3 oi, float tbest,
-                                     float& tnear) {
-  float t0x = fmaf_(mnx, inv.x, oi.x), t1x = fmaf_(mxx, inv.x, oi.x);
-  float t0y = fmaf_(mny, inv.y, oi.y), t1y = fmaf_(mxy, inv.y, oi.y);
-  float t0z = fmaf_(mnz, inv.z, oi.z), t1z = fmaf_(mxz, inv.z, oi.z);
-  float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
-                             __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
-  float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
-                             __builtin_fminf(__builtin_fmaxf(t0z, t1z), tbest));
-  tnear = tn;
-  return tn <= tf;
-}
-
 // General scenes: per-lane depth-first traversal of the child-pair BVH with the node stack in LDS
 // (stack[level][thread]: consecutive lanes hit consecutive banks; the stack is sized to the depth of
 // the tree that was built, PathtraceArgs/SceneView::stack_depth).
@@ -306,7 +290,8 @@ __device__ __forceinline__ bool slab(float mnx, float mny, float mnz, float mxx,
 //   child reference: bit 31 clear = interior node index; bit 31 set = leaf, (first << 2) | (count - 1);
 //   kBvhEmpty = absent child; kSentinel = empty stack.
 // Nodes are 32 bytes (two dwordx4 per visit): boxes on the scene's 16-bit grid, rounded outward — they only
-// order and cull; the triangle test is binary32 on the exact records.
+// order and cull; the triangle test is binary32 on the exact records.  A box corner q stands for origin + q * cell, so with
+// inv = cell / d and oi = (origin - o) / d a slab distance is one convert + one fma: t = q * inv + oi.
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kSentinel = 0xFFFFFFFEu;
 #ifndef RTPT_GRAD_NT_STORE
@@ -414,6 +399,7 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
   cflt* gr = (cflt*)sc.bvh_grid;
   const f3 inv{gr[3] * rd.x, gr[4] * rd.y, gr[5] * rd.z};
   const f3 oi{(gr[0] - o.x) * rd.x, (gr[1] - o.y) * rd.y, (gr[2] - o.z) * rd.z};
+  struct { uint32_t x, y, z; } const rot{rd.x < 0.0f ? 16u : 0u, rd.y < 0.0f ? 16u : 0u, rd.z < 0.0f ? 16u : 0u};
   int sp = 0;
   uint32_t cur = 0;  // root pair
   // entries [0, stack_lds) in LDS, the rest in global memory (SceneView::stack_spill)
@@ -452,11 +438,10 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
         RTPT_COUNT_TRIP(2);
         my_leaves++;
 #endif
-        const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sc.isect_leaf) + (first + j) * 48u);
-        const float4 a0 = r[0], a1 = r[1], a2 = r[2], b1 = r[4], b2 = r[5];
-        const uint32_t* pid = reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(sc.leaf_ids) + (first + j) * 4u);
-        const uint32_t ia = pid[0], ib = pid[1];
-        tri_pair_test_leaf(o, d, a0, a1, a2, b1, b2, ia + 1, ib + 1, h);
+        // one 80-byte pair record (SceneView::isect_leaf); base + 32-bit byte offset (rtpt_scene_upload bounds the scene)
+        const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sc.isect_leaf) + ((first + j) >> 1) * 80u);
+        const float4 p0 = r[0], p1 = r[1], p2 = r[2], p3 = r[3], p4 = r[4];
+        tri_pair_test_leaf(o, d, p0, p1, p2, f3{p3.x, p3.y, p3.z}, f3{p3.w, p4.x, p4.y}, f2u(p4.z) + 1, f2u(p4.w) + 1, h);
       }
       return;
     }
@@ -499,12 +484,27 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
     const uint32_t cl = b.z, cr = b.w;
     const float tb = h.t;
     float tl, tr;
-    auto lo16 = [](uint32_t w) { return static_cast<float>(w & 0xFFFFu); };
-    auto hi16 = [](uint32_t w) { return static_cast<float>(w >> 16); };
-    // both boxes are tested unconditionally (an absent child holds a zero box) so that the node is two
-    // independent 16-byte loads, not a load, a branch on the reference and another load
-    const bool sl = slab(lo16(a.x), hi16(a.x), lo16(a.y), hi16(a.y), lo16(a.z), hi16(a.z), inv, oi, tb, tl);
-    const bool sr = slab(lo16(a.w), hi16(a.w), lo16(b.x), hi16(b.x), lo16(b.y), hi16(b.y), inv, oi, tb, tr);
+    // Every dword of the six holds one axis of one box as (min16 | max16 << 16).  Rotated by 16 where the ray runs against
+    // the axis (rot, per ray), its low half is the plane the ray meets first and its high half the one it leaves through:
+    // the min / max pair per axis that sorted the two distances (12 per node) becomes one v_alignbit_b32 (6 per node).
+    // Same values: fma(q, inv, oi) is monotonic in q, increasing for inv > 0 and decreasing for inv < 0 (|d| is clamped away
+    // from 0 above, so inv is never 0 or NaN), so min(t(min), t(max)) IS t of the half selected here, bit for bit.
+    auto near_far = [&](uint32_t w, uint32_t rot_, float inv_, float oi_, float& tn_, float& tf_) {
+      const uint32_t q = __builtin_amdgcn_alignbit(w, w, rot_);
+      tn_ = fmaf_(static_cast<float>(q & 0xFFFFu), inv_, oi_);
+      tf_ = fmaf_(static_cast<float>(q >> 16), inv_, oi_);
+    };
+    float n0, n1, n2, f0, f1, f2;
+    near_far(a.x, rot.x, inv.x, oi.x, n0, f0);
+    near_far(a.y, rot.y, inv.y, oi.y, n1, f1);
+    near_far(a.z, rot.z, inv.z, oi.z, n2, f2);
+    tl = __builtin_fmaxf(__builtin_fmaxf(n0, n1), __builtin_fmaxf(n2, 0.0f));
+    const bool sl = tl <= __builtin_fminf(__builtin_fminf(f0, f1), __builtin_fminf(f2, tb));
+    near_far(a.w, rot.x, inv.x, oi.x, n0, f0);
+    near_far(b.x, rot.y, inv.y, oi.y, n1, f1);
+    near_far(b.y, rot.z, inv.z, oi.z, n2, f2);
+    tr = __builtin_fmaxf(__builtin_fmaxf(n0, n1), __builtin_fmaxf(n2, 0.0f));
+    const bool sr = tr <= __builtin_fminf(__builtin_fminf(f0, f1), __builtin_fminf(f2, tb));
     const bool hl = sl & (cl != kBvhEmpty), hr = sr & (cr != kBvhEmpty);
     if (hl && hr) {
       const bool left_first = tl <= tr;
@@ -550,8 +550,9 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
       const bool walk = !(cur & kLeafBit);
       const unsigned long long mw = __ballot(walk);
       if (!mw) break;
-      const unsigned long long ml = __ballot(!walk && cur != kSentinel);
-      if (__builtin_popcountll(ml) >= RTPT_BVH_LEAF_RATIO * __builtin_popcountll(mw)) break;
+      // lanes of this loop that are not walking hold a leaf (or have just run out of nodes): they wait
+      const int nw = __builtin_popcountll(mw), na = __builtin_popcountll(__ballot(true));
+      if (na - nw >= RTPT_BVH_LEAF_RATIO * nw) break;
       if (walk) node_step();
     }
     if ((cur & kLeafBit) && cur != kSentinel) {  // a leaf
@@ -606,7 +607,7 @@ __global__ void k_scene_prepare(ScenePrepArgs a) {
     a.shade[3 * i + 1] = make_float4(v1.x, v1.y, v1.z, n.y);
     a.shade[3 * i + 2] = make_float4(v2.x, v2.y, v2.z, n.z);
   }
-  {
+  if (!a.leaf_pairs) {
     uint32_t id = a.leaf_order[i];  // leaf slot i holds triangle id (ids stay in leaf_order)
     const float* t = a.tris + 9 * static_cast<size_t>(id);
     f3 v0 = ld3(t), v1 = ld3(t + 3), v2 = ld3(t + 6);
@@ -615,6 +616,20 @@ __global__ void k_scene_prepare(ScenePrepArgs a) {
     a.isect_leaf[3 * i] = make_float4(v0.x, v0.y, v0.z, e1.x);
     a.isect_leaf[3 * i + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
     a.isect_leaf[3 * i + 2] = make_float4(e2.z, nn.x, nn.y, nn.z);
+  } else if (!(i & 1u) && i + 1 < a.n_tris) {
+    // leaf slots (i, i + 1) hold the two triangles A = (a, b, c), B = (a, c, d) of one fan pair: one 80-byte record, each
+    // triangle's edges and plane normal computed exactly as for its own 48-byte record (SceneView::isect_leaf)
+    const uint32_t ia = a.leaf_order[i], ib = a.leaf_order[i + 1];
+    const float* ta = a.tris + 9 * static_cast<size_t>(ia);
+    const float* tb = a.tris + 9 * static_cast<size_t>(ib);
+    const f3 v0 = ld3(ta), e1 = ld3(ta + 3) - v0, e2 = ld3(ta + 6) - v0, nn = exact::cross(e1, e2);
+    const f3 v0b = ld3(tb), e1b = ld3(tb + 3) - v0b, e2b = ld3(tb + 6) - v0b, nb = exact::cross(e1b, e2b);
+    float4* r = a.isect_leaf + 5 * static_cast<size_t>(i >> 1);
+    r[0] = make_float4(v0.x, v0.y, v0.z, e1.x);
+    r[1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+    r[2] = make_float4(e2.z, nn.x, nn.y, nn.z);
+    r[3] = make_float4(e2b.x, e2b.y, e2b.z, nb.x);
+    r[4] = make_float4(nb.y, nb.z, u2f(ia), u2f(ib));
   }
 }
 
@@ -720,19 +735,13 @@ __global__ void k_ray_tables(int W, int H, float p00, float p11, float* dvx, flo
   }
 }
 
+// K0 (+ K1 when a.grad_on) for pixel (x, y), which must lie inside the frame and inside a's rows; `cand` = span_candidates of
+// the pixel's wave (brute force with culling only).  alpha_image != NULL (the fused K0 + K1 + K2 launch): the depth also goes
+// into the alpha of that image's pixel for rows [ay0, ay1) — the traced image is "rgbd" (atrous.hip) and the tracing
+// workgroups of that launch store the colour's 12 bytes only.
 template <int BVH>
-__global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
-  extern __shared__ uint32_t stack[];  // BVH: stack_depth x 256 entries (dynamic); unused otherwise
-#if RTPT_TILE_TIMELINE
-  TimelineScope tl_(0, blockIdx.y * gridDim.x + blockIdx.x);
-#endif
-  const int tid = threadIdx.y * kBlockX + threadIdx.x;
-  const int x = blockIdx.x * kBlockX + threadIdx.x;
-  const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
-  unsigned long long cand = 0;
-  if (!BVH && a.cull)
-    cand = span_candidates(a.bounds, a.scene.n_tris, static_cast<int>(blockIdx.x) * kBlockX, __builtin_amdgcn_readfirstlane(y));
-  if (x >= a.g.W || y >= a.g.y1) return;
+__device__ __forceinline__ void gbuffer_pixel(const GbufferArgs& a, int x, int y, unsigned long long cand, uint32_t* stack, int tid, int nt,
+                                              float4* alpha_image = nullptr, int ay0 = 0, int ay1 = 0) {
   // view-space direction of the pixel-centre ray: (ndc.x / P00, ndc.y / P11, -1) with ndc = (2 (x + .5) - W) / W.  Each
   // component is a function of the column or of the row alone: k_ray_tables evaluates the two divisions per column / row
   // once (same operands, same correctly-rounded operations), K0 reads them back — 4 divisions less per pixel
@@ -744,11 +753,12 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
   if (!BVH && a.cull)
     closest_hit_brute_set(a.scene, cand, o, d, h);
   else
-    closest_hit<BVH>(a.scene, o, d, h, stack, tid);
+    closest_hit<BVH>(a.scene, o, d, h, stack, tid, nt);
   const size_t i = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
   a.vis[i] = h.id1;  // visibility.frag.glsl:23
   if (a.normals) a.normals[i] = a.normal_tab[h.id1];
   f3 wp{0.f, 0.f, 0.f};
+  float dep = 1.0f;  // clear depth  main.cpp:1421
   if (h.id1) {
     float b1 = RTPT_DIV_SH(-h.u, h.ad), b2 = RTPT_DIV_SH(h.v, h.ad);
     float b0 = 1.0f - b1 - b2;
@@ -756,11 +766,12 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
     wp = bary_point(xyz(s[0]), xyz(s[1]), xyz(s[2]), b0, b1, b2);
     a.worldpos[i] = make_float4(wp.x, wp.y, wp.z, 1.0f);
     float cz = exact::mat_row_point(a.PV, 2, wp), cw = exact::mat_row_point(a.PV, 3, wp);
-    a.depth[i] = exact::div_(cz, cw);
+    dep = exact::div_(cz, cw);
   } else {
     a.worldpos[i] = make_float4(0.f, 0.f, 0.f, 1.0f);  // clear colour main.cpp:1420
-    a.depth[i] = 1.0f;                                  // clear depth  main.cpp:1421
   }
+  a.depth[i] = dep;
+  if (alpha_image && y >= ay0 && y < ay1) reinterpret_cast<float*>(alpha_image + i)[3] = dep;
   if (a.grad_on && y >= a.grad_y0 && y < a.grad_y1) {
     // K1 (temporalGradient.comp.glsl:104-172) on the values K0 just stored — the same bits it would load back (the world
     // position is computed ONCE: the stores above may alias the vertex records as far as the compiler knows, so a
@@ -768,6 +779,28 @@ __global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
     store_gradient(a.grad, i, gradient_lambda(h.id1, wp, a.lut, a.lut_prev, a.normal_tab, a.area_tab, ld3(a.g_cam), ld3(a.g_light), ld3(a.g_light_prev),
                                               ld3(a.g_color), ld3(a.g_color_prev)));
   }
+}
+
+// the 64 x 4-pixel tile (bx, by) of a's rows (k_gbuffer's workgroup, and the G-buffer workgroups of the fused launch)
+template <int BVH>
+__device__ __forceinline__ void gbuffer_tile(const GbufferArgs& a, uint32_t bx, uint32_t by, uint32_t* stack, float4* alpha_image = nullptr, int ay0 = 0,
+                                             int ay1 = 0) {
+  const int tid = threadIdx.y * kBlockX + threadIdx.x;
+  const int x = static_cast<int>(bx) * kBlockX + static_cast<int>(threadIdx.x);
+  const int y = a.g.y0 + static_cast<int>(by) * kBlockY + static_cast<int>(threadIdx.y);
+  unsigned long long cand = 0;
+  if (!BVH && a.cull) cand = span_candidates(a.bounds, a.scene.n_tris, static_cast<int>(bx) * kBlockX, __builtin_amdgcn_readfirstlane(y));
+  if (x >= a.g.W || y >= a.g.y1) return;
+  gbuffer_pixel<BVH>(a, x, y, cand, stack, tid, kThreads, alpha_image, ay0, ay1);
+}
+
+template <int BVH>
+__global__ __launch_bounds__(kThreads) void k_gbuffer(GbufferArgs a) {
+  extern __shared__ uint32_t stack[];  // BVH: stack_depth x 256 entries (dynamic); unused otherwise
+#if RTPT_TILE_TIMELINE
+  TimelineScope tl_(0, blockIdx.y * gridDim.x + blockIdx.x);
+#endif
+  gbuffer_tile<BVH>(a, blockIdx.x, blockIdx.y, stack);
 }
 
 __global__ __launch_bounds__(kThreads) void k_gradient(GradientArgs a) {
@@ -808,6 +841,12 @@ __device__ __forceinline__ f3 sky_color(f3 d) {  // raytrace.comp.glsl:95-107
     return f3{fmaf_(0.25f, t, it), fmaf_(0.5f, t, it), fmaf_(1.0f, t, it)};
   }
   return f3{0.03f, 0.03f, 0.03f};
+}
+
+// the colour of a pixel of an "rgbd" image without touching its alpha (one global_store_dwordx3)
+__device__ __forceinline__ void store_rgb(float4* px, f3 c) {
+  typedef float v3f_ __attribute__((ext_vector_type(3)));
+  *reinterpret_cast<v3f_*>(px) = v3f_{c.x, c.y, c.z};
 }
 
 // K2 tile: 64 x kPtRows pixels per workgroup.  More paths compacted together shrink the share of the half-empty
@@ -925,7 +964,10 @@ struct PathState {  // SoA in LDS, one slot per thread
 #ifndef RTPT_PT_CENTER_OUT
 #define RTPT_PT_CENTER_OUT 1
 #endif
-template <int BVH, bool COMPACT>
+// GB: the launch also holds the workgroups of K0 (+ K1) (k_gbuffer_pathtrace below), which put the G-buffer depth into the
+// traced image's alpha themselves: a path that ends stores the 12 bytes of its colour only.  The launch's grid is then
+// taller than the tile grid (a.tiles_y rows of tiles).
+template <int BVH, bool COMPACT, bool GB>
 __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
   // dynamic LDS, two tenants that are never live together: the BVH node stack (stack_depth x 256 entries, only
   // inside closest_hit) and the compaction exchange buffer (only between the barriers of the compaction step).
@@ -950,8 +992,9 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
   // workgroups are dispatched in the order of their linear index; tiles are taken column by column from the middle of
   // the frame outwards, so the last ones dispatched — the tail of the launch — are the outermost columns, where (camera
   // facing the scene) the paths are short.  A frame of a few thousand tiles is only ~2 generations of workgroups.
-  const uint32_t lin_ = blockIdx.y * gridDim.x + blockIdx.x, col_ = lin_ / gridDim.y;
-  uint32_t bx_ = (col_ & 1u) ? (gridDim.x - 1u) / 2u + (col_ + 1u) / 2u : (gridDim.x - 1u) / 2u - col_ / 2u, by_ = lin_ % gridDim.y;
+  const uint32_t tiles_y_ = GB ? a.tiles_y : gridDim.y;
+  const uint32_t lin_ = blockIdx.y * gridDim.x + blockIdx.x, col_ = lin_ / tiles_y_;
+  uint32_t bx_ = (col_ & 1u) ? (gridDim.x - 1u) / 2u + (col_ + 1u) / 2u : (gridDim.x - 1u) / 2u - col_ / 2u, by_ = lin_ % tiles_y_;
 #if RTPT_TILE_TIMELINE
   if (g_tile_order_n == gridDim.x * gridDim.y) {
     const uint32_t t_ = g_tile_order[lin_];
@@ -1019,7 +1062,10 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
           alive = false;
           if (a.spp == 1) {
             // :328,:343 — alpha carries the G-buffer depth for the filter (rgbd)
-            a.image[gi] = make_float4(acc.x, acc.y, acc.z, a.depth[gi]);
+            if (GB)
+              store_rgb(a.image + gi, acc);  // alpha = the G-buffer depth, stored by the G-buffer workgroups of this launch
+            else
+              a.image[gi] = make_float4(acc.x, acc.y, acc.z, a.depth[gi]);
           } else {
             sum_r[pix] += acc.x;  // :325 (one path per pixel at a time: no race)
             sum_g[pix] += acc.y;
@@ -1081,7 +1127,10 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
     if (x < a.g.W && y < a.g.y1) {
       const float ns = static_cast<float>(a.spp);
       const size_t gi = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
-      a.image[gi] = make_float4(sum_r[tid] / ns, sum_g[tid] / ns, sum_b[tid] / ns, a.depth[gi]);  // :328,:343
+      if (GB)
+        store_rgb(a.image + gi, f3{sum_r[tid] / ns, sum_g[tid] / ns, sum_b[tid] / ns});
+      else
+        a.image[gi] = make_float4(sum_r[tid] / ns, sum_g[tid] / ns, sum_b[tid] / ns, a.depth[gi]);  // :328,:343
     }
   }
   // "ray" = one closest-hit query; one 64-bit atomic per block
@@ -1109,7 +1158,7 @@ __global__ __launch_bounds__(kPtThreads)
 __attribute__((amdgpu_waves_per_eu(RTPT_PT_BVH_WAVES, RTPT_PT_BVH_WAVES)))
 #endif
 void k_pathtrace(PathtraceArgs a) {
-  pathtrace_tile<BVH, COMPACT>(a);
+  pathtrace_tile<BVH, COMPACT, false>(a);
 }
 template <bool COMPACT>
 __global__ __launch_bounds__(kPtThreads)
@@ -1117,7 +1166,40 @@ __global__ __launch_bounds__(kPtThreads)
 __attribute__((amdgpu_waves_per_eu(RTPT_PT_WAVES, RTPT_PT_WAVES)))
 #endif
 void k_pathtrace_small(PathtraceArgs a) {
-  pathtrace_tile<false, COMPACT>(a);
+  pathtrace_tile<false, COMPACT, false>(a);
+}
+
+// K0 + K1 + K2 in one launch (rtpt_gbuffer / rtpt_temporal_gradient recorded right before rtpt_raytrace: main.cpp:1105-1107
+// is that order; compacting variants only, the default policy).  Workgroups are dispatched in the order of their linear
+// index: rows [0, a.tiles_y) of the grid are the tracing tiles — long ones first, pathtrace_tile — and the rows behind them
+// the G-buffer's 64 x 4 tiles, a few microseconds each, which therefore start while the last tracing tiles drain: the
+// G-buffer's work fills the tail of the trace instead of having a launch, a ramp and a tail of its own.  Nothing in the
+// trace reads what the G-buffer writes except the depth in the traced image's alpha, and that the G-buffer workgroups
+// store themselves (gbuffer_pixel) while the tracing ones store the colour's 12 bytes — disjoint bytes, any order.
+template <int BVH>
+__global__ __launch_bounds__(kPtThreads)
+#if RTPT_PT_BVH_WAVES
+__attribute__((amdgpu_waves_per_eu(RTPT_PT_BVH_WAVES, RTPT_PT_BVH_WAVES)))
+#endif
+void k_gbuffer_pathtrace(PathtraceArgs a, GbufferArgs g) {
+  if (blockIdx.y < a.tiles_y) {
+    pathtrace_tile<BVH, true, true>(a);
+  } else {
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack[];
+    gbuffer_tile<BVH>(g, blockIdx.x, blockIdx.y - a.tiles_y, stack, a.image, a.g.y0, a.g.y1);
+  }
+}
+__global__ __launch_bounds__(kPtThreads)
+#if RTPT_PT_WAVES
+__attribute__((amdgpu_waves_per_eu(RTPT_PT_WAVES, RTPT_PT_WAVES)))
+#endif
+void k_gbuffer_pathtrace_small(PathtraceArgs a, GbufferArgs g) {
+  if (blockIdx.y < a.tiles_y) {
+    pathtrace_tile<0, true, true>(a);
+  } else {
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack[];
+    gbuffer_tile<0>(g, blockIdx.x, blockIdx.y - a.tiles_y, stack, a.image, a.g.y0, a.g.y1);
+  }
 }
 
 template <int BVH>
@@ -1345,13 +1427,24 @@ void launch_gradient(const GradientArgs& a, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;
   hipLaunchKernelGGL(k_gradient, grid_for(a.g), dim3(kBlockX, kBlockY), 0, s, a);
 }
-void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
+bool pathtrace_fuses_gbuffer(const PathtraceArgs& a, const GbufferArgs& g) {
+  // the G-buffer's rows must contain the traced ones (the depth in the traced image's alpha comes from them) and the two
+  // workgroup shapes must agree (they share the launch)
+  return a.compact && a.spp >= 1 && g.g.y0 <= a.g.y0 && g.g.y1 >= a.g.y1 && a.g.y1 > a.g.y0 && kPtRows == kBlockY;
+}
+uint32_t pathtrace_grid_blocks(const PathtraceArgs& a, const GbufferArgs* gb) {
+  const uint32_t gx = (a.g.W + kBlockX - 1) / kBlockX;
+  return gx * ((a.g.y1 - a.g.y0 + kPtRows - 1) / kPtRows + (gb ? (gb->g.y1 - gb->g.y0 + kBlockY - 1) / kBlockY : 0));
+}
+void launch_pathtrace(const PathtraceArgs& a, const GbufferArgs* gb, hipStream_t s) {
   if (a.g.y1 <= a.g.y0) return;
   dim3 block(kBlockX, kPtRows);
-  const dim3 grid((a.g.W + kBlockX - 1) / kBlockX, (a.g.y1 - a.g.y0 + kPtRows - 1) / kPtRows, 1);
+  const uint32_t tiles_y = (a.g.y1 - a.g.y0 + kPtRows - 1) / kPtRows;
+  const dim3 grid((a.g.W + kBlockX - 1) / kBlockX, tiles_y + (gb ? (gb->g.y1 - gb->g.y0 + kBlockY - 1) / kBlockY : 0), 1);
   const size_t stack_bytes = a.scene.use_bvh ? static_cast<size_t>(a.scene.stack_lds) * kPtThreads * 4 : 0;
   size_t dyn = stack_bytes > sizeof(PathState) ? stack_bytes : sizeof(PathState);  // shared by both tenants
   PathtraceArgs b = a;
+  b.tiles_y = tiles_y;
   b.multi_off = static_cast<uint32_t>(dyn / 4);
   const size_t dyn_queue = dyn;
   if (a.spp > 1) dyn += 4 * kPtThreads * 4;  // sum_r, sum_g, sum_b, rng_pix
@@ -1365,7 +1458,14 @@ void launch_pathtrace(const PathtraceArgs& a, hipStream_t s) {
   b.q_out = split ? a.queue[0] : nullptr;
   b.q_out_count = split ? a.queue_count : nullptr;
   if (split) (void)hipMemsetAsync(a.queue_count, 0, 2 * kPathQueues * sizeof(uint32_t), s);
-  if (a.compact) {
+  if (gb) {
+    if (a.scene.use_bvh && a.scene.leaf_pairs)
+      hipLaunchKernelGGL((k_gbuffer_pathtrace<2>), grid, block, dyn, s, b, *gb);
+    else if (a.scene.use_bvh)
+      hipLaunchKernelGGL((k_gbuffer_pathtrace<1>), grid, block, dyn, s, b, *gb);
+    else
+      hipLaunchKernelGGL(k_gbuffer_pathtrace_small, grid, block, dyn, s, b, *gb);
+  } else if (a.compact) {
     if (a.scene.use_bvh && a.scene.leaf_pairs)
       hipLaunchKernelGGL((k_pathtrace<2, true>), grid, block, dyn, s, b);
     else if (a.scene.use_bvh)

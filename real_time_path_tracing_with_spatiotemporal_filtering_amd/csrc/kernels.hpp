@@ -14,7 +14,11 @@ namespace rt {
 //   shade record  s0 = (v0.xyz, n.x)  s1 = (v1.xyz, n.y)  s2 = (v2.xyz, n.z)     n = unit geometric normal
 struct SceneView {
   const float4* isect_id;    // id order  (small-scene wave-uniform brute force)
-  const float4* isect_leaf;  // BVH leaf order
+  // BVH leaf order.  leaf_pairs == 0: one 48-byte isect record per leaf slot.  leaf_pairs != 0: one 80-byte record per PAIR
+  // of slots (2q, 2q + 1) — the two fan triangles share v0 and the edge e2_A == e1_B, and their ids ride in the record:
+  //   p0 = (v0.xyz, e1.x)  p1 = (e1.yz, e2.xy)  p2 = (e2.z, n.xyz)  p3 = (e2_B.xyz, n_B.x)  p4 = (n_B.yz, id_A, id_B as bits)
+  // five 16-byte loads per pair test instead of five + two id loads (the traversal is bound by its vector-memory requests)
+  const float4* isect_leaf;
   const uint32_t* leaf_ids;  // triangle id of each leaf slot
   const float4* shade;       // id order
   const BvhNodeQ* nodes;     // 32-byte child-pair nodes, boxes on a 16-bit grid (bvh.hpp)
@@ -123,6 +127,7 @@ struct PathtraceArgs {
   int32_t cull;                // 1: bounds[] is valid for the primary segment
   int32_t n_cu;                // compute units of the context's device (persistent queue-kernel grid)
   uint32_t multi_off;          // dword offset of the spp > 1 accumulators in dynamic LDS (set by launch_pathtrace)
+  uint32_t tiles_y;            // rows of 64 x 4 tiles of the traced rows (set by launch_pathtrace; the fused launch's grid is taller)
   // long paths (spp == 1, max_segments > 4): a launch covers the segment window [seg_begin, seg_end) and hands the
   // unfinished paths to the next one through a queue of 48-byte records (set by launch_pathtrace)
   uint32_t seg_begin, seg_end;
@@ -238,6 +243,7 @@ struct ScenePrepArgs {
   float4* isect_id;
   float4* isect_leaf;
   float4* shade;
+  uint32_t leaf_pairs;  // the BVH was built over fan pairs: isect_leaf holds one 80-byte record per pair (SceneView::isect_leaf)
 };
 
 void launch_scene_prepare(const ScenePrepArgs& a, hipStream_t s);
@@ -263,7 +269,11 @@ void launch_lut(const LutArgs& a, hipStream_t s);
 void launch_gbuffer(const GbufferArgs& a, hipStream_t s);
 void launch_ray_tables(int W, int H, float p00, float p11, float* dvx, float* dvy, hipStream_t s);
 void launch_gradient(const GradientArgs& a, hipStream_t s);
-void launch_pathtrace(const PathtraceArgs& a, hipStream_t s);
+// gb != NULL: K0 (+ K1) of gb's rows run inside the tile kernel's launch, behind the tracing tiles (pathtrace_fuses_gbuffer says
+// whether they can; pathtrace_grid_blocks = the workgroups of that launch, what the BVH stack's spill area is sized for)
+void launch_pathtrace(const PathtraceArgs& a, const GbufferArgs* gb, hipStream_t s);
+bool pathtrace_fuses_gbuffer(const PathtraceArgs& a, const GbufferArgs& g);
+uint32_t pathtrace_grid_blocks(const PathtraceArgs& a, const GbufferArgs* gb);
 void launch_atrous(const AtrousArgs& a, bool final_pass, hipStream_t s);
 bool atrous_final_fuses_present(const AtrousArgs& a);
 // `levels` consecutive iterations k, k+1, .. in one launch, intermediates in LDS (atrous_chain.hip): a.k = the first

@@ -126,8 +126,8 @@ __global__ void k_refit_quantise(RefitArgs a, uint32_t n_nodes) {
         while (q < 65535.0 && org + static_cast<float>(q) * cell < xhi) q += 1.0;
         qhi = static_cast<uint32_t>(q);
       }
-      nd.box[(side ? 6 : 0) + ax] = static_cast<uint16_t>(qlo);
-      nd.box[(side ? 9 : 3) + ax] = static_cast<uint16_t>(qhi);
+      nd.box[bvh_box_lo(side, ax)] = static_cast<uint16_t>(qlo);
+      nd.box[bvh_box_hi(side, ax)] = static_cast<uint16_t>(qhi);
     }
   }
   a.nodes[ni] = nd;

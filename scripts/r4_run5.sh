@@ -1,0 +1,12 @@
+#!/bin/bash
+O=gpurun_out/r4d; mkdir -p $O
+line() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(sys.argv[1], '|', d['ms_per_step'], {k:(v['avg_us'], v['launches_per_frame']) for k,v in d.get('kernels',{}).items()})" "$1"; }
+timeout -k 10 1500 python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; echo "pytest rc $?" >> $O/pytest.txt; tail -5 $O/pytest.txt
+for e in "X=0" "RTPT_NO_TRACE_FUSION=1"; do
+  for w in "--workload 4k --emulate-strip 3/8" "--workload 4k" "--workload 1080p" "--workload instanced --steps 60"; do
+    env $e timeout -k 10 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary $w 2>/dev/null | line "$e $w" >> $O/fuse_ab.txt
+  done
+done
+cat $O/fuse_ab.txt

@@ -108,9 +108,10 @@ def test_chain_is_what_runs_by_default_on_large_frames(hip_lib):
             app.drawScene()
         tm = ctx.timing_collect()
         assert (tm["k_atrous_chain"][1], tm["k_atrous"][1], tm["k_atrous_final"][1]) == want, (w, h, flags, tm)
-        # K0 and K1: one launch unless every pass is launched when called
+        # K0, K1 and K2: one launch unless every pass is launched when called
         fused = not (flags & hip_lib.FLAG_NO_FILTER_FUSION)
-        assert (tm["k_gbuffer_gradient"][1], tm["k_gbuffer"][1], tm["k_gradient"][1]) == ((3, 0, 0) if fused else (0, 3, 3)), tm
+        assert (tm["k_gbuffer_pathtrace"][1], tm["k_gbuffer_gradient"][1], tm["k_gbuffer"][1], tm["k_gradient"][1], tm["k_pathtrace"][1]) == \
+            ((3, 0, 0, 0, 0) if fused else (0, 0, 3, 3, 3)), tm
         app.backend.close()
 
 
@@ -138,7 +139,10 @@ def test_gbuffer_gradient_fusion_and_observation(hip_lib):
             app.copyImageToSwapChainsCurrentImage()
             app.frameCount += 1
         tm = ctx.timing_collect()
+        # fused: K0 + K1 stay recorded until rtpt_raytrace and share its launch; here the planes are read back right behind
+        # rtpt_temporal_gradient, so the two run as a launch of their own (k_gbuffer_gradient) and K2 as another
         assert tm["k_gbuffer_gradient"][1] == (3 if mode == "fused" else 0) and tm["k_gradient"][1] == (0 if mode == "fused" else 3)
+        assert tm["k_gbuffer_pathtrace"][1] == 0 and tm["k_pathtrace"][1] == 3
         outs.append(planes)
         app.backend.close()
     for other in outs[1:]:
