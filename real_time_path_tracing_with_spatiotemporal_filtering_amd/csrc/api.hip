@@ -137,6 +137,7 @@ struct rtpt_ctx {
   // recorded K0 (+ K1): rtpt_raytrace right behind them launches all three as one grid (kernels.hip: k_gbuffer_pathtrace);
   // RTPT_NO_TRACE_FUSION=1 (read at rtpt_create) keeps K0 + K1 a launch of their own for A/B runs
   bool fuse_trace = true;
+  rt::FilterPolicy filter_policy;  // RTPT_CHAIN_* (read once, here: rtpt_create)
   // K3 iterations recorded by rtpt_temporal_filter and not launched yet (see filter_flush)
   std::vector<FilterCall> pending;
   int chain_max = 2;        // iterations per chained launch (1 = never chain)
@@ -483,8 +484,6 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
     return fail(RTPT_E_INVALID, "max_segments, samples_per_pixel and sigma_n must be >= 1");
   if ((cfg->flags & RTPT_FLAG_EXT_SVGF_VARIANCE) && !(cfg->flags & RTPT_FLAG_EXT_VARIANCE))
     return fail(RTPT_E_INVALID, "RTPT_FLAG_EXT_SVGF_VARIANCE completes RTPT_FLAG_EXT_VARIANCE: set both");
-  if ((cfg->flags & RTPT_FLAG_EXT_SVGF_VARIANCE) && (cfg->row_begin != 0 || cfg->row_end != cfg->height))
-    return fail(RTPT_E_INVALID, "RTPT_FLAG_EXT_SVGF_VARIANCE needs a whole-frame context (its 7x7 estimate reads traced rows a strip does not hold)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
@@ -526,6 +525,12 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   if (const char* v = std::getenv("RTPT_NO_TRI_PAIRS")) c->no_pairing = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_HOST_REFIT")) c->host_refit = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_NO_TRACE_FUSION")) c->fuse_trace = std::atoi(v) == 0;
+  if (const char* v = std::getenv("RTPT_CHAIN_G1")) c->filter_policy.chain_g_pin = std::atoi(v);
+  if (const char* v = std::getenv("RTPT_CHAIN_GENERIC")) c->filter_policy.chain_generic = std::atoi(v);
+  if (const char* v = std::getenv("RTPT_CHAIN_WG_PER_CU")) c->filter_policy.chain_wg_per_cu = std::atoi(v);
+  if (const char* v = std::getenv("RTPT_CHAIN_SW")) c->filter_policy.chain_sw = std::atoi(v);
+  if (const char* v = std::getenv("RTPT_CHAIN_SW_G1")) c->filter_policy.chain_sw_g1 = std::atoi(v);
+  if (const char* v = std::getenv("RTPT_CHAIN_SW_G3")) c->filter_policy.chain_sw_g3 = std::atoi(v);
   if (const char* v = std::getenv("RTPT_CHAIN_MAX")) c->chain_max = std::max(1, std::min(3, std::atoi(v)));
   if (const char* v = std::getenv("RTPT_CHAIN_FINAL")) c->chain_final = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_BVH_STACK_LDS")) c->bvh_stack_lds = std::max(1, std::atoi(v));
@@ -580,10 +585,6 @@ int rtpt_resize(rtpt_ctx* c, uint32_t width, uint32_t height, uint32_t row_begin
   c->cfg.row_begin = row_begin;
   c->cfg.row_end = row_end;
   c->present_dst = c->present_fused_dst = nullptr;  // a swapchain image registered for the old size is not this size's
-  if ((c->cfg.flags & RTPT_FLAG_EXT_SVGF_VARIANCE) && (row_begin != 0 || row_end != height)) {
-    c->cfg = old;
-    return fail(RTPT_E_INVALID, "RTPT_FLAG_EXT_SVGF_VARIANCE needs a whole-frame context");
-  }
   int rc = alloc_planes(c);
   if (rc != RTPT_OK) {  // leave a usable context behind if the old size still fits
     c->cfg = old;
@@ -1370,6 +1371,7 @@ int filter_launch(rtpt_ctx* c, const FilterCall& f, int levels) {
         m.hist_y1 = c->ext_guides_y1;
       }
       m.svgf = (ext & rt::kExtSvgfVariance) ? 1 : 0;
+      m.rows_stored = static_cast<int32_t>(c->rows());
       m.moments_out = static_cast<float4*>(c->moments[c->moments_cur].ptr);
       m.var_out = static_cast<float*>(c->variance[0].ptr);
       rt::launch_moments(m, c->stream);
@@ -1379,7 +1381,7 @@ int filter_launch(rtpt_ctx* c, const FilterCall& f, int levels) {
     a.var_out = static_cast<float*>(c->variance[c->variance_last ^ 1].ptr);
     c->variance_last ^= 1;
     if ((ext & rt::kExtSvgfVariance) && c->var_scale.ptr) {  // SVGF's variance prefilter: the centre's scale only
-      rt::launch_var_prefilter(geom(c, y0, y1), a.var_in, static_cast<float*>(c->var_scale.ptr), c->stream);
+      rt::launch_var_prefilter(geom(c, y0, y1), static_cast<int>(c->rows()), a.var_in, static_cast<float*>(c->var_scale.ptr), c->stream);
       a.var_scale = static_cast<const float*>(c->var_scale.ptr);
     }
   }
@@ -1396,7 +1398,7 @@ int filter_launch(rtpt_ctx* c, const FilterCall& f, int levels) {
   {
     Timer tm(c, levels > 1 ? (final_pass ? RTPT_K_ATROUS_CHAIN_FINAL : RTPT_K_ATROUS_CHAIN) : (final_pass ? RTPT_K_ATROUS_FINAL : RTPT_K_ATROUS));
     if (levels > 1)
-      rt::launch_atrous_chain(a, levels, final_pass, c->stream);
+      rt::launch_atrous_chain(a, levels, final_pass, c->filter_policy, c->stream);
     else
       rt::launch_atrous(a, final_pass, c->stream);
   }

@@ -197,7 +197,7 @@ __constant__ float kGauss5[5][5] = {{1, 4, 7, 4, 1}, {4, 16, 26, 16, 4}, {7, 26,
 __device__ __forceinline__ float luminance(f3 c) { return fmaf_(0.0722f, c.z, fmaf_(0.7152f, c.y, 0.2126f * c.x)); }
 
 // RTPT_FLAG_EXT_VARIANCE (extension, see include/rtpt.h): first and second luminance moments accumulated along the
-// reprojected pixel, history length, and the variance the filter iterations are guided by.  Whole-frame contexts only.
+// reprojected pixel, history length, and the variance the filter iterations are guided by.
 __global__ __launch_bounds__(kThreads) void k_moments(MomentsArgs a) {
   const int x = blockIdx.x * kBlockX + threadIdx.x;
   const int y = a.g.y0 + blockIdx.y * kBlockY + threadIdx.y;
@@ -226,14 +226,17 @@ __global__ __launch_bounds__(kThreads) void k_moments(MomentsArgs a) {
   if (n < 4.0f) {
     if (a.svgf) {
       // SVGF: a history this short says nothing about the variance yet — estimate it from the current frame's luminance
-      // over the 7x7 neighbourhood, taps on the same primitive only (the centre always counts); rows the context does
-      // not hold are clamped like the frame border (whole-frame contexts only: rtpt_create refuses the flag on strips)
+      // over the 7x7 neighbourhood, taps on the same primitive only (the centre always counts), clamped at the frame border.
+      // On a strip the window of the outermost rows would leave the stored rows: those reads are clamped to what is stored
+      // (memory safety only — a strip stores 3 traced rows beyond the rows whose variance anything consumes, strips.py)
+      const int r_lo = a.g.row_base, r_hi = a.g.row_base + a.rows_stored - 1;
       float s1 = 0.0f, s2 = 0.0f, cnt = 0.0f;
       for (int dy = -3; dy <= 3; dy++)
         for (int dx = -3; dx <= 3; dx++) {
           int qx = x + dx, qy = y + dy;
           qx = qx < 0 ? 0 : (qx > W - 1 ? W - 1 : qx);
           qy = qy < 0 ? 0 : (qy > H - 1 ? H - 1 : qy);
+          qy = qy < r_lo ? r_lo : (qy > r_hi ? r_hi : qy);
           const size_t iqn = static_cast<size_t>(qy - a.g.row_base) * W + qx;
           if (a.vis[iqn] != id) continue;
           const float l = luminance(xyz(a.traced[iqn]));
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void k_moments(MomentsArgs a) {
 // RTPT_FLAG_EXT_SVGF_VARIANCE: the variance that scales an iteration's luminance weight is the 3x3 Gaussian of the variance
 // plane around the pixel (SVGF's variance prefilter), unit spacing whatever the iteration's stride: a pass of its own (8 B/px)
 // because the staged filter kernels hold rows k apart
-__global__ __launch_bounds__(kThreads) void k_var_prefilter(FrameGeom g, const float* __restrict__ var, float* __restrict__ out) {
+__global__ __launch_bounds__(kThreads) void k_var_prefilter(FrameGeom g, int rows_stored, const float* __restrict__ var, float* __restrict__ out) {
   const int x = blockIdx.x * kBlockX + threadIdx.x;
   const int y = g.y0 + blockIdx.y * kBlockY + threadIdx.y;
   if (x >= g.W || y >= g.y1) return;
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(kThreads) void k_var_prefilter(FrameGeom g, const f
       int qx = x + dx, qy = y + dy;
       qx = qx < 0 ? 0 : (qx > g.W - 1 ? g.W - 1 : qx);
       qy = qy < 0 ? 0 : (qy > g.H - 1 ? g.H - 1 : qy);
+      qy = qy < g.row_base ? g.row_base : (qy > g.row_base + rows_stored - 1 ? g.row_base + rows_stored - 1 : qy);  // memory safety on strips
       const float gw = (dx == 0 ? 2.0f : 1.0f) * (dy == 0 ? 2.0f : 1.0f);
       acc = fmaf_(gw, var[static_cast<size_t>(qy - g.row_base) * g.W + qx], acc);
     }
@@ -781,9 +785,9 @@ void launch_present(const FrameGeom& g, const float4* image, uint32_t* dst, hipS
   hipLaunchKernelGGL(k_present, grid_for(g), dim3(kBlockX, kBlockY), 0, s, g, image, dst);
 }
 
-void launch_var_prefilter(const FrameGeom& g, const float* var, float* out, hipStream_t s) {
+void launch_var_prefilter(const FrameGeom& g, int rows_stored, const float* var, float* out, hipStream_t s) {
   if (g.y1 <= g.y0) return;
-  hipLaunchKernelGGL(k_var_prefilter, grid_for(g), dim3(kBlockX, kBlockY), 0, s, g, var, out);
+  hipLaunchKernelGGL(k_var_prefilter, grid_for(g), dim3(kBlockX, kBlockY), 0, s, g, rows_stored, var, out);
 }
 
 void launch_moments(const MomentsArgs& a, hipStream_t s) {

@@ -601,16 +601,22 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 896), amdgpu_waves_per
 
 }  // namespace
 
-// rows per level per step of a launch.  The short-stride pair runs best with two where the frame is tall enough (its rings
-// then admit four workgroups of 8 waves per CU; 4K: 90.4 us against 95.6), but twice the workgroups also means row segments
-// half as long, each re-staging 2*sum(s) rows: at 1080p (17-row segments) two rows per step lose 0.5 us (30.5 against 30.0).
-// The switch sits between the two measured points (segments of 17 and 66 rows); RTPT_CHAIN_G1=2|3 pins it for A/B.
-static int chain_g(int k0, int levels, int n_strips, int rows, int n_cu) {
-  if (levels != 2 || k0 != 1 || kChG != 3) return kChG;
-  const char* e = std::getenv("RTPT_CHAIN_G1");  // read per launch (~0.2 us): tests switch it inside one process
-  const int pin = e ? std::atoi(e) : 0;
-  if (pin == 2 || pin == 3) return pin;
-  const int n_segs = (n_cu * 4) / (n_strips > 0 ? n_strips : 1);
+// rows per level per step of a launch (G; a workgroup is 4 G waves of a pair).  A row segment pays 2 (s0 + s1) + 2 G rows of
+// pipeline fill and re-staging whatever its length, so what decides is how long the segments of a launch are:
+//   * long segments (a 4K frame: 135 rows): three rows per step; the short-stride pair (1,2) two, its rings then admit four
+//     workgroups per CU (4K: 90.4 us against 95.6);
+//   * short segments (an 8-rank strip of the 4K frame: 19 rows at G = 3; 1080p: 34): FOUR rows per step — 16 waves per
+//     workgroup, still two workgroups per CU, a quarter fewer steps for the same fill.  Round 4, profiles/r04_chain_g_ab.csv:
+//     the 300-row strip 25.0 -> 21.9 us per pair, 1080p 32.9 -> 31.9, where the 4K frame loses (103 against 97.7).
+// RTPT_CHAIN_G1 (read by rtpt_create, FilterPolicy::chain_g_pin) pins 2, 3 or 4 for A/B runs and tests.
+static int chain_g(int k0, int levels, int n_strips, int rows, int n_cu, int pin) {
+  if (levels != 2 || kChG != 3) return kChG;
+  if (pin == 4 || ((pin == 2 || pin == 3) && k0 == 1)) return pin;
+  const int strips = n_strips > 0 ? n_strips : 1;
+  const int segs3 = (n_cu * 2) / strips;  // G = 3: two workgroups of 12 waves per CU
+  if (!pin && (segs3 < 1 || rows / segs3 < 48)) return 4;
+  if (k0 != 1) return kChG;
+  const int n_segs = (n_cu * 4) / strips;
   return n_segs >= 1 && rows / n_segs >= 40 ? 2 : 3;
 }
 
@@ -626,32 +632,22 @@ static size_t chain_lds(int k0, int levels, uint32_t n_tris, int G) {
   return off;
 }
 
-// rows per step of the sliding-window kernel: swept per pair (RTPT_CHAIN_SW_G1 / _G3 override for A/B)
-static int chain_sw_g(int k0) {
-  const char* e = std::getenv(k0 == 1 ? "RTPT_CHAIN_SW_G1" : "RTPT_CHAIN_SW_G3");
-  const int g = e ? std::atoi(e) : kSwG;
+// rows per step of the sliding-window kernel: swept per pair (RTPT_CHAIN_SW_G1 / _G3, FilterPolicy, override for A/B)
+static int chain_sw_g(int pin) {
+  const int g = pin ? pin : kSwG;
   return g == 2 || g == 4 || g == 6 ? g : 3;
 }
-size_t atrous_chain_sw_lds(int k0, uint32_t n_tris) {
+static size_t atrous_chain_sw_lds(int k0, uint32_t n_tris, int g) {
   const int np = static_cast<int>(n_tris) + 1;
   const size_t tab = static_cast<size_t>((np * np * 4 + 15) & ~15);
-  return tab + 20u * static_cast<size_t>(2 * chain_sw_g(k0)) * (static_cast<size_t>(kChCols + 2 * k0) + kChCols);
+  return tab + 20u * static_cast<size_t>(2 * g) * (static_cast<size_t>(kChCols + 2 * k0) + kChCols);
 }
 // the sliding-window kernel serves pairs whose 2 (s0 + s1) waves fit a workgroup
 static bool chain_sw_supported(int k0) { return 64 * 2 * (2 * k0 + 1) <= 896; }
-// RTPT_CHAIN_SW=1 selects the sliding-window kernel for A/B runs.  It is NOT the default: it issues 44 % fewer LDS
-// instructions and 12 % fewer VALU instructions per launch than k_atrous_chain and is slower (4K pairs 113-116 us against
-// 95-97; profiles/r03_chain_sw_ab.csv, r03_chain_pmc_*.json): the launch is bound by VALU issue inside barrier-phased
-// steps, not by the LDS array, and a residue class per wave leaves the waves of a step unevenly loaded.
-static int chain_variant() {  // read per launch (a getenv, ~0.2 us): tests switch it inside one process
-  const char* e = std::getenv("RTPT_CHAIN_SW");
-  return e ? std::atoi(e) : 0;
-}
-
-static bool chain_generic() {  // read per launch: tests switch it inside one process
-  const char* e = std::getenv("RTPT_CHAIN_GENERIC");
-  return e && std::atoi(e) != 0;
-}
+// FilterPolicy::chain_sw (RTPT_CHAIN_SW=1 at rtpt_create) selects the sliding-window kernel for A/B runs.  It is NOT the
+// default: it issues 44 % fewer LDS instructions and 12 % fewer VALU instructions per launch than k_atrous_chain and is slower
+// (4K pairs 113-116 us against 95-97; profiles/r03_chain_sw_ab.csv, r03_chain_pmc_*.json): the launch is bound by VALU issue
+// inside barrier-phased steps, not by the LDS array, and a residue class per wave leaves the waves of a step unevenly loaded.
 
 int atrous_chain_strip_width(int k0, int levels) {
   int e0 = 0;
@@ -674,6 +670,9 @@ hipError_t prepare_device_atrous_chain() {
   if (e == hipSuccess) e = (chain_attrs<2, kChG, 1>());
   if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 2, 1>());  // the pair (1,2) on tall frames
   if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 2, 0>());
+  if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 4, 0>());  // short row segments (strips, small frames): chain_g()
+  if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 4, 1>());
+  if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 4, 3>());
   constexpr int kMaxLds = 160 * 1024;
 #define RTPT_SW_ATTR(GG)                                                                                                              \
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain_sw<false, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds); \
@@ -690,19 +689,20 @@ bool atrous_chain_supported(int k0, int levels, uint32_t n_tris) {
   if (128 * levels * kChG > 1024) return false;  // two waves per row and level: the workgroup must fit 1024 threads
   if (n_tris + 1 > 64) return false;  // id-pair table in LDS (the per-pixel-normal variant is not chained)
   if (atrous_chain_strip_width(k0, levels) < 64) return false;
-  return chain_lds(k0, levels, n_tris, kChG) <= 160 * 1024;  // chain_g() never picks more rows per step than kChG
+  return chain_lds(k0, levels, n_tris, levels == 2 && kChG == 3 ? 4 : kChG) <= 160 * 1024;  // the most rows per step chain_g() picks
 }
 
-void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, hipStream_t s) {
+void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, const FilterPolicy& pol, hipStream_t s) {
   if (a0.g.y1 <= a0.g.y0) return;
   AtrousArgs a = a0;
   a.cz = -1.44269504088896341f / a.sigma_z;
   a.cl = -1.44269504088896341f / a.sigma_l;
-  const bool sw = levels == 2 && !final_pass && chain_variant() != 0 && chain_sw_supported(a.k);
+  const bool sw = levels == 2 && !final_pass && pol.chain_sw != 0 && chain_sw_supported(a.k);
   const int bw = atrous_chain_strip_width(a.k, levels);
   a.n_strips = (a.g.W + bw - 1) / bw;
-  const int g = chain_g(a.k, levels, a.n_strips, a.g.y1 - a.g.y0, a.n_cu > 0 ? a.n_cu : 256);
-  const size_t lds = sw ? atrous_chain_sw_lds(a.k, a.n_tris) : chain_lds(a.k, levels, a.n_tris, g);
+  const int g = chain_g(a.k, levels, a.n_strips, a.g.y1 - a.g.y0, a.n_cu > 0 ? a.n_cu : 256, pol.chain_g_pin);
+  const int sw_g = chain_sw_g(a.k == 1 ? pol.chain_sw_g1 : pol.chain_sw_g3);
+  const size_t lds = sw ? atrous_chain_sw_lds(a.k, a.n_tris, sw_g) : chain_lds(a.k, levels, a.n_tris, g);
   // one resident generation of workgroups: as many per CU as the LDS admits, row segments sized to fill them
   const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
   const int waves = sw ? 2 * (2 * a.k + 1) : 2 * levels * g;
@@ -710,10 +710,7 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, hipS
   if (per_cu > 32 / waves) per_cu = 32 / waves;
   if (per_cu < 1) per_cu = 1;
   const int rows = a.g.y1 - a.g.y0;
-  if (const char* e = std::getenv("RTPT_CHAIN_WG_PER_CU")) {  // A/B: workgroups per CU the row segments are sized for
-    const int v = std::atoi(e);
-    if (v >= 1 && v < per_cu) per_cu = v;
-  }
+  if (pol.chain_wg_per_cu >= 1 && pol.chain_wg_per_cu < per_cu) per_cu = pol.chain_wg_per_cu;  // A/B: workgroups per CU the segments are sized for
   int n_segs = (n_cu * per_cu) / a.n_strips;
   if (n_segs < 1) n_segs = 1;
   int seg_rows = (rows + n_segs - 1) / n_segs;
@@ -736,7 +733,7 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, hipS
     else                                                                                \
       hipLaunchKernelGGL((k_atrous_chain_sw<false, GG>), grid, block, lds, s, a);       \
     break;
-    switch (chain_sw_g(a.k)) {
+    switch (sw_g) {
       RTPT_SW_LAUNCH(2) RTPT_SW_LAUNCH(4) RTPT_SW_LAUNCH(6)
       default: RTPT_SW_LAUNCH(3)
     }
@@ -759,8 +756,15 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, hipS
   } while (0)
   // strides as compile-time constants for the pairs a default frame runs (N = 5: (1,2) and (3,4)); RTPT_CHAIN_GENERIC=1
   // runs the generic instantiation for A/B and for the test that the two agree
-  const bool generic = chain_generic();
-  if (levels == 2 && a.k == 1 && !generic) {
+  const bool generic = pol.chain_generic != 0;
+  if (levels == 2 && g == 4 && kChG == 3) {
+    if (a.k == 1 && !generic)
+      RTPT_LAUNCH_CHAIN(2, 4, 1);
+    else if (a.k == 3 && !generic)
+      RTPT_LAUNCH_CHAIN(2, 4, 3);
+    else
+      RTPT_LAUNCH_CHAIN(2, 4, 0);
+  } else if (levels == 2 && a.k == 1 && !generic) {
     if (g == 2 && kChG == 3)
       RTPT_LAUNCH_CHAIN(2, 2, 1);
     else

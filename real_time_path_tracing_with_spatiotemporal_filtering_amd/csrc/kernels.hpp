@@ -203,12 +203,14 @@ struct MomentsArgs {
   const float4* moments_prev;
   int32_t hist_row_base, hist_y0, hist_y1;
   int32_t svgf;         // RTPT_FLAG_EXT_SVGF_VARIANCE: spatial estimate for histories shorter than 4 frames
+  int32_t rows_stored;  // rows the planes hold from g.row_base on: the 7x7 estimate never reads beyond them (strips trace 3
+                        // rows more than their filter needs, so every variance that is consumed saw its whole window)
   float4* moments_out;  // (m1, m2, n, var)
   float* var_out;
 };
 void launch_moments(const MomentsArgs& a, hipStream_t s);
 // RTPT_FLAG_EXT_SVGF_VARIANCE: out = 3x3 Gaussian (1 2 1 / 2 4 2 / 1 2 1) / 16 of var, frame-clamped, rows [g.y0, g.y1)
-void launch_var_prefilter(const FrameGeom& g, const float* var, float* out, hipStream_t s);
+void launch_var_prefilter(const FrameGeom& g, int rows_stored, const float* var, float* out, hipStream_t s);
 
 // Long paths: segments handled by the tile kernel before the survivors are queued; every later window is twice as
 // long.  Swept at 4K on the Cornell box (k_pathtrace, 8 / 16 / 32 segments; single launch 969 / 1627 / 2843 us):
@@ -279,7 +281,16 @@ bool atrous_final_fuses_present(const AtrousArgs& a);
 // `levels` consecutive iterations k, k+1, .. in one launch, intermediates in LDS (atrous_chain.hip): a.k = the first
 // stride, a.in / a.out = input of the first and output of the last iteration (distinct buffers), final_pass = the last
 // level is the frame's FINAL pass (reprojection + blend)
-void launch_atrous_chain(const AtrousArgs& a, int levels, bool final_pass, hipStream_t s);
+// launch policy switches of the filter kernels, read from the environment ONCE per context (rtpt_create) — A/B runs and the
+// tests that pin a variant set them before creating the context; 0 = the shipped choice
+struct FilterPolicy {
+  int chain_g_pin = 0;      // RTPT_CHAIN_G1: rows per level and step of a chained pair (2, 3, 4)
+  int chain_generic = 0;    // RTPT_CHAIN_GENERIC: the instantiation that reads its strides instead of having them compiled in
+  int chain_wg_per_cu = 0;  // RTPT_CHAIN_WG_PER_CU: workgroups per CU the row segments are sized for
+  int chain_sw = 0;         // RTPT_CHAIN_SW: the sliding-window form of the pair (round 3, slower)
+  int chain_sw_g1 = 0, chain_sw_g3 = 0;  // RTPT_CHAIN_SW_G1 / _G3: its rows per step
+};
+void launch_atrous_chain(const AtrousArgs& a, int levels, bool final_pass, const FilterPolicy& pol, hipStream_t s);
 bool atrous_chain_supported(int k0, int levels, uint32_t n_tris);
 hipError_t prepare_device_atrous_chain();
 hipError_t prepare_device_atrous();  // per device, from rtpt_create: raises the dynamic-LDS limit of the staged filter kernels

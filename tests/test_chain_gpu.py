@@ -64,11 +64,12 @@ def test_sliding_window_variant_equals_separate_passes(hip_lib, monkeypatch, g):
                     assert np.array_equal(pa, pb)
 
 
-@pytest.mark.parametrize("g,generic", [(2, 0), (3, 0), (2, 1), (3, 1)])
-def test_rows_per_step_of_the_first_pair(hip_lib, monkeypatch, g, generic):
-    """the chain (1,2) runs two rows per level and step on tall frames and three otherwise (chain_g(), atrous_chain.hip):
-    RTPT_CHAIN_G1 pins either, and both give the bits of the separate passes at every frame shape — from the instantiations
-    with the strides of the default pairs compiled in and (RTPT_CHAIN_GENERIC=1) from the one that reads them"""
+@pytest.mark.parametrize("g,generic", [(2, 0), (3, 0), (4, 0), (2, 1), (3, 1), (4, 1)])
+def test_rows_per_step_of_a_pair(hip_lib, monkeypatch, g, generic):
+    """a chained pair runs four rows per level and step where its row segments are short (strips, small frames), the pair
+    (1,2) two on tall frames, three otherwise (chain_g(), atrous_chain.hip): RTPT_CHAIN_G1 pins the choice (4: every pair), and
+    all give the bits of the separate passes at every frame shape — from the instantiations with the strides of the default
+    pairs compiled in and (RTPT_CHAIN_GENERIC=1) from the one that reads them"""
     monkeypatch.setenv("RTPT_CHAIN_G1", str(g))
     monkeypatch.setenv("RTPT_CHAIN_GENERIC", str(generic))
     keys = [(), ("J",), ("D", "E"), ()]
