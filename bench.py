@@ -504,7 +504,7 @@ def main():
             try:   # every rank checks EVERY rank's plan, so a leg is skipped by all of them or by none
                 for r in range(world):
                     for k in range(1, wl["iterations"] + 1):
-                        StripPlan(wl["height"], world, r, wl["iterations"], kw.get("halo", args.halo), args.flags & 0x1F0).exchange_rows(k)
+                        StripPlan(wl["height"], world, r, wl["iterations"], kw.get("halo", args.halo), args.flags & 0x9F0).exchange_rows(k)
             except ValueError as ex:   # strips shorter than the exchange halo
                 if rank == 0:
                     result.setdefault("also", {})[name] = {"skipped": str(ex)}

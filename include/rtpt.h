@@ -134,7 +134,8 @@ typedef struct rtpt_visibility_data {
                                               luminance (taps on the same primitive only) instead of the temporal estimate, still
                                               scaled by 4/n; and the variance that scales an iteration's luminance weight is the 3x3
                                               Gaussian (1 2 1 / 2 4 2 / 1 2 1) / 16 of the variance plane around the pixel.
-                                              Whole-frame contexts only. */
+                                              On strip contexts the traced rows must reach 3 rows beyond every row whose variance
+                                              an iteration reads (the hosts' strip plans do that: strips.py / host/strips.cpp). */
 
 typedef struct rtpt_config {
   uint32_t struct_size;          /* = sizeof(rtpt_config), ABI guard */

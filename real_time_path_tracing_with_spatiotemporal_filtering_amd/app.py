@@ -183,6 +183,18 @@ class HipBackend:
         ptr = other.ctx.plane_ptr(abi.PLANE_PREVIOUS) + (y0 - base) * self.width * 16
         self.ctx.set_external_history(ptr, y0, y1)
 
+    def set_guides_from(self, other: "HipBackend"):
+        """the previous frame's id plane (and, with RTPT_FLAG_EXT_VARIANCE, its moment plane) = `other`'s, which ended that
+        frame: what the moment accumulation and the disocclusion test of this context's frame read at reprojected pixels"""
+        flags = self.ctx.cfg.flags
+        y0, y1 = other.ctx.cfg.row_begin, other.ctx.cfg.row_end
+        self.ctx.set_external_guides(other.ctx.plane_ptr(abi.PLANE_PREV_VIS_ID),
+                                     other.ctx.plane_ptr(abi.PLANE_MOMENTS_PREV) if flags & abi.FLAG_EXT_VARIANCE else None, y0, y1)
+
+    @property
+    def guided(self) -> bool:
+        return bool(self.ctx.cfg.flags & (abi.FLAG_EXT_VARIANCE | abi.FLAG_EXT_DISOCCLUSION))
+
     def close(self):
         self.ctx.close()
 
@@ -194,7 +206,9 @@ class PipelinedBackend:
     passes overlap the tail of the previous frame; the finished frame is handed across as external history
     behind a stream-to-stream wait.  Same results as one backend (the RNG is seeded by pixel + frame number),
     ~16 % more frames per second at 4K on one MI355X and ~31 % on a 270-row strip (frame latency unchanged).
-    Not available with RTPT_FLAG_EXT_DISOCCLUSION (each context's previous id plane is two frames old).
+    RTPT_FLAG_EXT_DISOCCLUSION / _VARIANCE read the previous frame's id and moment planes as well: those are handed across the
+    same way before the first filter iteration (each context's own "previous" planes are two frames old) — the filter of a
+    frame then starts behind the previous frame's, the passes before it still overlap.
 
     `backends` are two objects with the backend protocol (HipBackend; the CPU tests pass oracle backends)."""
 
@@ -243,6 +257,11 @@ class PipelinedBackend:
 
     def temporal_filter(self, pc, ubo, y0, y1):
         k, n = pc.waveletIteration, pc.maxWaveletIteration
+        if k == 1 and self.frame > 0 and getattr(self.cur, "guided", False):
+            # the moment accumulation (this iteration) and the disocclusion test (the final one) read the previous frame's id /
+            # moment planes, which live in the other backend
+            self._wait_prev()
+            self.cur.set_guides_from(self.prev)
         if k == n and (k & 1) and self.frame > 0 and not self._ext_by_app:
             # the previous frame's final strip lives in the other backend's PREVIOUS plane, rows = its final rows
             self._wait_prev()
@@ -633,18 +652,15 @@ def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode=
     """createBuffers + loadMesh + buildAccelerationStructure for one rank.  `mesh` = (xyz, idx) replaces
     the OBJ (synthetic scenes of scenes.py)."""
     plan = StripPlan(height, world, rank, iterations, mode, flags & abi.FLAG_EXT_MASK)
-    if world > 1 and (flags & abi.FLAG_EXT_SVGF_VARIANCE):
-        raise ValueError("RTPT_FLAG_EXT_SVGF_VARIANCE needs a whole-frame context (its 7x7 spatial estimate reads traced rows a "
-                         "strip does not hold)")
     if torch_planes is None:
         torch_planes = world > 1  # halo exchange and the history all-gather move rows of torch-owned planes
     def one():
         return HipBackend(width, height, plan, max_segments=max_segments, flags=flags, torch_planes=torch_planes,
                           debug_mask=debug_mask)
     if frames_in_flight == 2:
-        if flags & (abi.FLAG_EXT_DISOCCLUSION | abi.FLAG_EXT_VARIANCE):
-            raise ValueError("two frames in flight cannot serve RTPT_FLAG_EXT_DISOCCLUSION / _VARIANCE "
-                             "(previous id plane and moment history live in one context)")
+        if world > 1 and flags & (abi.FLAG_EXT_DISOCCLUSION | abi.FLAG_EXT_VARIANCE):
+            raise ValueError("two frames in flight on strips cannot serve RTPT_FLAG_EXT_DISOCCLUSION / _VARIANCE yet "
+                             "(the bands of the previous id / moment planes would have to come from the other context of every rank)")
         be = PipelinedBackend([one(), one()])
     elif frames_in_flight == 1:
         be = one()

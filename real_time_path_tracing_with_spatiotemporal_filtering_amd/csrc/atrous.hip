@@ -395,9 +395,6 @@ constexpr int kPairMax = 64;    // ids (T+1) for which the pair table is kept in
 #ifndef RTPT_COMB_WAVES
 #define RTPT_COMB_WAVES 4
 #endif
-#ifndef RTPT_COMB_ORDER
-#define RTPT_COMB_ORDER 1  // 1: row-major work list dealt item by item (shipping); 0: each block walks down a column
-#endif
 #ifndef RTPT_COMB_PRIO
 #define RTPT_COMB_PRIO 1  // waves run at priority 3 while they issue an item's DMAs: 4K 67.0 -> 65.5 us (in-process A/B)
 #endif
@@ -466,7 +463,7 @@ void k_atrous_comb_sh(AtrousArgs a) {
 
   // Work list.  A logical block = four CONSECUTIVE chunks (one per wave) of one residue and one
   // column.  Each XCD (physical blocks b, b+8, ...) owns a contiguous eighth of the list; see
-  // RTPT_COMB_ORDER below for the order inside it.  The grid is persistent: the pair table is loaded once
+  // the work list below for the order inside it.  The grid is persistent: the pair table is loaded once
   // per block, not per work item.  Speed only, never correctness: any mapping filters every pixel exactly
   // once.  (Tried on top of order 1 and dropped: an L2 prefetch of the block's next item, one dword per
   // 128-byte line — 68 -> 82 us; the memory system is saturated by requests, not starved of them.)
@@ -492,11 +489,10 @@ void k_atrous_comb_sh(AtrousArgs a) {
   bx = __builtin_amdgcn_readfirstlane(bx);
   cg = __builtin_amdgcn_readfirstlane(cg);
 
-#if RTPT_COMB_ORDER == 1
   // row-major list (residue, chunk group, column), dealt to the XCD's blocks item by item: the blocks
   // resident on an XCD work on a few consecutive row bands at any time, so the column halos of x-neighbours
   // and the rows shared by consecutive bands meet in that XCD's L2 (PMC: 245 -> 200 MB fetched per 4K
-  // launch against the column-walk order 0; 4K 66-72 -> 64-68 us, 1080p 20.5 -> 18.5 us)
+  // launch against round 2's order, each block walking down a column; 4K 66-72 -> 64-68 us, 1080p 20.5 -> 18.5 us)
   (void)lb_lo; (void)lb_hi; (void)r; (void)bx; (void)cg;
 #pragma unroll 1
   for (uint32_t lb = x_lo + jx; lb < x_hi; lb += per_xcd) {
@@ -505,18 +501,6 @@ void k_atrous_comb_sh(AtrousArgs a) {
   const int r_now = __builtin_amdgcn_readfirstlane(static_cast<int>(r_u));
   const int cg_now = __builtin_amdgcn_readfirstlane(static_cast<int>(cg_u));
   const int bx_now = __builtin_amdgcn_readfirstlane(static_cast<int>(rem_u - cg_u * static_cast<uint32_t>(a.tiles_x)));
-#else
-#pragma unroll 1
-  for (uint32_t lb = lb_lo; lb < lb_hi; lb++) {
-  const int r_now = r, bx_now = bx, cg_now = cg;
-  if (++cg == a.tiles_y) {
-    cg = 0;
-    if (++bx == a.tiles_x) {
-      bx = 0;
-      ++r;
-    }
-  }
-#endif
   const int yg = a.g.y0 + cg_now * (kShWaves * kCombM * k) + r_now;  // first output row of the group
   if (yg >= a.g.y1) continue;                                      // block-uniform
   const int x0 = bx_now * (kBlockX * kShHalves);

@@ -315,289 +315,12 @@ __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Sliding-window form of the pair (round 3).  In k_atrous_chain a wave owns ROW g of every step, so each output reads
-// its 9 cells (+ 9 ids) from LDS again although consecutive outputs of one residue class (rows y, y + s, y + 2s, ...)
-// share two of their three tap rows: LDS array time was as large as the VALU time and the two did not overlap.  Here a
-// wave owns a RESIDUE CLASS c of its level (rows y = c mod s_l) and one 64-column half of the strip; it keeps the three
-// tap rows (y - s, y, y + s) x three tap columns of its class in registers and, for every new row of its class that the
-// level before it has finished, reads only that row's three cells, rotates the window (by renaming: the loop body exists
-// in three register phases) and emits row y = j - s.  Per output: 3 cell reads instead of 9 (the 9 id-pair weight
-// look-ups stay).  Same taps, same weights, same accumulation order as the separate passes: bit-identical.
-//   levels run as a software pipeline with one barrier per step of G rows, as before:
-//     step t:  DMA stages input rows   in_start + t G + r            (level-0 waves)
-//              level 0 consumes rows   in_start + (t-1) G + r        -> writes rows j - s0 into ring 1
-//              level 1 consumes rows   in_start - s0 + (t-2) G + r   -> stores rows j - s1 to global memory
-//   so both rings are plain double buffers of 2G rows (the old rings held 2 s + 2G: what was re-read lives in registers).
-//   Frame clamp of the tap ROWS (:136): when row 0 arrives every class loads it into all three window rows ("everything
-//   above is row 0"); when row H-1 arrives every class shifts it in once more and emits its last row(s) against it.
-#ifndef RTPT_CHAIN_SW_G
-#define RTPT_CHAIN_SW_G 3
+#ifndef RTPT_AB_VARIANTS
+#define RTPT_AB_VARIANTS 0
 #endif
-constexpr int kSwG = RTPT_CHAIN_SW_G;
-
-struct SwCell {  // plain scalars: HIP's float4 carries a union, which keeps part of a register window in scratch
-  float r, g, b, d;  // rgbd
-  uint32_t id;
-};
-typedef float sw_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ SwCell sw_load(const float4* col, const uint32_t* ids, int i) {
-  const sw_v4f v = *reinterpret_cast<const sw_v4f*>(col + i);
-  return SwCell{v.x, v.y, v.z, v.w, ids[i]};
-}
-struct SwRow {
-  SwCell l, m, r;  // columns x - s, x, x + s
-};
-
-template <bool EXACT>
-__device__ __forceinline__ void sw_tap(const AtrousArgs& a, const float* prow, f3 cp, float dp, const SwCell& q, f3& num, float& den) {
-  const f3 cq{q.r, q.g, q.b};
-  const float dq = q.d;
-  const float wn = prow[q.id];  // :62 via the id-pair table
-  const f3 dc = cp - cq;
-  if (EXACT) {
-    const float wd = exact::exp_(-__builtin_fabsf(dp - dq) / a.sigma_z);  // :67-68
-    const float wl = exact::exp_(-exact::length(dc) / a.sigma_l);         // :73
-    const float hw_ = (1.0f / 9.0f) * ((wn * wd) * wl);                   // :77, :145
-    num = f3{fmaf_(hw_, cq.x, num.x), fmaf_(hw_, cq.y, num.y), fmaf_(hw_, cq.z, num.z)};  // :146
-    den = den + hw_;                                                                       // :147
-  } else {
-    const float e = fmaf_(__builtin_fabsf(dp - dq), a.cz, fast::sqrt_(exact::dot(dc, dc)) * a.cl);
-    const float w = wn * __builtin_amdgcn_exp2f(e);
-    num = f3{fmaf_(w, cq.x, num.x), fmaf_(w, cq.y, num.y), fmaf_(w, cq.z, num.z)};
-    den = den + w;
-  }
-}
-
-// temporalFiltering.comp.glsl:118-155 for one pixel whose 3x3 taps sit in registers: A = row y - s, B = row y, C = row y + s
-template <bool EXACT>
-__device__ __forceinline__ f3 sw_filter(const AtrousArgs& a, const float* pairw, int NP, const SwRow& A, const SwRow& B, const SwRow& C) {
-  const f3 cp{B.m.r, B.m.g, B.m.b};
-  const float dp = B.m.d;
-  const uint32_t idp = B.m.id;
-  const float* prow = pairw + idp * NP;
-  f3 num{0.f, 0.f, 0.f};
-  float den = 0.f;
-  // :132-133: x offset outer, y offset inner
-  sw_tap<EXACT>(a, prow, cp, dp, A.l, num, den);
-  sw_tap<EXACT>(a, prow, cp, dp, B.l, num, den);
-  sw_tap<EXACT>(a, prow, cp, dp, C.l, num, den);
-  sw_tap<EXACT>(a, prow, cp, dp, A.m, num, den);
-  {
-    const float w = prow[idp];  // centre tap: q == p, both exponentials are exactly 1
-    if (EXACT) {
-      const float hw_ = (1.0f / 9.0f) * w;
-      num = f3{fmaf_(hw_, cp.x, num.x), fmaf_(hw_, cp.y, num.y), fmaf_(hw_, cp.z, num.z)};
-      den = den + hw_;
-    } else {
-      num = f3{fmaf_(w, cp.x, num.x), fmaf_(w, cp.y, num.y), fmaf_(w, cp.z, num.z)};
-      den = den + w;
-    }
-  }
-  sw_tap<EXACT>(a, prow, cp, dp, C.m, num, den);
-  sw_tap<EXACT>(a, prow, cp, dp, A.r, num, den);
-  sw_tap<EXACT>(a, prow, cp, dp, B.r, num, den);
-  sw_tap<EXACT>(a, prow, cp, dp, C.r, num, den);
-  if (EXACT) return f3{num.x / den, num.y / den, num.z / den};  // :150
-  return num * fast::rcp_(den);
-}
-
-template <bool EXACT, int G>
-__global__ __attribute__((amdgpu_flat_work_group_size(64, 896), amdgpu_waves_per_eu(8))) void k_atrous_chain_sw(AtrousArgs a) {
-  constexpr int RR = 2 * G;  // ring rows: a double buffer of G rows
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int W = a.g.W, H = a.g.H;
-  const int lane = static_cast<int>(threadIdx.x);
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
-  const int NP = static_cast<int>(a.n_tris) + 1;
-  const int s0 = a.k, s1 = a.k + 1;  // main.cpp:1259-1260: waveletIteration = k, tap offset i*k (:135)
-  const int E0 = s1;                 // level 0 is computed s1 columns beyond the strip on either side
-  const int bw = kChCols - 2 * E0;
-  const int in_stride = kChCols + 2 * s0;
-  // LDS: [id-pair weights][ring 0: staged input cells, ids][ring 1: level-0 output cells, ids]
-  const uint32_t tab = static_cast<uint32_t>((NP * NP * 4 + 15) & ~15);
-  const uint32_t r0_col = tab, r0_ids = r0_col + 16u * static_cast<uint32_t>(RR * in_stride);
-  const uint32_t r1_col = r0_ids + 4u * static_cast<uint32_t>(RR * in_stride), r1_ids = r1_col + 16u * static_cast<uint32_t>(RR * kChCols);
-  float* pairw = reinterpret_cast<float*>(lds_raw);
-  const int nthreads = static_cast<int>(blockDim.x * blockDim.y);
-  for (int i = wave * 64 + lane; i < NP * NP; i += nthreads) pairw[i] = a.pair_tab[i];
-
-  // this workgroup's strip and row segment (XCD-aware list as in k_atrous_chain)
-  const uint32_t nb = static_cast<uint32_t>(a.n_strips) * static_cast<uint32_t>(a.n_segs);
-  const uint32_t per_xcd = (nb + 7u) >> 3;
-  const uint32_t lb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  if (lb >= nb) return;  // block-uniform, before any barrier
-  const int seg = static_cast<int>(lb / static_cast<uint32_t>(a.n_strips));
-  const int strip = static_cast<int>(lb - static_cast<uint32_t>(seg) * static_cast<uint32_t>(a.n_strips));
-  const int x0 = strip * bw;
-  const int ya = a.g.y0 + seg * a.seg_rows;
-  const int yb = ya + a.seg_rows < a.g.y1 ? ya + a.seg_rows : a.g.y1;
-  if (ya >= yb) return;
-  // rows each level produces for this segment, rows to stage (frame clamp of the taps, :136)
-  const int lo1 = ya, hi1 = yb - 1;
-  const int lo0 = lo1 - s1 < 0 ? 0 : lo1 - s1, hi0 = hi1 + s1 > H - 1 ? H - 1 : hi1 + s1;
-  const int ilo = lo0 - s0 < 0 ? 0 : lo0 - s0, ihi = hi0 + s0 > H - 1 ? H - 1 : hi0 + s0;
-  const int in_start = ya - s0 - s1;
-  const int T = (hi1 - lo1 + 2 * (s0 + s1)) / G + 3;  // steps until level 1 has consumed row hi1 + s1
-
-  // ---- this wave's role: level lw, residue class cw of its OUTPUT rows, half hw of the strip
-  const int n0 = 2 * s0;
-  const int lw = wave < n0 ? 0 : 1;
-  const int wi = lw ? wave - n0 : wave;
-  const int cw = wi >> 1, hw = wi & 1;
-  const int sl = lw ? s1 : s0;
-  const int lo_in = lw ? lo0 : ilo, hi_in = lw ? hi0 : ihi;   // rows of this level's INPUT that exist
-  const int lo_out = lw ? lo1 : lo0, hi_out = lw ? hi1 : hi0;
-  const int src_stride = lw ? kChCols : in_stride;
-  const int colv = hw * 64 + lane;
-  const int El = lw ? 0 : E0;
-  const int xv = x0 - El + colv;                            // frame column this lane stands for
-  const int xc = xv < 0 ? 0 : (xv > W - 1 ? W - 1 : xv);    // :136: the lane of an outside column computes the clamped one
-  int csrc = xc - x0 + El + sl;                             // its column in the source ring (origin x0 - El - sl)
-  {
-    const int cmax = src_stride - 1 - sl;                   // lanes beyond the level's extent (level 1: colv >= bw) stay in the row
-    csrc = csrc > cmax ? cmax : csrc;
-  }
-  const float4* scol = reinterpret_cast<const float4*>(lds_raw + (lw ? r1_col : r0_col));
-  const uint32_t* sids = reinterpret_cast<const uint32_t*>(lds_raw + (lw ? r1_ids : r0_ids));
-  float4* dcol = reinterpret_cast<float4*>(lds_raw + r1_col);
-  uint32_t* dids = reinterpret_cast<uint32_t*>(lds_raw + r1_ids);
-  const int src_origin = lw ? in_start - s0 : in_start;     // ring slot of row j = (j - src_origin) mod RR
-  // the class's next input row / next output row
-  int next_j = lo_in + posmod(cw - lo_in, sl);
-  int next_y = lo_out + posmod(cw - lo_out, sl);
-  int yB = -0x40000000, yC = -0x40000000;
-  SwRow R0{}, R1{}, R2{};
-
-  // ---- staging duty (level-0 waves): task q = 2 r + chunk covers columns [64 chunk, 64 chunk + 64) of row r of the step;
-  // the chunk-0 task also covers the tail [128, in_stride).  Lane offsets are recomputed per task (registers are scarce).
-  auto stage_off = [&](int col) {  // byte offset of staged column `col` of the strip in a frame row, clamped (:136)
-    int gx = x0 - E0 - s0 + col + lane;
-    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
-    return static_cast<uint32_t>(gx) * 16u;
-  };
-  const bool tail_lane = lane < 2 * s0;
-  const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)lds_raw));
-
-  __syncthreads();  // pair table visible
-
-  // ---- the pipeline step this wave stands in: staging duty at its top, wait + barrier at its end
-  int t = 0;
-  auto stage = [&](int ts) {
-    if (lw != 0 || ts >= T) return;
-    for (int q = wi; q < 2 * G; q += n0) {
-      const int r = q >> 1, ch = q & 1;
-      const int iy = in_start + ts * G + r;
-      if (iy >= ilo && iy <= ihi) {
-        const size_t grow = static_cast<size_t>(iy - a.g.row_base) * W;
-        const float4* rin = a.in + grow;
-        const uint32_t* rvis = a.vis + grow;
-        const uint32_t slot = static_cast<uint32_t>(ts * G + r) % static_cast<uint32_t>(RR);
-        const uint32_t cell = slot * static_cast<uint32_t>(in_stride) + static_cast<uint32_t>(ch) * 64u;
-        const uint32_t off = stage_off(ch * 64);
-        __builtin_amdgcn_s_setprio(3);
-        dma_b128(rin, off, lds0 + r0_col + cell * 16u);
-        dma_b32(rvis, off >> 2, lds0 + r0_ids + cell * 4u);
-        if (ch == 0 && tail_lane) {
-          const uint32_t cellt = slot * static_cast<uint32_t>(in_stride) + 128u;
-          const uint32_t offt = stage_off(128);
-          dma_b128(rin, offt, lds0 + r0_col + cellt * 16u);
-          dma_b32(rvis, offt >> 2, lds0 + r0_ids + cellt * 4u);
-        }
-        __builtin_amdgcn_s_setprio(0);
-      }
-    }
-  };
-  // run the pipeline forward to step `tn`: every wave of the workgroup passes the same T barriers
-  auto step_to = [&](int tn) {
-    while (t < tn) {
-      // staged rows landed, ring writes done; the barrier publishes both to the next step
-      if (lw == 0)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      t++;
-      stage(t);
-    }
-  };
-
-  auto emit = [&](const SwRow& A, const SwRow& B, const SwRow& C) {
-    const int y = next_y;
-    next_y += sl;
-    const f3 filtered = sw_filter<EXACT>(a, pairw, NP, A, B, C);
-    const float dp = B.m.d;
-    if (lw == 0) {
-      // :152 into the next level's ring instead of filteredImageBuffer
-      const int di = static_cast<int>(static_cast<uint32_t>(y - in_start + s0) % static_cast<uint32_t>(RR)) * kChCols + colv;
-      dcol[di] = make_float4(filtered.x, filtered.y, filtered.z, dp);
-      dids[di] = B.m.id;
-    } else if (colv < bw && x0 + colv < W) {
-      typedef float v4f_ __attribute__((ext_vector_type(4)));
-      v4f_ o4 = {filtered.x, filtered.y, filtered.z, a.alpha_zero ? 0.0f : dp};
-      __builtin_nontemporal_store(o4, reinterpret_cast<v4f_*>(a.out + static_cast<size_t>(y - a.g.row_base) * W + x0 + colv));  // :152 (level 1: xv = x0 + colv)
-    }
-  };
-  auto ready = [&]() {
-    const int want = next_y + sl > H - 1 ? H - 1 : next_y + sl;
-    return next_y <= hi_out && yB == next_y && yC == want;
-  };
-  // The class's events in order: row 0 (frame top, every class), its own rows, row H-1 (frame bottom, every class), and —
-  // for the class of row H-1 — that row once more.  ev = the next event's row, kExtra marks the repeat, kDone the end.
-  constexpr int kDone = 0x7fffffff;
-  bool extra = false;
-  auto next_event = [&](int after) -> int {  // smallest event row > after (after = -1: the first)
-    int e = next_j <= hi_in ? next_j : kDone;                            // own rows (next_j is kept > after by the caller)
-    if (after < 0 && lo_in == 0) e = 0;                                  // the top row
-    if (hi_in == H - 1 && after < H - 1 && e > H - 1) e = H - 1;         // the bottom row
-    return e;
-  };
-  // one event in a FIXED register phase: C receives row j (A, B, C name rows y - s, y, y + s after the rotation)
-  auto arrive = [&](SwRow& A, SwRow& B, SwRow& C, int j) {
-    if (!extra) {
-      step_to((j - src_origin) / G + 1 + lw);  // the step in which row j can be read from the source ring
-      const int ro = static_cast<int>(static_cast<uint32_t>(j - src_origin) % static_cast<uint32_t>(RR)) * src_stride + csrc;
-      C.l = sw_load(scol, sids, ro - sl);
-      C.m = sw_load(scol, sids, ro);
-      C.r = sw_load(scol, sids, ro + sl);
-      if (j == next_j) next_j += sl;
-    } else {
-      C = B;  // row H-1 again: the last row of its class reads (H-1-s, H-1, H-1)
-    }
-    yB = yC;
-    yC = j;
-    if (j == 0 && !extra) {  // everything above the frame is row 0 (:136)
-      A = C;
-      B = C;
-      yB = 0;
-    }
-    if (ready()) {
-      // a row whose lower tap row is clamped to H-1 has its window complete EARLY (row H-1 arrived before row y + s
-      // would have): it still goes out in the step row y + s belongs to — the double-buffered ring of the next level
-      // has room for G rows per step, and the row that shares its slot (y - 2G) is read until then
-      if (next_y + sl > H - 1) step_to((next_y + sl - src_origin) / G + 1 + lw);
-      emit(A, B, C);
-    }
-    // what comes next
-    if (!extra && j == H - 1 && next_y == H - 1 && next_y <= hi_out) {
-      extra = true;
-      return j;
-    }
-    if (extra) return kDone;
-    return next_event(j);
-  };
-
-  stage(0);
-  int ev = next_event(-1);
-  while (ev != kDone) {  // the window rotates by renaming: three copies of the body, one per register phase
-    ev = arrive(R1, R2, R0, ev);
-    if (ev == kDone) break;
-    ev = arrive(R2, R0, R1, ev);
-    if (ev == kDone) break;
-    ev = arrive(R0, R1, R2, ev);
-  }
-  step_to(T);
-}
+#if RTPT_AB_VARIANTS
+#include "experiments/chain_sliding_window.inc"
+#endif
 
 }  // namespace
 
@@ -632,6 +355,7 @@ static size_t chain_lds(int k0, int levels, uint32_t n_tris, int G) {
   return off;
 }
 
+#if RTPT_AB_VARIANTS
 // rows per step of the sliding-window kernel: swept per pair (RTPT_CHAIN_SW_G1 / _G3, FilterPolicy, override for A/B)
 static int chain_sw_g(int pin) {
   const int g = pin ? pin : kSwG;
@@ -648,6 +372,9 @@ static bool chain_sw_supported(int k0) { return 64 * 2 * (2 * k0 + 1) <= 896; }
 // default: it issues 44 % fewer LDS instructions and 12 % fewer VALU instructions per launch than k_atrous_chain and is slower
 // (4K pairs 113-116 us against 95-97; profiles/r03_chain_sw_ab.csv, r03_chain_pmc_*.json): the launch is bound by VALU issue
 // inside barrier-phased steps, not by the LDS array, and a residue class per wave leaves the waves of a step unevenly loaded.
+// marks a library built with the A/B variants (tests skip the variant checks without it)
+extern "C" __attribute__((visibility("default"))) int rtpt_debug_ab_variants(void) { return 1; }
+#endif
 
 int atrous_chain_strip_width(int k0, int levels) {
   int e0 = 0;
@@ -673,12 +400,14 @@ hipError_t prepare_device_atrous_chain() {
   if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 4, 0>());  // short row segments (strips, small frames): chain_g()
   if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 4, 1>());
   if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 4, 3>());
+#if RTPT_AB_VARIANTS
   constexpr int kMaxLds = 160 * 1024;
 #define RTPT_SW_ATTR(GG)                                                                                                              \
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain_sw<false, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds); \
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atrous_chain_sw<true, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
   RTPT_SW_ATTR(2) RTPT_SW_ATTR(3) RTPT_SW_ATTR(4) RTPT_SW_ATTR(6)
 #undef RTPT_SW_ATTR
+#endif
   if (e == hipSuccess) e = (chain_attrs<3, kChG, 0>());
   return e;
 }
@@ -697,12 +426,20 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, cons
   AtrousArgs a = a0;
   a.cz = -1.44269504088896341f / a.sigma_z;
   a.cl = -1.44269504088896341f / a.sigma_l;
+#if RTPT_AB_VARIANTS
   const bool sw = levels == 2 && !final_pass && pol.chain_sw != 0 && chain_sw_supported(a.k);
+#else
+  const bool sw = false;
+#endif
   const int bw = atrous_chain_strip_width(a.k, levels);
   a.n_strips = (a.g.W + bw - 1) / bw;
   const int g = chain_g(a.k, levels, a.n_strips, a.g.y1 - a.g.y0, a.n_cu > 0 ? a.n_cu : 256, pol.chain_g_pin);
+#if RTPT_AB_VARIANTS
   const int sw_g = chain_sw_g(a.k == 1 ? pol.chain_sw_g1 : pol.chain_sw_g3);
   const size_t lds = sw ? atrous_chain_sw_lds(a.k, a.n_tris, sw_g) : chain_lds(a.k, levels, a.n_tris, g);
+#else
+  const size_t lds = chain_lds(a.k, levels, a.n_tris, g);
+#endif
   // one resident generation of workgroups: as many per CU as the LDS admits, row segments sized to fill them
   const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
   const int waves = sw ? 2 * (2 * a.k + 1) : 2 * levels * g;
@@ -725,6 +462,7 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, cons
   a.n_segs = (rows + seg_rows - 1) / seg_rows;
   const uint32_t nb = static_cast<uint32_t>(a.n_strips) * static_cast<uint32_t>(a.n_segs);
   const dim3 grid(((nb + 7u) / 8u) * 8u), block(64, waves);
+#if RTPT_AB_VARIANTS
   if (sw) {
 #define RTPT_SW_LAUNCH(GG)                                                              \
   case GG:                                                                              \
@@ -740,6 +478,7 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, cons
 #undef RTPT_SW_LAUNCH
     return;
   }
+#endif
 #define RTPT_LAUNCH_CHAIN(LV, GG, KK)                                                              \
   do {                                                                                             \
     if (a.exact) {                                                                                 \

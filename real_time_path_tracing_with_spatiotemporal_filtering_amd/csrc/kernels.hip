@@ -23,39 +23,21 @@ struct HitRec {
   float u, v, ad;  // scaled barycentrics of the best hit, u NEGATED: b1 = -u/ad, b2 = v/ad (tri_test)
 };
 
-// which of the divisions of the tracing kernels use exact::div_ (rtpt_math.hpp).  Neither, as shipped: the tracing kernels
+// The divisions of the tracing kernels are hipcc's correctly rounded ones, not exact::div_ (rtpt_math.hpp): the tracing kernels
 // sit at their 64-VGPR budget (8 waves per SIMD), the short sequence keeps the refined reciprocal live next to the operands
 // of the long path, and what the fewer instructions bring (K2 at 4K 368.7 -> 364.9 us with both) the spills take back on the
-// BVH kernel (3.34 -> 3.41 ms).  profiles/r03_div_ab.csv; scripts/ab_libs.sh with -DRTPT_SHORT_DIV_TH=1 -DRTPT_SHORT_DIV_SHADE=1.
-#ifndef RTPT_SHORT_DIV_TH
-#define RTPT_SHORT_DIV_TH 0
-#endif
-#ifndef RTPT_SHORT_DIV_SHADE
-#define RTPT_SHORT_DIV_SHADE 0
-#endif
-#if RTPT_SHORT_DIV_TH
-#define RTPT_DIV_TH(a, b) exact::div_((a), (b))
-#else
-#define RTPT_DIV_TH(a, b) ((a) / (b))
-#endif
-#if RTPT_SHORT_DIV_SHADE
-#define RTPT_DIV_SH(a, b) exact::div_((a), (b))
-#else
-#define RTPT_DIV_SH(a, b) ((a) / (b))
-#endif
+// BVH kernel (3.34 -> 3.41 ms; profiles/r03_div_ab.csv).  Two names so that the two groups stay easy to find.
+#define RTPT_DIV_TH(a, b) ((a) / (b))  // hit distances
+#define RTPT_DIV_SH(a, b) ((a) / (b))  // shading (barycentrics, the light test, the pixel's ndc)
 
 // Scalar-triple-product form of Moller-Trumbore, plane normal n = e1 x e2 precomputed per triangle,
 // division deferred until a candidate passes the inside tests:
 //   det = -d.n,  tt = (o-v0).n,  c = (o-v0) x d,  u = e2.c,  v = -e1.c        (21 flops instead of 27)
 // record: r0 = (v0.xyz, e1.x)  r1 = (e1.yz, e2.xy)  r2 = (e2.z, n.xyz)
-#ifndef RTPT_TRI_XOR_SIGN
-#define RTPT_TRI_XOR_SIGN 1
-#endif
 template <bool TIE_BREAK>
 __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float4 r2, uint32_t id1, HitRec& h) {
   f3 v0{r0.x, r0.y, r0.z}, e1{r0.w, r1.x, r1.y}, e2{r1.z, r1.w, r2.x}, n{r2.y, r2.z, r2.w};
   f3 tv = o - v0;
-#if RTPT_TRI_XOR_SIGN
   // The signs of u, v, tt follow the sign of det = -d.n.  Instead of comparing det with 0 and selecting three negations
   // (a v_cmp whose result three VOP3 selects must wait two cycles for), the sign bit of d.n is XORed into e2.c, e1.c and
   // tt: that yields -u, +v and -tt of the oriented triangle (v = -e1.c takes the other sign), so two of the tests read
@@ -72,24 +54,6 @@ __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float
   const bool ok = (u <= 0.0f) && (v >= 0.0f) && (v - u <= ad) && (tt < 0.0f);
   if (ok) {
     const float th = RTPT_DIV_TH(-tt, ad);
-#else
-  float det = -exact::dot(d, n);
-  float tt = exact::dot(tv, n);
-  f3 c = exact::cross(tv, d);
-  float u = exact::dot(e2, c);
-  float v = -exact::dot(e1, c);
-  float ad = __builtin_fabsf(det);
-  if (det < 0.0f) {
-    u = -u;
-    v = -v;
-    tt = -tt;
-  }
-  // no "ad > 0" term: with ad == 0 only u == v == 0 passes, th is then +inf (tt > 0), and +inf never beats h.t
-  bool ok = (u >= 0.0f) && (v >= 0.0f) && (u + v <= ad) && (tt > 0.0f);
-  if (ok) {
-    float th = RTPT_DIV_TH(tt, ad);
-    u = -u;  // HitRec keeps -u
-#endif
     bool better = th < h.t;
     if (TIE_BREAK) better = better || (th == h.t && h.id1 != 0 && id1 < h.id1);
     if (better) {
@@ -102,7 +66,6 @@ __device__ __forceinline__ void tri_test(f3 o, f3 d, float4 r0, float4 r1, float
   }
 }
 
-#if RTPT_TRI_XOR_SIGN
 // Two triangles (a, b, c), (a, c, d) of one fan-triangulated face (main.cpp:416-428 via D5: every `f` line of the
 // Cornell OBJ is a quad) share v0 and the edge c - a: tv = o - v0, c = tv x d and e2_A . c == e1_B . c are the SAME
 // binary32 values in both tests, so the second test reuses them — 17 instead of 30 VALU, each triangle's own arithmetic
@@ -201,7 +164,6 @@ __device__ __forceinline__ void tri_pair_test_leaf(f3 o, f3 d, float4 r0, float4
     }
   }
 }
-#endif
 
 // Small scenes (<= 64 triangles, the Cornell box has 32): every lane of the wave tests the same
 // triangle at the same time, so the record address is wave-uniform and the loads are scalar
@@ -218,7 +180,6 @@ __device__ __forceinline__ void closest_hit_brute(const SceneView& sc, f3 o, f3 
 #ifndef RTPT_BRUTE_UNROLL
 #define RTPT_BRUTE_UNROLL 8  // triangles whose records are fetched per batch of scalar loads; K2 at 4K: 2: 517, 4: 505, 8: 499, 16: 498 us
 #endif
-#if RTPT_TRI_XOR_SIGN
 #ifndef RTPT_PAIR_UNROLL
 #define RTPT_PAIR_UNROLL 8  // faces whose records are fetched per batch of scalar loads; K2 at 4K: 2: 384.7, 4: 378.1, 8: 376.3, 16: 376.0 us
 #endif
@@ -231,7 +192,6 @@ __device__ __forceinline__ void closest_hit_brute(const SceneView& sc, f3 o, f3 
     }
     return;
   }
-#endif
 #pragma unroll RTPT_BRUTE_UNROLL
   for (uint32_t i = 0; i < n; i++) {
     const v4f a0 = rec[3 * i], a1 = rec[3 * i + 1], a2 = rec[3 * i + 2];
@@ -255,16 +215,11 @@ __device__ __forceinline__ void closest_hit_brute_set(const SceneView& sc, unsig
   typedef float v4f __attribute__((ext_vector_type(4)));
   using cv4f = const __attribute__((address_space(4))) v4f;
   cv4f* rec = (cv4f*)sc.isect_id;
-#if RTPT_TRI_XOR_SIGN
   const bool paired = sc.paired != 0;
-#else
-  const bool paired = false;
-#endif
   while (cand) {
     const uint32_t i = static_cast<uint32_t>(__builtin_ctzll(cand));
     cand &= cand - 1;
     const v4f a0 = rec[3 * i], a1 = rec[3 * i + 1], a2 = rec[3 * i + 2];
-#if RTPT_TRI_XOR_SIGN
     if (paired && !(i & 1u) && (cand & (1ull << (i + 1)))) {  // both triangles of a fan pair are candidates (wave-uniform)
       cand &= cand - 1;
       const v4f b1 = rec[3 * i + 4], b2 = rec[3 * i + 5];
@@ -272,7 +227,6 @@ __device__ __forceinline__ void closest_hit_brute_set(const SceneView& sc, unsig
                     make_float4(b1.x, b1.y, b1.z, b1.w), make_float4(b2.x, b2.y, b2.z, b2.w), i + 1, h);
       continue;
     }
-#endif
     tri_test<false>(o, d, make_float4(a0.x, a0.y, a0.z, a0.w), make_float4(a1.x, a1.y, a1.z, a1.w),
                     make_float4(a2.x, a2.y, a2.z, a2.w), i + 1, h);
   }
@@ -296,9 +250,6 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kSentinel = 0xFFFFFFFEu;
 #ifndef RTPT_GRAD_NT_STORE
 #define RTPT_GRAD_NT_STORE 1
-#endif
-#ifndef RTPT_BVH_SPECULATE
-#define RTPT_BVH_SPECULATE 0
 #endif
 #ifndef RTPT_BVH_LEAF_RATIO
 #define RTPT_BVH_LEAF_RATIO 2  // 0: 2981 us, 1: 2734, 2: 2714, 3: 2728 for K2 on the 1.15M-triangle frame (profiles/r04_bvh_ab.csv)
@@ -431,7 +382,6 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
   };
   auto test_leaf = [&](uint32_t ref) {
     const uint32_t first = (ref & ~kLeafBit) >> 2, cnt = (ref & 3u) + 1u;
-#if RTPT_TRI_XOR_SIGN
     if (PAIRS) {
       for (uint32_t j = 0; j < cnt; j += 2) {
 #if RTPT_BVH_COUNT
@@ -445,7 +395,6 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
       }
       return;
     }
-#endif
 #if RTPT_LEAF_BATCH > 1
     // fetch the records of RTPT_LEAF_BATCH triangles before testing any of them: one memory round trip per
     // batch instead of one per triangle (indices past the leaf are clamped to its last triangle and skipped)
@@ -518,29 +467,6 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
       cur = pop();
     }
   };
-#if RTPT_BVH_SPECULATE
-  // speculative while-while: a lane that reaches a leaf postpones it and keeps walking until it holds a second
-  // leaf (or runs out of nodes), so fewer lanes idle while the slowest lane of the wave finds its first leaf
-  uint32_t post = kSentinel;
-  while (true) {
-    while (true) {
-      if (cur & kLeafBit) {  // a leaf or the sentinel
-        if (cur == kSentinel || post != kSentinel) break;
-        post = cur;
-        cur = pop();
-        continue;
-      }
-      node_step();
-    }
-    if (post == kSentinel) break;  // then cur is the sentinel too
-    test_leaf(post);
-    post = kSentinel;
-    if (cur != kSentinel) {
-      test_leaf(cur);
-      cur = pop();
-    }
-  }
-#else
 #if RTPT_BVH_LEAF_RATIO
   // while-while with an early hand-over: the node loop stops not only when every lane holds a leaf (or is done) but as
   // soon as the lanes waiting with a leaf outnumber the lanes still walking RTPT_BVH_LEAF_RATIO to one — the few walkers
@@ -568,7 +494,6 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
       cur = pop();
     }
   }
-#endif
 #endif
 }
 

@@ -1,4 +1,4 @@
-// kernels.hpp — launch interface between the C-ABI layer (api.hip) and the gfx950 kernels
+// kernels.hpp — launch interface between the C-ABI layer (api_*.hip) and the gfx950 kernels
 // (kernels.hip).  Plain structs passed by value as kernel arguments.
 #pragma once
 

@@ -136,7 +136,7 @@ void PathTracingApplication::createBuffers() {
       rs.plan.rank = r;
       rs.plan.iterations = opt_.maxWaveletIteration;
       rs.plan.exchange = opt_.exchange_halo;
-      rs.plan.ext_flags = opt_.flags & 0x1F0u;
+      rs.plan.ext_flags = opt_.flags & 0x9F0u;
       const Rows st = rs.plan.stored(), own = rs.plan.own();
       cfg.row_begin = static_cast<uint32_t>(st.first);
       cfg.row_end = static_cast<uint32_t>(st.second);
@@ -450,6 +450,15 @@ void PathTracingApplication::applyTemporalFiltering() {
   }
   for (int k = 1; k <= opt_.maxWaveletIteration; k++) {           // :1259
     pushConstants.waveletIteration = k;                           // :1260
+    if (opt_.frames_in_flight == 2 && k == 1 && frameCount > 0 && (opt_.flags & (RTPT_FLAG_EXT_VARIANCE | RTPT_FLAG_EXT_DISOCCLUSION))) {
+      // the moment accumulation (this iteration) and the disocclusion test (the final one) read the previous frame's id and
+      // moment planes, which the other context holds: handed across like the history image (app.py: PipelinedBackend)
+      void *ids = nullptr, *mom = nullptr;
+      check(rtpt_stream_wait(ctx_, last_), "rtpt_stream_wait");
+      check(rtpt_plane_ptr(last_, RTPT_PLANE_PREV_VIS_ID, &ids), "rtpt_plane_ptr");
+      if (opt_.flags & RTPT_FLAG_EXT_VARIANCE) check(rtpt_plane_ptr(last_, RTPT_PLANE_MOMENTS_PREV, &mom), "rtpt_plane_ptr");
+      check(rtpt_set_external_guides(ctx_, ids, mom, 0, opt_.height), "rtpt_set_external_guides");
+    }
     if (opt_.frames_in_flight == 2 && k == opt_.maxWaveletIteration && (k & 1) && frameCount > 0) {
       // the blend reads the previous frame, which the other context finished (or is finishing) on its own stream
       void* prev = nullptr;
@@ -619,7 +628,7 @@ std::string PathTracingApplication::planJson(int frames, const std::vector<std::
   auto rows = [](Rows r) { return "[" + std::to_string(r.first) + ", " + std::to_string(r.second) + "]"; };
   for (int r = 0; r < R; r++) {
     StripPlan p;
-    p.height = H; p.world = R; p.rank = r; p.iterations = N; p.exchange = opt_.exchange_halo;
+    p.height = H; p.world = R; p.rank = r; p.iterations = N; p.exchange = opt_.exchange_halo; p.ext_flags = opt_.flags & 0x9F0u;
     out += std::string(r ? ", " : "") + "{\"own\": " + rows(p.own()) + ", \"stored\": " + rows(p.stored()) + ", \"raytrace\": " +
            rows(p.raytrace_rows()) + ", \"filter\": [";
     for (int k = 1; k <= N; k++) out += std::string(k > 1 ? ", " : "") + rows(p.filter_rows(k));

@@ -25,7 +25,7 @@ int StripPlan::halo() const {
   if (world == 1) return 0;
   int h = 0;
   for (int k = 1; k <= iterations; k++) h = exchange ? std::max(h, reach(k)) : h + reach(k);
-  return h;
+  return exchange ? std::max(h, reach(1) + svgf_pad()) : h + svgf_pad();
 }
 Rows StripPlan::grow(int rows) const {
   const Rows o = own();
@@ -46,7 +46,7 @@ std::vector<StripPlan::Exchange> StripPlan::exchange_rows(int k) const {
   std::vector<Exchange> out;
   if (world == 1 || !exchange) return out;
   const Rows o = own();
-  const int r = reach(k);
+  const int r = reach(k) + (k == 1 ? svgf_pad() : 0);  // iteration 1's variance taps look 3 traced rows further (strips.py)
   auto check = [&](int peer) {
     const Rows p = bounds(height, world, peer);
     if (p.second - p.first < r || o.second - o.first < r)

@@ -38,6 +38,8 @@ struct StripPlan {
     const int stride = (ext_flags & RTPT_FLAG_EXT_POW2_STRIDE) ? (1 << (k - 1)) : k;
     return stride * ((ext_flags & RTPT_FLAG_EXT_GAUSS5) ? 2 : 1);
   }
+  // RTPT_FLAG_EXT_SVGF_VARIANCE (with _EXT_VARIANCE): the 7x7 spatial variance estimate needs 3 more traced rows (strips.py)
+  int svgf_pad() const { return (ext_flags & 0x900u) == 0x900u ? 3 : 0; }
   int halo() const;                     // rows stored beyond the owned strip on each side
   Rows stored() const;
   Rows grow(int rows) const;

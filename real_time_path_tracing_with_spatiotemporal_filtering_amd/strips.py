@@ -36,6 +36,13 @@ class StripPlan:
         stride = (1 << (k - 1)) if (self.ext_flags & 0x40) else k
         return stride * (2 if (self.ext_flags & 0x20) else 1)
 
+    @property
+    def svgf_pad(self) -> int:
+        """RTPT_FLAG_EXT_SVGF_VARIANCE (with _EXT_VARIANCE): a pixel with a short moment history takes its variance from the
+        7x7 neighbourhood of the traced frame, so the traced rows must reach 3 rows beyond every row whose variance
+        iteration 1 reads"""
+        return 3 if (self.ext_flags & 0x900) == 0x900 else 0
+
     def __post_init__(self):
         if self.mode not in ("exchange", "redundant"):
             raise ValueError(f"unknown halo mode {self.mode!r}")
@@ -60,8 +67,8 @@ class StripPlan:
             return 0
         n = self.iterations
         if self.mode == "exchange":
-            return max(self.reach(k) for k in range(1, n + 1))
-        return sum(self.reach(k) for k in range(1, n + 1))
+            return max(max(self.reach(k) for k in range(1, n + 1)), self.reach(1) + self.svgf_pad)
+        return sum(self.reach(k) for k in range(1, n + 1)) + self.svgf_pad
 
     @property
     def stored(self):
@@ -83,7 +90,7 @@ class StripPlan:
     def raytrace_rows(self):
         if self.world == 1 or self.mode == "exchange":
             return self.own
-        return self._grow(sum(self.reach(k) for k in range(1, self.iterations + 1)))
+        return self._grow(sum(self.reach(k) for k in range(1, self.iterations + 1)) + self.svgf_pad)
 
     def filter_rows(self, k: int):
         """rows iteration k must produce on this rank."""
@@ -107,7 +114,7 @@ class StripPlan:
         o0, o1 = self.own
         out = []
         up, down = self.neighbours()
-        r = self.reach(k)
+        r = self.reach(k) + (self.svgf_pad if k == 1 else 0)   # iteration 1's variance taps look 3 traced rows further
         if up is not None:
             u0, u1 = self.bounds(self.height, self.world, up)
             if u1 - u0 < r or o1 - o0 < r:

@@ -47,9 +47,12 @@ def test_chain_equals_separate_passes(hip_lib, size, exact):
 
 @pytest.mark.parametrize("g", [2, 3, 6])
 def test_sliding_window_variant_equals_separate_passes(hip_lib, monkeypatch, g):
-    """RTPT_CHAIN_SW=1: the round-3 sliding-window kernel (a wave owns a residue class of rows and keeps the 3x3 tap
-    window in registers; not the default — measured slower, profiles/r03_chain_sw_ab.csv) computes the same bits, at the
+    """RTPT_CHAIN_SW=1: the round-3 sliding-window kernel (csrc/experiments/: a wave owns a residue class of rows and keeps
+    the 3x3 tap window in registers; measured slower, profiles/r03_chain_sw_ab.csv; only in -DRTPT_AB_VARIANTS=1 builds)
+    computes the same bits, at the
     frame borders (top/bottom clamp events), on ragged strips and for every rows-per-step setting"""
+    if not hasattr(hip_lib.load(), "rtpt_debug_ab_variants"):
+        pytest.skip("the library was built without the A/B variants (scripts/build_variant.sh ab -DRTPT_AB_VARIANTS=1, RTPT_LIB_PATH)")
     monkeypatch.setenv("RTPT_CHAIN_SW", "1")
     monkeypatch.setenv("RTPT_CHAIN_SW_G1", str(g))
     monkeypatch.setenv("RTPT_CHAIN_SW_G3", str(g))

@@ -101,7 +101,8 @@ def test_cpp_host_rccl_transport_single_rank(app_binary, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks,halo,flags", [(3, "exchange", 0xF0), (3, "redundant", 0x1F0), (2, "redundant", 0x180), (3, "exchange", 0x190)])
+@pytest.mark.parametrize("ranks,halo,flags", [(3, "exchange", 0xF0), (3, "redundant", 0x1F0), (2, "redundant", 0x180), (3, "exchange", 0x190),
+                                              (3, "redundant", 0x900), (2, "exchange", 0x900)])
 def test_cpp_host_strips_serve_the_extension_modes(app_binary, hip_lib, tmp_path, ranks, halo, flags):
     """SURVEY 8(f) rank 1 in the product host's strip mode: 5x5 taps / 2^(k-1) stride widen the halo (StripPlan::reach),
     adaptive alpha reads the gradient, and the disocclusion test / moment accumulation read the previous frame's id and
@@ -122,6 +123,27 @@ def test_cpp_host_strips_serve_the_extension_modes(app_binary, hip_lib, tmp_path
     want = app.backend.ctx.readback(hip_lib.PLANE_IMAGE)
     got = read_pfm(pfm)
     assert np.array_equal(bits(got), bits(np.ascontiguousarray(want[..., :3])))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0x180, 0x900])
+def test_cpp_host_two_frames_in_flight_serve_the_guided_extension_modes(app_binary, hip_lib, tmp_path, flags):
+    """--frames-in-flight 2 with the disocclusion test / variance guidance: the previous frame's id and moment planes are
+    handed from the context that ended that frame to the one building the next (rtpt_stream_wait + rtpt_set_external_guides
+    before the first filter iteration) — the serial Python host's frame, bit for bit (exact filter)."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    W, H, SEG, N = 160, 144, 3, 5
+    keys = ["", "E", "J", "QA", "", "E", "D", ""]
+    pfm = tmp_path / "fif.pfm"
+    out = subprocess.run([app_binary, "--width", str(W), "--height", str(H), "--segments", str(SEG), "--iterations", str(N),
+                          "--frames", str(len(keys)), "--script", ",".join(keys), "--dump", str(pfm), "--flags", hex(flags),
+                          "--exact-filter", "--frames-in-flight", "2"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    app = make_app(W, H, max_segments=SEG, iterations=N, flags=flags | hip_lib.FLAG_EXACT_FILTER)
+    for k in keys:
+        app.drawScene(tuple(k))
+    want = app.backend.ctx.readback(hip_lib.PLANE_IMAGE)
+    assert np.array_equal(bits(read_pfm(pfm)), bits(np.ascontiguousarray(want[..., :3])))
 
 
 @pytest.mark.gpu
@@ -194,8 +216,8 @@ def test_cpp_host_present_with_two_frames_in_flight_and_odd_sizes(app_binary, hi
     assert np.fromfile(raw, np.uint8).tobytes() == oracle.present_bgra8(want).tobytes()
 
 
-@pytest.mark.parametrize("halo", ["redundant", "exchange"])
-def test_cpp_strip_plan_and_history_bands_equal_the_python_mirror(app_binary, halo):
+@pytest.mark.parametrize("halo,flags", [("redundant", 0), ("exchange", 0), ("redundant", 0x900), ("exchange", 0x960)])
+def test_cpp_strip_plan_and_history_bands_equal_the_python_mirror(app_binary, halo, flags):
     """host-only (no GPU): `rtpt_app --plan-only` prints the C++ host's strip plan and, per scripted frame, the
     previous-frame rows every rank's final pass can reach (host/strips.cpp); the Python mirror (strips.py), which the gloo
     tests exercise end to end, must produce the same rows — same ownership, same halos, same reprojection bound."""
@@ -207,11 +229,12 @@ def test_cpp_strip_plan_and_history_bands_equal_the_python_mirror(app_binary, ha
     W, H, N, R = 333, 217, 5, 4
     keys = ["", "E", "E", "D", "QS", "", "W"]
     out = subprocess.run([app_binary, "--plan-only", "--width", str(W), "--height", str(H), "--iterations", str(N), "--ranks", str(R),
-                          "--halo", halo, "--frames", str(len(keys)), "--script", ",".join(keys)], capture_output=True, text=True)
+                          "--halo", halo, "--frames", str(len(keys)), "--script", ",".join(keys), "--flags", hex(flags)],
+                         capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     plan = json.loads(out.stdout)
     for r, p in enumerate(plan["ranks"]):
-        sp = StripPlan(H, R, r, N, halo)
+        sp = StripPlan(H, R, r, N, halo, flags)
         assert tuple(p["own"]) == sp.own and tuple(p["stored"]) == sp.stored and tuple(p["raytrace"]) == sp.raytrace_rows()
         assert [tuple(x) for x in p["filter"]] == [sp.filter_rows(k) for k in range(1, N + 1)]
     app = PathTracingApplication(Recorder(), W, H, N)

@@ -651,6 +651,39 @@ def test_two_frames_in_flight_soak(hip_lib):
         assert np.isfinite(outs[0][..., :3]).mean() > 0.999
 
 
+@pytest.mark.parametrize("ext", [0x80, 0x100, 0x180, 0x900, 0x1F0])
+def test_two_frames_in_flight_with_the_guided_extension_modes(hip_lib, ext):
+    """RTPT_FLAG_EXT_DISOCCLUSION / _VARIANCE (/ _SVGF_VARIANCE) read the previous frame's id and moment planes, which with
+    two frames in flight live in the OTHER context: handed across before the first filter iteration (rtpt_stream_wait +
+    rtpt_set_external_guides, app.PipelinedBackend).  40 frames without a host sync, camera and light moving: the serial
+    host's bits (exact filter) — the moment history makes the last frame depend on every earlier one."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    keys = "DDAAEEQQJJLLWS"
+    w, h = 200, 120
+    outs = []
+    for fif in (1, 2):
+        app = make_app(w, h, max_segments=3, iterations=5, flags=hip_lib.FLAG_EXACT_FILTER | ext, frames_in_flight=fif)
+        for f in range(40):
+            app.drawScene((keys[f % len(keys)],) if f % 3 else ())
+        be = app.backend
+        outs.append(be.final_image_rows(0, h) if fif == 2 else be.readback_rows(hip_lib.PLANE_PREVIOUS, 0, h))
+        be.close()
+    assert np.array_equal(bits(outs[0]), bits(outs[1])), hex(ext)
+    assert np.isfinite(outs[0][..., :3]).all()
+
+
+@pytest.mark.parametrize("mode", ["redundant", "exchange"])
+def test_svgf_variance_completion_on_strips(hip_lib, mode):
+    """RTPT_FLAG_EXT_SVGF_VARIANCE (0x900 with the variance flag it completes) on 2-4 strips: the 7x7 spatial estimate of
+    young pixels reads traced rows 3 beyond the rows whose variance an iteration consumes — the strip plans trace (redundant
+    halo) or receive (exchange halo, iteration 1) those rows — and the 3x3 variance prefilter reads one row either side.
+    Camera and light moving (disocclusions keep producing short histories), against the single context, bit for bit."""
+    keys = [(), ("E",), ("J",), ("Q", "A"), (), ("D",)]
+    for R in (2, 3, 4):
+        _strips_vs_single(130, 121, 3, 5, R, mode, 0x900, keys)
+    _strips_vs_single(96, 80, 2, 3, 2, mode, 0x9F0, keys[:4])   # with the tap-shape modes widening the reach
+
+
 def test_resize_keeps_scene_and_restarts_history(hip_lib, oracle, cornell):
     """rtpt_resize (framebuffer resize, main.cpp:275-278/:1310): new planes, same scene; the frames after it equal
     a freshly created context of the new size, whose first final pass has no history (frameNumber is the caller's)."""

@@ -61,6 +61,32 @@ def test_plan_with_extension_reach(ext, mode):
                     assert send[1] - send[0] == recv[1] - recv[0] == reach
 
 
+@pytest.mark.parametrize("ext", [0x900, 0x9F0, 0x960])
+@pytest.mark.parametrize("mode", ["exchange", "redundant"])
+def test_plan_with_the_svgf_variance_estimate(ext, mode):
+    """RTPT_FLAG_EXT_SVGF_VARIANCE: the variance iteration 1 reads at rows (its rows +- reach(1)) may be the 7x7 spatial
+    estimate, which reads traced rows 3 further: those rows must have been traced here (redundant) or arrive with iteration 1's
+    halo (exchange), and they must be stored"""
+    H, R, N = 1080, 4, 5
+    for r in range(R):
+        p = StripPlan(H, R, r, N, mode, ext)
+        assert p.svgf_pad == 3 and StripPlan(H, R, r, N, mode, ext & ~0x100).svgf_pad == 0
+        s0, s1 = p.stored
+        f0, f1 = p.filter_rows(1)
+        need = (max(0, f0 - p.reach(1) - 3), min(H, f1 + p.reach(1) + 3))
+        assert s0 <= need[0] and need[1] <= s1
+        if mode == "redundant":
+            t0, t1 = p.raytrace_rows()
+            assert t0 <= need[0] and need[1] <= t1
+        else:
+            assert p.raytrace_rows() == p.own
+            for _, send, recv in p.exchange_rows(1):
+                assert send[1] - send[0] == recv[1] - recv[0] == p.reach(1) + 3
+            for k in range(2, N + 1):
+                for _, send, recv in p.exchange_rows(k):
+                    assert send[1] - send[0] == p.reach(k)
+
+
 def test_exchange_lists_are_symmetric():
     H, R, N = 240, 4, 5
     plans = [StripPlan(H, R, r, N, "exchange") for r in range(R)]
