@@ -268,6 +268,8 @@ constexpr uint32_t kSentinel = 0xFFFFFFFEu;
 #if RTPT_BVH_COUNT
 constexpr int kCountBuckets = 16;
 __device__ unsigned long long g_bvh_count[kCountBuckets][8];
+// secondary rays by direction octant (bit 0: d.x < 0, bit 1: d.y < 0, bit 2: d.z < 0): {rays, node visits, sum of squares}
+__device__ unsigned long long g_bvh_octant[8][3];
 #define RTPT_COUNT_TRIP(slot)                                                                   \
   do {                                                                                          \
     const unsigned long long m_ = __ballot(1);                                                  \
@@ -323,15 +325,21 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
     }
   }
   struct Flush {
-    uint32_t* w; uint32_t* n; uint32_t* l; int b;
+    uint32_t* w; uint32_t* n; uint32_t* l; int b; int oct;
     __device__ ~Flush() {
+      if (b >= 2) {
+        unsigned long long* q = g_bvh_octant[oct & 7];
+        atomicAdd(&q[0], 1ull);
+        atomicAdd(&q[1], static_cast<unsigned long long>(*n));
+        atomicAdd(&q[2], static_cast<unsigned long long>(*n) * *n);
+      }
       atomicMax(&w[4], *n);
       atomicMax(&w[5], *l);
       const unsigned long long m_ = __ballot(1);
       if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(m_)))
         for (int i = 0; i < 8; i++) atomicAdd(&g_bvh_count[b & (kCountBuckets - 1)][i], static_cast<unsigned long long>(w[i]));
     }
-  } flush_{cnt_w, &my_nodes, &my_leaves, bucket};
+  } flush_{cnt_w, &my_nodes, &my_leaves, bucket, (d.x < 0.0f ? 1 : 0) | (d.y < 0.0f ? 2 : 0) | (d.z < 0.0f ? 4 : 0)};
 #endif
   // A ray with a NaN component cannot hit anything (every comparison of tri_test fails, D7) — but min/max drop
   // NaNs, so every box would "pass" and that one lane would walk all of the scene: on the 1.15M-triangle lattice
@@ -1316,9 +1324,11 @@ extern "C" __attribute__((visibility("default"))) int rtpt_debug_tile_order(cons
 // counting build only: read (and clear) the traversal counters
 extern "C" __attribute__((visibility("default"))) int rtpt_debug_bvh_counters(unsigned long long* out, int clear) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_count), sizeof(unsigned long long) * kCountBuckets * 8) != hipSuccess) return -1;
+  if (out && hipMemcpyFromSymbol(out + kCountBuckets * 8, HIP_SYMBOL(g_bvh_octant), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
   if (clear) {
     static unsigned long long zero[kCountBuckets * 8];
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_count), zero, sizeof zero) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_octant), zero, sizeof(unsigned long long) * 24) != hipSuccess) return -1;
   }
   return 0;
 }

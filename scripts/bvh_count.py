@@ -47,7 +47,7 @@ def main():
                    cameraOrigin=cam, z_far=zfar, lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
     app.drawScene(())  # frame 0 (no history yet)
     app.backend.ctx.sync()
-    buf = (C.c_ulonglong * (16 * 8))()
+    buf = (C.c_ulonglong * (16 * 8 + 24))()
     fn(buf, 1)
     for _ in range(args.frames):
         app.drawScene(())
@@ -82,6 +82,16 @@ def main():
         print(f"{name:12s} {e['rays']:11d} {e['node_visits_per_ray']:9.1f} {e['leaf_tests_per_ray']:8.2f} | "
               f"{e['node']['util']:9.3f} {e['node']['length_cap']:5.3f} {e['node']['phase']:5.3f} | "
               f"{e['leaf']['util']:9.3f} {e['leaf']['length_cap']:5.3f} {e['leaf']['phase']:5.3f} | {e['share_of_trips']:.3f}  fill {e['entry_fill']:.3f}")
+    # secondary rays by direction octant: do rays of some octants walk much further than others (a sort key)?
+    print("octant (x<0, y<0, z<0)   rays      mean node visits   std")
+    res["octants"] = {}
+    for o in range(8):
+        n, s1, s2 = (int(buf[16 * 8 + 3 * o + i]) for i in range(3))
+        if n:
+            mean = s1 / n
+            std = max(0.0, s2 / n - mean * mean) ** 0.5
+            res["octants"][str(o)] = {"rays": n // args.frames, "mean_nodes": mean, "std_nodes": std}
+            print(f"   {o & 1}{(o >> 1) & 1}{(o >> 2) & 1}             {n // args.frames:10d}   {mean:8.1f}          {std:6.1f}")
     if args.out:
         json.dump(res, open(args.out, "w"), indent=1)
 

@@ -12,7 +12,8 @@ for G in \
   "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE" \
   "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES" ; do
   i=$((i+1))
-  timeout -k 10 280 rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT/p$i -- python3 bench.py --workload instanced --steps 6 --warmup 2 --prewarm-seconds 0 --no-cpu-baseline --no-secondary > $OUT/p$i.json 2> $OUT/p$i.err || { echo pass $i failed; tail -3 $OUT/p$i.err; }
+  # RTPT_NO_TRACE_FUSION=1: K0 + K1 and K2 as launches of their own, so that the counters are the traversal's alone
+  RTPT_NO_TRACE_FUSION=1 timeout -k 10 280 rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT/p$i -- python3 bench.py --workload instanced --steps 6 --warmup 2 --prewarm-seconds 0 --no-cpu-baseline --no-secondary > $OUT/p$i.json 2> $OUT/p$i.err || { echo pass $i failed; tail -3 $OUT/p$i.err; }
   echo "pass $i done"
 done
 python3 - $OUT "${COMMIT:-unknown}" <<'PY'
@@ -21,6 +22,8 @@ out, commit = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 dur = collections.defaultdict(lambda: [0.0, 0])
 def short(n):
+    if "k_gbuffer_pathtrace" in n:
+        return "k_gbuffer_pathtrace"
     for k in ("k_pathtrace_queue", "k_pathtrace", "k_gbuffer", "k_atrous"):
         if k in n:
             return k

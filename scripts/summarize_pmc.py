@@ -24,6 +24,8 @@ def short(name):
         # k_atrous_comb_sh<CW, FINAL, EXACT> / k_atrous<FINAL, EXACT>
         m = re.search(r"k_atrous(?:_comb_sh<\d+, |<)(true|false)", name)
         return "k_atrous_final" if (m and m.group(1) == "true") else "k_atrous"
+    if "k_gbuffer_pathtrace" in name:   # K0 + K1 + K2 in one launch (round 4)
+        return "k_gbuffer_pathtrace"
     for k in ("k_pathtrace", "k_gbuffer", "k_gradient", "k_lut", "k_pair_weights"):
         if k in name:
             return k
