@@ -216,8 +216,8 @@ int rtpt_debug_bvh_check(rtpt_ctx* c, uint64_t stats[8]) {
         cb = sub[ref];
       }
       for (int a = 0; a < 3; a++) {
-        const float qlo = g[a] + static_cast<float>(nd.box[rt::bvh_box_lo(side, a)]) * g[3 + a];
-        const float qhi = g[a] + static_cast<float>(nd.box[rt::bvh_box_hi(side, a)]) * g[3 + a];
+        const float qlo = std::fmaf(static_cast<float>(nd.box[rt::bvh_box_lo(side, a)]), g[3 + a], g[a]);  // the decode refit.hip checks against
+        const float qhi = std::fmaf(static_cast<float>(nd.box[rt::bvh_box_hi(side, a)]), g[3 + a], g[a]);  // the decode refit.hip checks against
         if (!(qlo <= cb.mn[a] && qhi >= cb.mx[a])) stats[5]++;
         me.mn[a] = std::min(me.mn[a], cb.mn[a]);
         me.mx[a] = std::max(me.mx[a], cb.mx[a]);
@@ -240,8 +240,8 @@ int rtpt_debug_bvh_check(rtpt_ctx* c, uint64_t stats[8]) {
         if ((side ? q[ni].rref : q[ni].lref) == rt::kBvhEmpty) continue;
         for (int a = 0; a < 3; a++) {
           const float slack = 4.0f * g[3 + a] + 2.0f * pad;
-          const float qlo = g[a] + static_cast<float>(q[ni].box[rt::bvh_box_lo(side, a)]) * g[3 + a];
-          const float qhi = g[a] + static_cast<float>(q[ni].box[rt::bvh_box_hi(side, a)]) * g[3 + a];
+          const float qlo = std::fmaf(static_cast<float>(q[ni].box[rt::bvh_box_lo(side, a)]), g[3 + a], g[a]);  // the decode refit.hip checks against
+          const float qhi = std::fmaf(static_cast<float>(q[ni].box[rt::bvh_box_hi(side, a)]), g[3 + a], g[a]);  // the decode refit.hip checks against
           if (qlo < sc.mn[a] - slack || qhi > sc.mx[a] + slack) stats[6]++;
         }
       }
@@ -329,8 +329,8 @@ static int bvh_check_impl(const float* build_tris, const float* tris, uint32_t n
       for (int a = 0; a < 3; a++) {
         if (!(bmn[a] <= cb.mn[a] && bmx[a] >= cb.mx[a])) stats[5]++;
         // the device box: origin + q * cell, evaluated as the traversal's arithmetic implies (binary32)
-        const float qlo = g.origin[a] + static_cast<float>(q[ni].box[rt::bvh_box_lo(side, a)]) * g.cell[a];
-        const float qhi = g.origin[a] + static_cast<float>(q[ni].box[rt::bvh_box_hi(side, a)]) * g.cell[a];
+        const float qlo = std::fmaf(static_cast<float>(q[ni].box[rt::bvh_box_lo(side, a)]), g.cell[a], g.origin[a]);
+        const float qhi = std::fmaf(static_cast<float>(q[ni].box[rt::bvh_box_hi(side, a)]), g.cell[a], g.origin[a]);
         if (!(qlo <= bmn[a] && qhi >= bmx[a])) stats[6]++;
         me.mn[a] = std::min(me.mn[a], cb.mn[a]);
         me.mx[a] = std::max(me.mx[a], cb.mx[a]);

@@ -330,10 +330,11 @@ BvhGrid pack_quantised_nodes(const Bvh& bvh, std::vector<BvhNodeQ>& out) {
     g.origin[a] = static_cast<float>(lo[a] - static_cast<double>(g.cell[a]));
     cell[a] = g.cell[a];
   }
-  // the decoded face origin + q * cell is formed in binary32 (the traversal's fma has the same operands up to
-  // the common factor 1/d): step until THAT value is on the outer side.  What is left between the two roundings
-  // is a few ulp of the coordinate, two orders of magnitude below the padding of the boxes.
-  auto decode = [&](double q, int a) { return g.origin[a] + static_cast<float>(q) * g.cell[a]; };
+  // the decoded face is ONE binary32 fma, fma(q, cell, origin) — the same expression in the device refit (refit.hip) and in
+  // the checkers (api_selftest.hip): step until THAT value is on the outer side.  The traversal computes
+  // q * (cell / d) + (origin - o) / d instead; what lies between the two is a few ulp of the coordinate, two orders of
+  // magnitude below the padding of the boxes, which is what absorbs it.
+  auto decode = [&](double q, int a) { return std::fmaf(static_cast<float>(q), g.cell[a], g.origin[a]); };
   auto qdown = [&](float x, int a) -> uint16_t {
     double q = std::floor((static_cast<double>(x) - static_cast<double>(g.origin[a])) / cell[a]);
     q = std::min(65535.0, std::max(0.0, q));

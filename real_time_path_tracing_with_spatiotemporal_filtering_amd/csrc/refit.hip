@@ -115,15 +115,18 @@ __global__ void k_refit_quantise(RefitArgs a, uint32_t n_nodes) {
       if (!empty) {
         const float org = a.grid[ax], cell = a.grid[3 + ax];
         const float xlo = mn[ax] - pad, xhi = mx[ax] + pad;
-        // the decoded face org + q * cell is formed in binary32 (the traversal's fma has the same operands up to the
-        // common factor 1/d): step until THAT value is on the outer side
+        // the decoded face is formed as ONE binary32 fma, fma(q, cell, org) — written out so that the device, the host's
+        // rtpt_debug_bvh_check and this loop agree whatever -ffp-contract says: step until THAT value is on the outer side.
+        // The traversal never forms this value: it computes q * (cell / d) + (org - o) / d, which differs from
+        // (fma(q, cell, org) - o) / d by a few ulps of the box coordinate; the 1e-5 x diagonal padding (pad, above) is what
+        // absorbs that difference (round-3 advice: the check alone does not).
         double q = __builtin_floor((static_cast<double>(xlo) - static_cast<double>(org)) / static_cast<double>(cell));
         q = q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q);
-        while (q > 0.0 && org + static_cast<float>(q) * cell > xlo) q -= 1.0;
+        while (q > 0.0 && __builtin_fmaf(static_cast<float>(q), cell, org) > xlo) q -= 1.0;
         qlo = static_cast<uint32_t>(q);
         q = __builtin_ceil((static_cast<double>(xhi) - static_cast<double>(org)) / static_cast<double>(cell));
         q = q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q);
-        while (q < 65535.0 && org + static_cast<float>(q) * cell < xhi) q += 1.0;
+        while (q < 65535.0 && __builtin_fmaf(static_cast<float>(q), cell, org) < xhi) q += 1.0;
         qhi = static_cast<uint32_t>(q);
       }
       nd.box[bvh_box_lo(side, ax)] = static_cast<uint16_t>(qlo);
