@@ -282,8 +282,9 @@ def _cpu_baseline_child(wl, budget_s=12.0):
         return dt, rays
 
     if not banded:
-        # 16 rows x 240 columns = one row's worth of pixels, a row per thread, through the lattice's fourth layer of boxes
-        rows, cols = 16, W // 16
+        # 2 rows per thread x 240 columns (two frame rows' worth of pixels at 16 threads, ~10 s), through the lattice's fourth
+        # layer of boxes
+        rows, cols = 2 * cores, W // 16
         y0, x0 = H // 2 - H // 16, W // 2 - cols // 2
         O.set_columns(x0, x0 + cols)
         dt, rays = band_frame(rows, y0)

@@ -334,6 +334,7 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   if (const char* v = std::getenv("RTPT_NO_TRI_PAIRS")) c->no_pairing = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_HOST_REFIT")) c->host_refit = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_NO_TRACE_FUSION")) c->fuse_trace = std::atoi(v) == 0;
+  if (const char* v = std::getenv("RTPT_TRACE_POOL")) c->trace_pool = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_CHAIN_G1")) c->filter_policy.chain_g_pin = std::atoi(v);
   if (const char* v = std::getenv("RTPT_CHAIN_GENERIC")) c->filter_policy.chain_generic = std::atoi(v);
   if (const char* v = std::getenv("RTPT_CHAIN_WG_PER_CU")) c->filter_policy.chain_wg_per_cu = std::atoi(v);
@@ -367,6 +368,7 @@ int rtpt_destroy(rtpt_ctx* c) {
   for (auto& b : c->vis) free_buf(b);
   free_buf(c->normals);
   free_buf(c->path_queue_count);
+  free_buf(c->path_pool);
   for (auto& b : c->path_queue) free_buf(b);
   for (auto& b : c->moments) free_buf(b);
   for (auto& b : c->variance) free_buf(b);

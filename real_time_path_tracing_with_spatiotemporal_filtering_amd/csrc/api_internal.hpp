@@ -138,6 +138,10 @@ struct rtpt_ctx {
   // recorded K0 (+ K1): rtpt_raytrace right behind them launches all three as one grid (kernels.hip: k_gbuffer_pathtrace);
   // RTPT_NO_TRACE_FUSION=1 (read at rtpt_create) keeps K0 + K1 a launch of their own for A/B runs
   bool fuse_trace = true;
+  // K2 of scenes whose BVH is built over fan pairs as the path-pool kernel (kernels.hip: k_pathtrace_pool): RTPT_TRACE_POOL
+  // (read at rtpt_create); path_pool = the workgroups' slabs, allocated on first use
+  bool trace_pool = false;
+  Buf path_pool;
   rt::FilterPolicy filter_policy;  // RTPT_CHAIN_* (read once, here: rtpt_create)
   // K3 iterations recorded by rtpt_temporal_filter and not launched yet (see filter_flush)
   std::vector<FilterCall> pending;

@@ -848,6 +848,19 @@ bool atrous_final_fuses_present(const AtrousArgs& a) {
   return !a.direct && pair_mode && a.k >= 1 && a.k <= 16;
 }
 
+// Workgroups per XCD of the persistent comb kernel for a list of nlb work items (an XCD takes an eighth of the list and deals
+// it to its workgroups item by item).  Not simply "every slot": with 2 100 items for 2 048 slots — the final pass of a 270-row
+// strip — 52 workgroups would take a second item while the rest idle, and the launch lasts two items instead of one and a
+// bit.  Every workgroup gets the same number of items (+-1): ceil(items / slots) each, on as few workgroups as that takes
+// (round 4: the strip's final pass 22.0 -> see profiles/r04_comb_balance_ab.csv).
+static uint32_t comb_blocks_per_xcd(uint32_t nlb, uint32_t slots_per_xcd) {
+  const uint32_t items_xcd = (nlb + 7u) / 8u;
+  if (slots_per_xcd < 1u) slots_per_xcd = 1u;
+  const uint32_t per_block = (items_xcd + slots_per_xcd - 1u) / slots_per_xcd;  // items a workgroup must take at least
+  const uint32_t blocks = per_block ? (items_xcd + per_block - 1u) / per_block : 1u;
+  return blocks < 1u ? 1u : blocks;
+}
+
 void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
   if (a0.g.y1 <= a0.g.y0) return;
   AtrousArgs a = a0;
@@ -875,8 +888,7 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
       uint32_t per_cu = static_cast<uint32_t>((160u * 1024u) / lds);
       if (per_cu > 32u / kShWaves) per_cu = 32u / kShWaves;
       if (per_cu < 1u) per_cu = 1u;
-      uint32_t per_xcd = static_cast<uint32_t>((n_cu + 7) / 8) * per_cu;
-      if (per_xcd > (nlb + 7) / 8) per_xcd = (nlb + 7) / 8;
+      const uint32_t per_xcd = comb_blocks_per_xcd(nlb, static_cast<uint32_t>((n_cu + 7) / 8) * per_cu);
       const dim3 grid(per_xcd * 8u), sblock(kBlockX, kShWaves);
 #define RTPT_LAUNCH_EXT(CW, RR, VV)                                                                                 \
   do {                                                                                                              \
@@ -948,8 +960,7 @@ void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {
     uint32_t per_cu = static_cast<uint32_t>((160u * 1024u) / lds);
     if (per_cu > 32u / kShWaves) per_cu = 32u / kShWaves;
     if (per_cu < 1u) per_cu = 1u;
-    uint32_t per_xcd = static_cast<uint32_t>((n_cu + 7) / 8) * per_cu;
-    if (per_xcd > (nlb + 7) / 8) per_xcd = (nlb + 7) / 8;
+    const uint32_t per_xcd = comb_blocks_per_xcd(nlb, static_cast<uint32_t>((n_cu + 7) / 8) * per_cu);
     dim3 grid(per_xcd * 8u), sblock(kBlockX, kShWaves);
 #define RTPT_LAUNCH_COMB(CW, NRM)                                                                          \
   do {                                                                                                \

@@ -127,7 +127,9 @@ struct PathtraceArgs {
   int32_t cull;                // 1: bounds[] is valid for the primary segment
   int32_t n_cu;                // compute units of the context's device (persistent queue-kernel grid)
   uint32_t multi_off;          // dword offset of the spp > 1 accumulators in dynamic LDS (set by launch_pathtrace)
-  uint32_t tiles_y;            // rows of 64 x 4 tiles of the traced rows (set by launch_pathtrace; the fused launch's grid is taller)
+  uint32_t tiles_y;            // rows of tiles of the traced rows (set by launch_pathtrace; the fused launch's grid is taller)
+  void* pool_slab;             // path-pool form of the tile kernel (kernels.hip: k_pathtrace_pool): pathtrace_pool_bytes() of
+                               // scratch owned by the context, or NULL
   // long paths (spp == 1, max_segments > 4): a launch covers the segment window [seg_begin, seg_end) and hands the
   // unfinished paths to the next one through a queue of 48-byte records (set by launch_pathtrace)
   uint32_t seg_begin, seg_end;
@@ -276,6 +278,8 @@ void launch_gradient(const GradientArgs& a, hipStream_t s);
 void launch_pathtrace(const PathtraceArgs& a, const GbufferArgs* gb, hipStream_t s);
 bool pathtrace_fuses_gbuffer(const PathtraceArgs& a, const GbufferArgs& g);
 uint32_t pathtrace_grid_blocks(const PathtraceArgs& a, const GbufferArgs* gb);
+bool pathtrace_uses_pool(const PathtraceArgs& a);
+size_t pathtrace_pool_bytes(int W, int rows);
 void launch_atrous(const AtrousArgs& a, bool final_pass, hipStream_t s);
 bool atrous_final_fuses_present(const AtrousArgs& a);
 // `levels` consecutive iterations k, k+1, .. in one launch, intermediates in LDS (atrous_chain.hip): a.k = the first
