@@ -31,11 +31,12 @@ class HipBackend:
     """abi.Context + (optionally) torch-owned colour planes so halo rows can be sent with RCCL."""
 
     def __init__(self, width, height, plan: StripPlan | None = None, max_segments=32, flags=0, device=-1,
-                 torch_planes=False, debug_mask=0):
+                 torch_planes=False, debug_mask=0, samples_per_pixel=1):
         self.plan = plan or StripPlan(height, 1, 0, 1)
         cfg = abi.config_default(width, height)
         cfg.row_begin, cfg.row_end = self.plan.stored
         cfg.max_segments = max_segments
+        cfg.samples_per_pixel = samples_per_pixel   # raytrace.comp.glsl:306 (the reference runs 1)
         cfg.flags = flags
         cfg.device = device
         self.ctx = abi.Context(cfg)
@@ -648,7 +649,7 @@ class PathTracingApplication:
 
 def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode="exchange", flags=0,
              torch_planes=None, debug_mask=0, scene=DEFAULT_SCENE, instance_xforms=None, group=None, mesh=None,
-             frames_in_flight=1, **app_kw):
+             frames_in_flight=1, samples_per_pixel=1, **app_kw):
     """createBuffers + loadMesh + buildAccelerationStructure for one rank.  `mesh` = (xyz, idx) replaces
     the OBJ (synthetic scenes of scenes.py)."""
     plan = StripPlan(height, world, rank, iterations, mode, flags & abi.FLAG_EXT_MASK)
@@ -656,7 +657,7 @@ def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode=
         torch_planes = world > 1  # halo exchange and the history all-gather move rows of torch-owned planes
     def one():
         return HipBackend(width, height, plan, max_segments=max_segments, flags=flags, torch_planes=torch_planes,
-                          debug_mask=debug_mask)
+                          debug_mask=debug_mask, samples_per_pixel=samples_per_pixel)
     if frames_in_flight == 2:
         if world > 1 and flags & (abi.FLAG_EXT_DISOCCLUSION | abi.FLAG_EXT_VARIANCE):
             raise ValueError("two frames in flight on strips cannot serve RTPT_FLAG_EXT_DISOCCLUSION / _VARIANCE yet "

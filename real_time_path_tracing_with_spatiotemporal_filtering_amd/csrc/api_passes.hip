@@ -244,9 +244,9 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
   a.queue_region = 0;
   a.pool_slab = nullptr;
   if (c->trace_pool && c->use_bvh && c->leaf_pairs && a.compact && a.spp == 1) {
-    const size_t need = rt::pathtrace_pool_bytes(static_cast<int>(c->cfg.width), static_cast<int>(c->rows()));
-    if (c->path_pool.bytes < need && (rc = alloc_buf(c->path_pool, need))) return rc;
-    a.pool_slab = c->path_pool.ptr;
+    const size_t need = rt::pathtrace_pool_bytes(static_cast<int>(c->cfg.width), static_cast<int>(c->rows()));  // 0: not built in
+    if (need && c->path_pool.bytes < need && (rc = alloc_buf(c->path_pool, need))) return rc;
+    a.pool_slab = need ? c->path_pool.ptr : nullptr;
   }
   if (a.compact && a.spp == 1 && a.max_segments > rt::pt_first_window(c->use_bvh) && !(c->cfg.flags & RTPT_FLAG_SINGLE_LAUNCH_PATHS)) {
     // a region holds the survivors of ceil(workgroups / kPathQueues) workgroups of 256 paths (kernels.hip); the

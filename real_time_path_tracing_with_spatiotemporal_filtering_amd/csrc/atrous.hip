@@ -848,17 +848,14 @@ bool atrous_final_fuses_present(const AtrousArgs& a) {
   return !a.direct && pair_mode && a.k >= 1 && a.k <= 16;
 }
 
-// Workgroups per XCD of the persistent comb kernel for a list of nlb work items (an XCD takes an eighth of the list and deals
-// it to its workgroups item by item).  Not simply "every slot": with 2 100 items for 2 048 slots — the final pass of a 270-row
-// strip — 52 workgroups would take a second item while the rest idle, and the launch lasts two items instead of one and a
-// bit.  Every workgroup gets the same number of items (+-1): ceil(items / slots) each, on as few workgroups as that takes
-// (round 4: the strip's final pass 22.0 -> see profiles/r04_comb_balance_ab.csv).
+// Workgroups per XCD of the persistent comb kernel: every resident slot, but no more workgroups than work items (an XCD takes an
+// eighth of the list and deals it to its workgroups item by item).  Giving every workgroup the same number of items instead
+// (1 050 workgroups x 2 items rather than 2 048 slots for the 2 100 items of a strip's final pass) was measured in round 4
+// and changes nothing (strip final 22.0 -> 23.1 us, 4K 110.8 -> 106.8, within the spread): the launch is bound by bytes in
+// flight, not by its last items.
 static uint32_t comb_blocks_per_xcd(uint32_t nlb, uint32_t slots_per_xcd) {
   const uint32_t items_xcd = (nlb + 7u) / 8u;
-  if (slots_per_xcd < 1u) slots_per_xcd = 1u;
-  const uint32_t per_block = (items_xcd + slots_per_xcd - 1u) / slots_per_xcd;  // items a workgroup must take at least
-  const uint32_t blocks = per_block ? (items_xcd + per_block - 1u) / per_block : 1u;
-  return blocks < 1u ? 1u : blocks;
+  return slots_per_xcd > items_xcd ? (items_xcd ? items_xcd : 1u) : (slots_per_xcd ? slots_per_xcd : 1u);
 }
 
 void launch_atrous(const AtrousArgs& a0, bool final_pass, hipStream_t s) {

@@ -1219,319 +1219,12 @@ __global__ __launch_bounds__(kPtThreads) void k_pathtrace_queue(PathtraceArgs a)
   if (tid == 0 && block_rays) atomicAdd(a.raycount + (blockIdx.x & (kRayCounters - 1u)), static_cast<unsigned long long>(block_rays));
 }
 
-// ------------------------------------------------------------------------------------------
-// K2 for BVH scenes, path-pool form (round 4).
-//
-// In the tile kernel a lane owns one path and a wave's traversal lasts as long as its longest ray: on the 1.15M-triangle
-// lattice a ray visits 31 +- 7 nodes, so the longest of 64 needs ~1.5x the mean and, with the partly filled last wave of a
-// compacted tile, the lanes are busy for 0.58 of the node loop's trips at best (scripts/bvh_count.py: length_cap).  Here a
-// workgroup owns a 64 x kPoolRows tile (four paths per lane), keeps the paths as 48-byte records in a slab of global memory
-// (L2-resident while the tile is alive) and alternates two phases per segment:
-//   extend  the waves pull rays from the tile's pool as their lanes run out of work — a lane that finishes stores its hit and
-//           takes the next ray at the wave's next refill point (when kPoolRefill lanes are idle), so lanes stay busy until
-//           the pool is empty: persistent-wave traversal with an LDS node stack per lane, nothing but rays in flight;
-//   shade   every lane takes a path, applies raytrace.comp.glsl:226-267 to its hit and, if the path goes on, appends the
-//           record of its next ray to the other half of the slab (compaction by ballot + one LDS atomic per wave).
-// Same rays, same per-path arithmetic and RNG stream as the tile kernel: same image, bit for bit.
-// ------------------------------------------------------------------------------------------
-#ifndef RTPT_POOL_ROWS
-#define RTPT_POOL_ROWS 16
+#ifndef RTPT_AB_VARIANTS
+#define RTPT_AB_VARIANTS 0
 #endif
-#ifndef RTPT_POOL_REFILL
-#define RTPT_POOL_REFILL 16
+#if RTPT_AB_VARIANTS
+#include "experiments/pathtrace_pool.inc"
 #endif
-constexpr int kPoolRows = RTPT_POOL_ROWS;
-constexpr int kPoolPaths = kBlockX * kPoolRows;
-constexpr int kPoolRefill = RTPT_POOL_REFILL;  // idle lanes of a wave that trigger a refill
-
-// the extend phase of one workgroup: rays rec[3 i] = (pix, rng, o.x, o.y), rec[3 i + 1] = (o.z, d), i < n; hits[i] = (id + 1 as
-// bits, -u, v, |d.n|) (HitRec).  Pairs only (the lattice, and every scene made of fan-triangulated quads).
-__device__ __forceinline__ void extend_pool(const SceneView& sc, const float4* rec, float4* hits, uint32_t n, uint32_t* next, uint32_t* stack,
-                                            int tid, int nt, float tmax) {
-  const uint32_t lane = static_cast<uint32_t>(tid) & 63u;
-  using cflt = const __attribute__((address_space(4))) float;
-  cflt* gr = (cflt*)sc.bvh_grid;
-  const int lds_levels = static_cast<int>(sc.stack_lds);
-  const size_t spill_stride = static_cast<size_t>(gridDim.x) * gridDim.y * nt;
-  uint32_t* const spill = sc.stack_spill + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * nt + tid;
-  using lds_u32 = __attribute__((address_space(3))) uint32_t;
-  lds_u32* const stack_lds = (lds_u32*)stack;
-  f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, 1.f}, inv{0.f, 0.f, 0.f}, oi{0.f, 0.f, 0.f};
-  uint32_t rx = 0, ry = 0, rz = 0;
-  HitRec h{tmax, 0u, 0.f, 0.f, 1.f};
-  int sp = 0;
-  uint32_t cur = kSentinel, my = 0;
-  bool has = false;        // this lane holds a ray whose hit is not stored yet
-  bool exhausted = false;  // wave-uniform: the pool has no rays left
-  auto push = [&](uint32_t v) {
-    if (sp < lds_levels)
-      stack_lds[sp * nt + tid] = v;
-    else
-      spill[static_cast<size_t>(sp - lds_levels) * spill_stride] = v;
-    sp++;
-  };
-  auto pop = [&]() -> uint32_t {
-    if (sp > 0) {
-      sp--;
-      uint32_t v = stack_lds[(sp < lds_levels ? sp : 0) * nt + tid];
-      if (__builtin_expect(sp >= lds_levels, 0)) v = spill[static_cast<size_t>(sp - lds_levels) * spill_stride];
-      return v;
-    }
-    return kSentinel;
-  };
-  // (the trip bound is a guard for the box this runs on, not part of the algorithm: every path of the loop makes progress —
-  // a refill consumes pool indices, a node step descends or pops, a leaf test pops — and a wave needs a few hundred trips)
-  for (uint32_t guard = 0; guard < (1u << 22); guard++) {
-    // ---- refill point: lanes without work store their hit and take the next rays of the pool
-    const unsigned long long idle = __ballot(cur == kSentinel);
-    const int n_idle = __builtin_popcountll(idle);
-    if (n_idle == 64 || (!exhausted && n_idle >= kPoolRefill)) {
-      if (cur == kSentinel && has) {
-        hits[my] = make_float4(u2f(h.id1), h.u, h.v, h.ad);
-        has = false;
-      }
-      if (!exhausted) {
-        const uint32_t first = static_cast<uint32_t>(__builtin_ctzll(idle));
-        uint32_t base = 0;
-        if (lane == first) base = atomicAdd(next, static_cast<uint32_t>(n_idle));
-        base = __builtin_amdgcn_readlane(base, first);
-        exhausted = base + static_cast<uint32_t>(n_idle) >= n;
-        if (cur == kSentinel) {
-          const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
-          if (idx < n) {
-            const float4 q0 = rec[3 * static_cast<size_t>(idx)], q1 = rec[3 * static_cast<size_t>(idx) + 1];
-            o = f3{q0.z, q0.w, q1.x};
-            d = f3{q1.y, q1.z, q1.w};
-            h = HitRec{tmax, 0u, 0.f, 0.f, 1.f};
-            my = idx;
-            has = true;
-            sp = 0;
-            // a ray with a NaN component hits nothing (closest_hit_bvh): its empty hit is stored at the next refill point
-            if (!(__builtin_isunordered(o.x, d.x) || __builtin_isunordered(o.y, d.y) || __builtin_isunordered(o.z, d.z))) {
-              auto nz = [](float v) { return __builtin_fabsf(v) < 1e-20f ? __builtin_copysignf(1e-20f, v) : v; };
-              const f3 rd{fast::rcp_(nz(d.x)), fast::rcp_(nz(d.y)), fast::rcp_(nz(d.z))};
-              inv = f3{gr[3] * rd.x, gr[4] * rd.y, gr[5] * rd.z};
-              oi = f3{(gr[0] - o.x) * rd.x, (gr[1] - o.y) * rd.y, (gr[2] - o.z) * rd.z};
-              rx = rd.x < 0.0f ? 16u : 0u;
-              ry = rd.y < 0.0f ? 16u : 0u;
-              rz = rd.z < 0.0f ? 16u : 0u;
-              cur = 0;  // root pair
-            }
-          }
-        }
-      }
-      if (__ballot(cur != kSentinel) == 0ull) {  // nobody has work
-        if (has) {  // rays that ended at once (NaN)
-          hits[my] = make_float4(u2f(h.id1), h.u, h.v, h.ad);
-          has = false;
-        }
-        if (exhausted) break;
-        continue;
-      }
-    }
-    // ---- node phase (closest_hit_bvh's, with its early hand-over to the leaf phase)
-    while (true) {
-      const bool walk = !(cur & kLeafBit);
-      const unsigned long long mw = __ballot(walk);
-      if (!mw) break;
-      const unsigned long long ml = __ballot((cur & kLeafBit) && cur != kSentinel);
-      if (__builtin_popcountll(ml) >= RTPT_BVH_LEAF_RATIO * __builtin_popcountll(mw) && ml) break;
-      if (walk) {
-        const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(sc.nodes) + (cur << 5));
-        const uint4 a = np[0], b = np[1];
-        const uint32_t cl = b.z, cr = b.w;
-        const float tb = h.t;
-        auto near_far = [&](uint32_t w, uint32_t rot_, float inv_, float oi_, float& tn_, float& tf_) {
-          const uint32_t q = __builtin_amdgcn_alignbit(w, w, rot_);
-          tn_ = fmaf_(static_cast<float>(q & 0xFFFFu), inv_, oi_);
-          tf_ = fmaf_(static_cast<float>(q >> 16), inv_, oi_);
-        };
-        float n0, n1, n2, f0, f1, f2;
-        near_far(a.x, rx, inv.x, oi.x, n0, f0);
-        near_far(a.y, ry, inv.y, oi.y, n1, f1);
-        near_far(a.z, rz, inv.z, oi.z, n2, f2);
-        const float tl = __builtin_fmaxf(__builtin_fmaxf(n0, n1), __builtin_fmaxf(n2, 0.0f));
-        const bool sl = tl <= __builtin_fminf(__builtin_fminf(f0, f1), __builtin_fminf(f2, tb));
-        near_far(a.w, rx, inv.x, oi.x, n0, f0);
-        near_far(b.x, ry, inv.y, oi.y, n1, f1);
-        near_far(b.y, rz, inv.z, oi.z, n2, f2);
-        const float tr = __builtin_fmaxf(__builtin_fmaxf(n0, n1), __builtin_fmaxf(n2, 0.0f));
-        const bool sr = tr <= __builtin_fminf(__builtin_fminf(f0, f1), __builtin_fminf(f2, tb));
-        const bool hl = sl & (cl != kBvhEmpty), hr = sr & (cr != kBvhEmpty);
-        if (hl && hr) {
-          const bool left_first = tl <= tr;
-          push(left_first ? cr : cl);
-          cur = left_first ? cl : cr;
-        } else if (hl) {
-          cur = cl;
-        } else if (hr) {
-          cur = cr;
-        } else {
-          cur = pop();
-        }
-      }
-    }
-    // ---- leaf phase
-    if ((cur & kLeafBit) && cur != kSentinel) {
-      const uint32_t first = (cur & ~kLeafBit) >> 2, cnt = (cur & 3u) + 1u;
-      for (uint32_t j = 0; j < cnt; j += 2) {
-        const float4* r = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(sc.isect_leaf) + ((first + j) >> 1) * 80u);
-        const float4 p0 = r[0], p1 = r[1], p2 = r[2], p3 = r[3], p4 = r[4];
-        tri_pair_test_leaf(o, d, p0, p1, p2, f3{p3.x, p3.y, p3.z}, f3{p3.w, p4.x, p4.y}, f2u(p4.z) + 1, f2u(p4.w) + 1, h);
-      }
-      cur = pop();
-    }
-  }
-}
-
-template <bool GB>
-__global__ __launch_bounds__(kPtThreads)
-#if RTPT_PT_BVH_WAVES
-__attribute__((amdgpu_waves_per_eu(RTPT_PT_BVH_WAVES, RTPT_PT_BVH_WAVES)))
-#endif
-void k_pathtrace_pool(PathtraceArgs a, GbufferArgs g) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t stack[];
-  if (GB && blockIdx.y >= a.tiles_y) {  // the G-buffer's tiles behind the tracing ones (k_gbuffer_pathtrace)
-    gbuffer_tile<2>(g, blockIdx.x, blockIdx.y - a.tiles_y, stack, a.image, a.g.y0, a.g.y1);
-    return;
-  }
-  __shared__ uint32_t s_next, s_count;
-  __shared__ unsigned int block_rays;
-  __shared__ uint32_t wave_cnt[kPtRows];
-  __shared__ uint32_t q_base;
-  const int tid = threadIdx.y * kBlockX + threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
-  const uint32_t lane = threadIdx.x;
-  if (tid == 0) {
-    block_rays = 0;
-    s_count = 0;
-  }
-  // tiles column by column from the middle of the frame outwards, as in pathtrace_tile
-  const uint32_t tiles_y_ = GB ? a.tiles_y : gridDim.y;
-  const uint32_t lin_ = blockIdx.y * gridDim.x + blockIdx.x, col_ = lin_ / tiles_y_;
-  const uint32_t bx_ = (col_ & 1u) ? (gridDim.x - 1u) / 2u + (col_ + 1u) / 2u : (gridDim.x - 1u) / 2u - col_ / 2u, by_ = lin_ % tiles_y_;
-  const int tile_x0 = static_cast<int>(bx_) * kBlockX, tile_y0 = a.g.y0 + static_cast<int>(by_) * kPoolRows;
-  const float fw = static_cast<float>(a.g.W), fh = static_cast<float>(a.g.H);
-  const f3 light_c = ld3(a.light_c);
-  // this workgroup's slab: two record buffers (3 float4 per path) and the hits
-  float4* const slab = reinterpret_cast<float4*>(a.pool_slab) + static_cast<size_t>(lin_) * (7u * kPoolPaths);
-  float4* recs[2] = {slab, slab + 3 * kPoolPaths};
-  float4* const hits = slab + 6 * kPoolPaths;
-  unsigned int rays = 0;
-  __syncthreads();
-  // ---- primary rays (raytrace.comp.glsl:297-320) of the tile's pixels, in pixel order
-#pragma unroll 1
-  for (int r = 0; r < kPoolRows / kPtRows; r++) {
-    const int px = tile_x0 + static_cast<int>(lane), py = tile_y0 + r * kPtRows + wave;
-    const bool valid = px < a.g.W && py < a.g.y1;
-    f3 o = ld3(a.cam), d{0.f, 0.f, -1.f};
-    uint32_t rng = 0;
-    if (valid) {
-      rng = exact::rng_seed(static_cast<uint32_t>(px), static_cast<uint32_t>(py), a.frame, a.batch);  // :297
-      float u1 = glsl_max(1e-38f, exact::rng_next(rng));  // :87 Box-Muller
-      float u2 = exact::rng_next(rng);
-      float rad = exact::sqrt_(-2.0f * exact::log_(u1));
-      float sn, cs;
-      exact::sincos2pi(u2, sn, cs);
-      float cx = fmaf_(a.jitter, rad * cs, static_cast<float>(px) + 0.5f);  // :314
-      float cy = fmaf_(a.jitter, rad * sn, static_cast<float>(py) + 0.5f);
-      float ux = RTPT_DIV_SH(fmaf_(2.0f, cx, -fw), fh);     // :315
-      float uy = -RTPT_DIV_SH(fmaf_(2.0f, cy, -fh), fh);  // :316
-      d = exact::normalize(f3{a.slope * ux, a.slope * uy, -1.0f});  // :319-320
-    }
-    const unsigned long long m = __ballot(valid);
-    uint32_t wbase = 0;
-    if (lane == 0 && m) wbase = atomicAdd(&s_count, static_cast<uint32_t>(__builtin_popcountll(m)));
-    wbase = __builtin_amdgcn_readfirstlane(wbase);
-    if (valid) {
-      const uint32_t slot = wbase + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-      float4* q = recs[0] + 3 * static_cast<size_t>(slot);
-      const uint32_t pixg = (static_cast<uint32_t>(py) << 16) | static_cast<uint32_t>(px);
-      q[0] = make_float4(u2f(pixg), u2f(rng), o.x, o.y);
-      q[1] = make_float4(o.z, d.x, d.y, d.z);
-      q[2] = make_float4(1.f, 1.f, 1.f, 0.f);  // :201
-    }
-  }
-  __syncthreads();
-  uint32_t n = s_count;
-  int cb = 0;
-  for (uint32_t seg = 0; seg < a.seg_end && n; seg++) {
-    if (tid == 0) {
-      s_next = 0;
-      s_count = 0;
-    }
-    __syncthreads();  // also: the records of this segment are written
-    extend_pool(a.scene, recs[cb], hits, n, &s_next, stack, tid, kPtThreads, a.tmax);
-    __syncthreads();  // every hit is stored
-    // ---- shade: a path per lane
-#pragma unroll 1
-    for (uint32_t base = 0; base < n; base += kPtThreads) {
-      const uint32_t i = base + static_cast<uint32_t>(tid);
-      bool alive = false;
-      uint32_t pixg = 0, rng = 0;
-      f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, -1.f}, acc{1.f, 1.f, 1.f};
-      if (i < n) {
-        const float4* q = recs[cb] + 3 * static_cast<size_t>(i);
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2], hv = hits[i];
-        pixg = f2u(q0.x);
-        rng = f2u(q0.y);
-        o = f3{q0.z, q0.w, q1.x};
-        d = f3{q1.y, q1.z, q1.w};
-        acc = f3{q2.x, q2.y, q2.z};
-        HitRec h{a.tmax, f2u(hv.x), hv.y, hv.z, hv.w};
-        const int x = static_cast<int>(pixg & 0xFFFFu), y = static_cast<int>(pixg >> 16);
-        if (y >= a.count_y0 && y < a.count_y1) rays++;
-        const size_t gi = static_cast<size_t>(y - a.g.row_base) * a.g.W + x;
-        if (seg == 0 && a.hit_id) a.hit_id[gi] = h.id1;
-        if (shade_segment(a, h, seg, light_c, o, d, acc, rng)) {
-          if (GB)
-            store_rgb(a.image + gi, acc);
-          else
-            a.image[gi] = make_float4(acc.x, acc.y, acc.z, a.depth[gi]);  // :328,:343 (+ depth in alpha)
-        } else {
-          alive = true;
-        }
-      }
-      const unsigned long long m = __ballot(alive);
-      uint32_t wbase = 0;
-      if (lane == 0 && m) wbase = atomicAdd(&s_count, static_cast<uint32_t>(__builtin_popcountll(m)));
-      wbase = __builtin_amdgcn_readfirstlane(wbase);
-      if (alive) {
-        const uint32_t slot = wbase + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-        float4* q = recs[cb ^ 1] + 3 * static_cast<size_t>(slot);
-        q[0] = make_float4(u2f(pixg), u2f(rng), o.x, o.y);
-        q[1] = make_float4(o.z, d.x, d.y, d.z);
-        q[2] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-      }
-    }
-    __syncthreads();
-    n = s_count;
-    cb ^= 1;
-  }
-  if (a.seg_end < a.max_segments) {  // the unfinished paths continue in a queue kernel (k_pathtrace_queue)
-#pragma unroll 1
-    for (uint32_t base = 0; base < n; base += kPtThreads) {
-      const uint32_t i = base + static_cast<uint32_t>(tid);
-      const bool alive = i < n;
-      uint32_t pixg = 0, rng = 0;
-      f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, -1.f}, acc{1.f, 1.f, 1.f};
-      if (alive) {
-        const float4* q = recs[cb] + 3 * static_cast<size_t>(i);
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-        pixg = f2u(q0.x);
-        rng = f2u(q0.y);
-        o = f3{q0.z, q0.w, q1.x};
-        d = f3{q1.y, q1.z, q1.w};
-        acc = f3{q2.x, q2.y, q2.z};
-      }
-      enqueue_paths(a, lin_ % kPathQueues, wave_cnt, &q_base, alive, wave, lane, pixg, rng, o, d, acc);
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
-  if ((tid & 63) == 0 && rays) atomicAdd(&block_rays, rays);
-  __syncthreads();
-  if (tid == 0 && block_rays) atomicAdd(a.raycount + (lin_ & (kRayCounters - 1u)), static_cast<unsigned long long>(block_rays));
-}
 
 // ------------------------------------------------------------------------------------------
 __global__ void k_selftest_math(int op, const float* in, float* out, size_t n) {
@@ -1681,13 +1374,20 @@ bool pathtrace_fuses_gbuffer(const PathtraceArgs& a, const GbufferArgs& g) {
   // workgroup shapes must agree (they share the launch)
   return a.compact && a.spp >= 1 && g.g.y0 <= a.g.y0 && g.g.y1 >= a.g.y1 && a.g.y1 > a.g.y0 && kPtRows == kBlockY;
 }
-// the path-pool form of the tile kernel serves scenes whose BVH is built over fan pairs, one sample per pixel
+// the path-pool form of the tile kernel (experiments/pathtrace_pool.inc, -DRTPT_AB_VARIANTS=1 builds only) serves scenes whose
+// BVH is built over fan pairs, one sample per pixel
+#if RTPT_AB_VARIANTS
 bool pathtrace_uses_pool(const PathtraceArgs& a) {
   return a.pool_slab && a.scene.use_bvh && a.scene.leaf_pairs && a.compact && a.spp == 1;
 }
 size_t pathtrace_pool_bytes(int W, int rows) {  // slabs of the tracing workgroups of a launch over `rows` rows
   return static_cast<size_t>((W + kBlockX - 1) / kBlockX) * ((rows + kPoolRows - 1) / kPoolRows) * (7u * kPoolPaths * sizeof(float4));
 }
+#else
+constexpr int kPoolRows = kPtRows;
+bool pathtrace_uses_pool(const PathtraceArgs&) { return false; }
+size_t pathtrace_pool_bytes(int, int) { return 0; }
+#endif
 uint32_t pathtrace_grid_blocks(const PathtraceArgs& a, const GbufferArgs* gb) {
   const uint32_t gx = (a.g.W + kBlockX - 1) / kBlockX;
   const int tr = pathtrace_uses_pool(a) ? kPoolRows : kPtRows;
@@ -1717,12 +1417,15 @@ void launch_pathtrace(const PathtraceArgs& a, const GbufferArgs* gb, hipStream_t
   b.q_out = split ? a.queue[0] : nullptr;
   b.q_out_count = split ? a.queue_count : nullptr;
   if (split) (void)hipMemsetAsync(a.queue_count, 0, 2 * kPathQueues * sizeof(uint32_t), s);
+#if RTPT_AB_VARIANTS
   if (pool) {
     if (gb)
       hipLaunchKernelGGL((k_pathtrace_pool<true>), grid, block, dyn, s, b, *gb);
     else
       hipLaunchKernelGGL((k_pathtrace_pool<false>), grid, block, dyn, s, b, GbufferArgs{});
-  } else if (gb) {
+  } else
+#endif
+  if (gb) {
     if (a.scene.use_bvh && a.scene.leaf_pairs)
       hipLaunchKernelGGL((k_gbuffer_pathtrace<2>), grid, block, dyn, s, b, *gb);
     else if (a.scene.use_bvh)

@@ -155,6 +155,45 @@ def test_gbuffer_gradient_fusion_and_observation(hip_lib):
     assert (outs[0][-1][..., 0] > 0).any(), "the light / camera moves did produce a gradient"
 
 
+@pytest.mark.parametrize("flags", [0, 2])        # brute force / forced BVH
+@pytest.mark.parametrize("spp", [1, 4])
+def test_gbuffer_gradient_raytrace_in_one_launch_equals_three(hip_lib, monkeypatch, flags, spp):
+    """rtpt_gbuffer and rtpt_temporal_gradient stay recorded until rtpt_raytrace arrives (main.cpp:1105-1107 is that order) and
+    then run in ITS launch, the G-buffer's tiles dispatched behind the tracing tiles (kernels.hip: k_gbuffer_pathtrace): the
+    traced image (alpha = the G-buffer depth, written by the G-buffer workgroups while the tracing ones store 12 bytes), every
+    G-buffer plane, the gradient and the ray count equal the three separate launches (RTPT_NO_TRACE_FUSION=1), bit for bit —
+    whole frames and a row range whose G-buffer rows exceed the traced ones (the strips' exchange mode)."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    planes = (hip_lib.PLANE_IMAGE, hip_lib.PLANE_VIS_ID, hip_lib.PLANE_WORLDPOS, hip_lib.PLANE_DEPTH, hip_lib.PLANE_GRADIENT)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setenv("RTPT_NO_TRACE_FUSION", "0" if fused else "1")
+        res = []
+        for (w, h, rank, world) in ((200, 90, 0, 1), (130, 97, 1, 3)):
+            app = make_app(w, h, max_segments=3, iterations=1, flags=flags, rank=rank, world=world, mode="exchange", torch_planes=False,
+                           samples_per_pixel=spp)
+            ctx = app.backend.ctx
+            ctx.timing_enable(1)
+            for f in range(3):
+                app.updateScene(("J",) if f == 1 else (("D",) if f == 2 else ()))
+                app.drawVisbilityBuffer()
+                app.computeTemporalGradient()
+                app.drawSceneToImage()
+                res += [ctx.readback(p) for p in planes]
+                if world == 1:   # (a lone rank of three has nobody to swap halo rows with: K0-K2 are what is under test)
+                    app.applyTemporalFiltering()
+                ctx.end_frame()
+                app.frameCount += 1
+            tm = ctx.timing_collect()
+            assert (tm["k_gbuffer_pathtrace"][1], tm["k_pathtrace"][1], tm["k_gbuffer_gradient"][1]) == ((3, 0, 0) if fused else (0, 3, 3)), tm
+            res.append(ctx.raycount())
+            app.backend.close()
+        outs.append(res)
+    for a, b in zip(*outs):
+        assert np.array_equal(bits(a), bits(b)) if isinstance(a, np.ndarray) else a == b
+    assert outs[0][0][..., 3].any(), "the traced image carries the depth in its alpha"
+
+
 def test_observation_between_iterations_sees_the_separate_pass_state(hip_lib, oracle, cornell):
     """rtpt_temporal_filter records; a readback between iterations must show exactly what the separate dispatches leave
     (main.cpp:1264-1281: odd k writes filteredImageBuffer, even k writes image), and the frame must still finish right"""
