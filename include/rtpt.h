@@ -281,9 +281,14 @@ int rtpt_scene_set_materials(rtpt_ctx* ctx, const uint32_t* tri_material, uint32
 int rtpt_gbuffer(rtpt_ctx* ctx, const rtpt_ubo* ubo, uint32_t y0, uint32_t y1);
 /* computeTemporalGradient (main.cpp:1201-1220; temporalGradient.comp.glsl:104-172).  Called right behind rtpt_gbuffer
  * (the reference's order, main.cpp:1105-1106) for rows that call covered, the two run as ONE launch: rtpt_gbuffer records
- * its dispatch, and every entry point other than this one launches it first, alone. */
+ * its dispatch, and every entry point other than this one launches it first, alone.  Since ABI version 4 the pair stays
+ * recorded until rtpt_raytrace (below). */
 int rtpt_temporal_gradient(rtpt_ctx* ctx, const rtpt_push_constants* pc, uint32_t y0, uint32_t y1);
-/* drawSceneToImage (main.cpp:1222-1253; raytrace.comp.glsl:273-344) */
+/* drawSceneToImage (main.cpp:1222-1253; raytrace.comp.glsl:273-344).  Called right behind rtpt_gbuffer +
+ * rtpt_temporal_gradient (main.cpp:1105-1107) whose rows contain [y0, y1), the three run as ONE launch (the G-buffer's
+ * workgroups are dispatched behind the tracing ones and fill the trace's tail): any other entry point in between launches the
+ * recorded passes first, so the planes always hold what the separate dispatches leave there.  RTPT_FLAG_NO_FILTER_FUSION (or
+ * RTPT_NO_TRACE_FUSION=1 in rtpt_create's environment) keeps the launches apart. */
 int rtpt_raytrace(rtpt_ctx* ctx, const rtpt_push_constants* pc, uint32_t y0, uint32_t y1);
 /* one iteration of applyTemporalFiltering's loop body (main.cpp:1259-1305;
  * temporalFiltering.comp.glsl:191-265).  The host loops k = 1..maxWaveletIteration exactly
