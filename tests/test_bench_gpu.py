@@ -40,6 +40,22 @@ def test_single_rank_line(hip_lib):
     assert d["value"] > 1000 and d["rays_per_frame"] > 1920 * 1080
 
 
+def test_default_line_carries_the_stress_configuration_and_both_cpu_baselines(hip_lib):
+    """`python bench.py` as the driver runs it (short): the headline is BASELINE configs[2]; `also` carries configs[1] and —
+    round 4 — configs[4] (1,152,000 triangles) with per-kernel times, the traversal's committed PMC figures and a CPU baseline
+    of its own from a bounded pixel sample; `cpu_baseline` of the headline is still there; K0 + K1 + K2 are one kernel."""
+    d = _run([sys.executable, "bench.py", "--steps", "16", "--warmup", "2"])
+    assert REQUIRED | {"cpu_baseline", "also"} <= set(d) and d["config"]["workload"].startswith("cornell-4k")
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 1 and d["cpu_baseline"]["cores"] >= 1
+    assert "k_gbuffer_pathtrace" in d["kernels"] and "k_pathtrace" not in d["kernels"]
+    inst = d["also"]["instanced-4k-1spp-8seg-5atrous"]
+    assert inst["triangles"] == 1152000 and inst["max_segments"] == 8 and 0.5 < inst["ms_per_step"] < 50
+    assert inst["kernels"]["k_gbuffer_pathtrace"]["avg_us"] > 100 and inst["traversal"]["committed_measurement"]
+    cb = inst["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "Mray/s" and 0 < cb["value"] < 1 and "brute force" in cb["sample"]
+    assert "cornell-1080p-1spp-4seg-5atrous" in d["also"]
+
+
 @pytest.mark.parametrize("halo", ["redundant", "exchange"])
 def test_two_rank_rehearsal_counts_the_same_rays(hip_lib, halo):
     one = _run([sys.executable, "bench.py", "--workload", "1080p", "--steps", "6", "--warmup", "1", "--no-cpu-baseline",
