@@ -258,54 +258,22 @@ constexpr uint32_t kSentinel = 0xFFFFFFFEu;
 #define RTPT_LEAF_BATCH 2  // 1: 3.72 ms, 2: 3.65 ms, 4: 4.79 ms (registers) on the 1.15M-triangle trace
 #endif
 
-// Counting build (-DRTPT_BVH_COUNT=1, scripts/bvh_count.py; never the shipped library): where the traversal's idle lanes are.
-// Per call of closest_hit_bvh and wave: trips of the node loop / of the leaf loop, the lanes active in each trip, and the
-// longest lane's trips — summed per bucket (0 = K0's primary rays, 1 + s = path segment s) into g_bvh_count[bucket][8]:
-//   {node trips, node lane-trips, leaf trips, leaf lane-trips, max node trips of a lane, max leaf trips of a lane, calls, lanes}
+// Profiling builds (never the shipped library): -DRTPT_BVH_COUNT=1 counts the trips and active lanes of the traversal's loops
+// (scripts/bvh_count.py), -DRTPT_TILE_TIMELINE=1 records when every K0 / K2 workgroup starts and ends (scripts/tile_timeline.py).
+// Their definitions live in experiments/trace_instrumentation.inc; what remains here are the hooks.
 #ifndef RTPT_BVH_COUNT
 #define RTPT_BVH_COUNT 0
 #endif
-#if RTPT_BVH_COUNT
-constexpr int kCountBuckets = 16;
-__device__ unsigned long long g_bvh_count[kCountBuckets][8];
-// secondary rays by direction octant (bit 0: d.x < 0, bit 1: d.y < 0, bit 2: d.z < 0): {rays, node visits, sum of squares}
-__device__ unsigned long long g_bvh_octant[8][3];
-#define RTPT_COUNT_TRIP(slot)                                                                   \
-  do {                                                                                          \
-    const unsigned long long m_ = __ballot(1);                                                  \
-    if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(m_))) {                    \
-      cnt_w[slot] += 1u;                                                                        \
-      cnt_w[slot + 1] += static_cast<uint32_t>(__builtin_popcountll(m_));                       \
-    }                                                                                           \
-  } while (0)
-#else
-#define RTPT_COUNT_TRIP(slot) do {} while (0)
-#endif
-
-// Timeline build (-DRTPT_TILE_TIMELINE=1, scripts/tile_timeline.py; never the shipped library): start and end of every
-// workgroup of the last launch of a kernel on the 100 MHz wall clock, and where it ran (HW_ID, XCC_ID).
 #ifndef RTPT_TILE_TIMELINE
 #define RTPT_TILE_TIMELINE 0
 #endif
-#if RTPT_TILE_TIMELINE
-constexpr uint32_t kTimelineMax = 1u << 16;
-__device__ unsigned long long g_timeline[2][kTimelineMax][3];  // [kernel: 0 K0, 1 K2][workgroup]{start, end, hw}
-__device__ uint32_t g_tile_order[kTimelineMax];  // experiment: K2 workgroup b takes tile g_tile_order[b] (by * gx + bx); see rtpt_debug_tile_order
-__device__ uint32_t g_tile_order_n;              // 0: the built-in order
-struct TimelineScope {
-  unsigned long long t0;
-  uint32_t k, b;
-  __device__ TimelineScope(uint32_t kernel, uint32_t block) : t0(wall_clock64()), k(kernel), b(block) {}
-  __device__ ~TimelineScope() {
-    __syncthreads();
-    if (threadIdx.x == 0 && threadIdx.y == 0 && b < kTimelineMax) {
-      g_timeline[k][b][0] = t0;
-      g_timeline[k][b][1] = wall_clock64();
-      g_timeline[k][b][2] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11))) << 32) |
-                            __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-    }
-  }
-};
+#if RTPT_BVH_COUNT || RTPT_TILE_TIMELINE
+#define RTPT_INSTR_DEVICE
+#include "experiments/trace_instrumentation.inc"
+#undef RTPT_INSTR_DEVICE
+#endif
+#if !RTPT_BVH_COUNT
+#define RTPT_COUNT_TRIP(slot) do {} while (0)
 #endif
 
 template <bool PAIRS>  // the tree was built over fan pairs (bvh.hpp): a leaf is one or two of them (A, B, A, B)
@@ -313,33 +281,7 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
                                                int tid, int nt = kThreads, int bucket = 0) {
   if (__builtin_isunordered(o.x, d.x) || __builtin_isunordered(o.y, d.y) || __builtin_isunordered(o.z, d.z)) return;  // see below
 #if RTPT_BVH_COUNT
-  __shared__ uint32_t cnt_all[16][8];
-  uint32_t* const cnt_w = cnt_all[(tid >> 6) & 15];
-  uint32_t my_nodes = 0, my_leaves = 0;
-  {
-    const unsigned long long m_ = __ballot(1);
-    if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(m_))) {
-      for (int i = 0; i < 6; i++) cnt_w[i] = 0;
-      cnt_w[6] = 1u;
-      cnt_w[7] = static_cast<uint32_t>(__builtin_popcountll(m_));
-    }
-  }
-  struct Flush {
-    uint32_t* w; uint32_t* n; uint32_t* l; int b; int oct;
-    __device__ ~Flush() {
-      if (b >= 2) {
-        unsigned long long* q = g_bvh_octant[oct & 7];
-        atomicAdd(&q[0], 1ull);
-        atomicAdd(&q[1], static_cast<unsigned long long>(*n));
-        atomicAdd(&q[2], static_cast<unsigned long long>(*n) * *n);
-      }
-      atomicMax(&w[4], *n);
-      atomicMax(&w[5], *l);
-      const unsigned long long m_ = __ballot(1);
-      if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(m_)))
-        for (int i = 0; i < 8; i++) atomicAdd(&g_bvh_count[b & (kCountBuckets - 1)][i], static_cast<unsigned long long>(w[i]));
-    }
-  } flush_{cnt_w, &my_nodes, &my_leaves, bucket, (d.x < 0.0f ? 1 : 0) | (d.y < 0.0f ? 2 : 0) | (d.z < 0.0f ? 4 : 0)};
+  RTPT_COUNT_BEGIN(bucket, d);
 #endif
   // A ray with a NaN component cannot hit anything (every comparison of tri_test fails, D7) — but min/max drop
   // NaNs, so every box would "pass" and that one lane would walk all of the scene: on the 1.15M-triangle lattice
@@ -1311,34 +1253,10 @@ __global__ __launch_bounds__(kThreads) void k_selftest_trace(SceneView sc, const
 
 }  // namespace
 
-#if RTPT_TILE_TIMELINE
-// timeline build only: {start, end, hw} of the first n workgroups of the last K0 (kernel 0) / K2 (kernel 1) launch
-extern "C" __attribute__((visibility("default"))) int rtpt_debug_timeline(int kernel, unsigned long long* out, uint32_t n) {
-  if (kernel < 0 || kernel > 1 || n > kTimelineMax) return -1;
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 3 * n,
-                             sizeof(unsigned long long) * 3 * kTimelineMax * kernel) == hipSuccess ? 0 : -1;
-}
-#endif
-#if RTPT_TILE_TIMELINE
-// timeline build only: the order in which K2's workgroups take their tiles (n = 0: back to the built-in order)
-extern "C" __attribute__((visibility("default"))) int rtpt_debug_tile_order(const uint32_t* order, uint32_t n) {
-  if (n > kTimelineMax) return -1;
-  if (n && hipMemcpyToSymbol(HIP_SYMBOL(g_tile_order), order, sizeof(uint32_t) * n) != hipSuccess) return -1;
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_tile_order_n), &n, sizeof n) == hipSuccess ? 0 : -1;
-}
-#endif
-#if RTPT_BVH_COUNT
-// counting build only: read (and clear) the traversal counters
-extern "C" __attribute__((visibility("default"))) int rtpt_debug_bvh_counters(unsigned long long* out, int clear) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_count), sizeof(unsigned long long) * kCountBuckets * 8) != hipSuccess) return -1;
-  if (out && hipMemcpyFromSymbol(out + kCountBuckets * 8, HIP_SYMBOL(g_bvh_octant), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
-  if (clear) {
-    static unsigned long long zero[kCountBuckets * 8];
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_count), zero, sizeof zero) != hipSuccess) return -1;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_octant), zero, sizeof(unsigned long long) * 24) != hipSuccess) return -1;
-  }
-  return 0;
-}
+#if RTPT_BVH_COUNT || RTPT_TILE_TIMELINE
+#define RTPT_INSTR_HOST
+#include "experiments/trace_instrumentation.inc"
+#undef RTPT_INSTR_HOST
 #endif
 
 void launch_scene_prepare(const ScenePrepArgs& a, hipStream_t s) {
