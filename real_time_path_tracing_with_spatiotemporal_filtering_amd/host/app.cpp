@@ -75,6 +75,14 @@ void PathTracingApplication::loadMesh() {
       throw std::runtime_error("--tessellate needs a mesh of fan-triangulated quads");
   }
   instanceXforms_.clear();
+  if (!opt_.instances.empty()) {
+    if (opt_.lattice[0] > 0) throw std::runtime_error("--instances and --lattice exclude each other");
+    std::ifstream f(opt_.instances);
+    if (!f) throw std::runtime_error("cannot read " + opt_.instances);
+    float v;
+    while (f >> v) instanceXforms_.push_back(v);
+    if (instanceXforms_.empty() || instanceXforms_.size() % 12) throw std::runtime_error(opt_.instances + ": 12 floats per instance expected");
+  }
   if (opt_.lattice[0] > 0) {
     instanceXforms_ = lattice_xforms(opt_.lattice[0], opt_.lattice[1], opt_.lattice[2], opt_.pitch);
     const LatticeView v = lattice_view(opt_.lattice[0], opt_.lattice[1], opt_.lattice[2], opt_.pitch);

@@ -27,6 +27,8 @@ struct Options {
   int tessellate = 1;
   int lattice[3] = {0, 0, 0};           // 0: no instancing (one identity instance)
   float pitch = 2.5f;
+  std::string instances;                // text file, 12 floats per instance (3x4 row-major transform): a general instance list
+                                        // in place of main.cpp:728-741's identity (camera and light stay the reference's)
   // row strips across GPUs (new work, the reference is single-device)
   int ranks = 1;                        // strips the frame is split into
   int rank = -1;                        // >= 0: this process is that rank (one GPU per process, RCCL between them);

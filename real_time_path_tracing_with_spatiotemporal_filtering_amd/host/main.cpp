@@ -18,7 +18,7 @@ static void usage(const char* argv0) {
   std::printf(
       "usage: %s [--width W] [--height H] [--frames N] [--segments S] [--iterations K]\n"
       "          [--scene file.obj] [--script \"keys0,keys1,...\"] [--dump out.pfm] [--exact-filter]\n"
-      "          [--tessellate n] [--lattice NXxNYxNZ [--pitch P]] [--dump-scene out.bin]\n"
+      "          [--tessellate n] [--lattice NXxNYxNZ [--pitch P] | --instances file] [--dump-scene out.bin]\n"
       "          [--frames-in-flight 1|2]\n"
       "          [--ranks R [--rank r --rccl-id-file F [--rccl-nonce N] [--rccl-timeout S]] [--halo redundant|exchange] [--device D]]\n"
       "          [--present none|rgba8|f32 [--dump-present out.raw]]\n"
@@ -32,6 +32,7 @@ static void usage(const char* argv0) {
       "  strips are gathered on rank 0 (rgba8: in that format, f32: as float rows); --dump-present writes rank 0's last image raw\n"
       "  --tessellate n splits every quad of the OBJ into n x n cells; --lattice instances the mesh on a lattice of translations and\n"
       "  frames it (camera, light, far plane): --lattice 10x10x10 --tessellate 6 is BASELINE.json configs[4], 1,152,000 triangles;\n"
+      "  --instances file: 12 floats per instance (3x4 row-major transforms) instead of the one identity instance;\n"
       "  --dump-scene writes what rtpt_scene_upload receives (with --plan-only: no GPU needed)\n"
       "  keys per frame are the reference's GLFW keys: WASDQE move the camera, IJKLUO the light\n"
       "  defaults are the reference's constants: 1000x800, 32 segments, 9 iterations (main.cpp:52-55)\n",
@@ -66,6 +67,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--tessellate")) opt.tessellate = std::atoi(need("--tessellate"));
     else if (!std::strcmp(argv[i], "--pitch")) opt.pitch = static_cast<float>(std::atof(need("--pitch")));
     else if (!std::strcmp(argv[i], "--dump-scene")) dump_scene = need("--dump-scene");
+    else if (!std::strcmp(argv[i], "--instances")) opt.instances = need("--instances");
     else if (!std::strcmp(argv[i], "--lattice")) {
       if (std::sscanf(need("--lattice"), "%dx%dx%d", &opt.lattice[0], &opt.lattice[1], &opt.lattice[2]) != 3 || opt.lattice[0] < 1 ||
           opt.lattice[1] < 1 || opt.lattice[2] < 1) {

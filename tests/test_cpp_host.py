@@ -336,3 +336,72 @@ def test_cpp_host_runs_the_lattice_scene_like_the_python_host(app_binary, hip_li
     got = read_pfm(pfm)
     assert np.array_equal(bits(got), bits(np.ascontiguousarray(want[..., :3])))
     assert stats["rays"] == app.backend.ctx.raycount()
+
+
+def _instance_file(tmp_path):
+    """three instances with rotation, shear-free scale and translation (3x4 row-major), as text"""
+    c, s_ = np.float32(np.cos(0.3)), np.float32(np.sin(0.3))
+    xf = np.array([[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0],
+                   [c, 0, s_, 2.4, 0, 1, 0, 0.0, -s_, 0, c, -1.0],
+                   [0.5, 0, 0, -2.2, 0, 0.5, 0, 0.0, 0, 0, 0.5, 0.5]], np.float32)
+    path = tmp_path / "instances.txt"
+    path.write_text("\n".join(" ".join(repr(float(v)) for v in row) for row in xf))
+    return path, xf
+
+
+def test_cpp_instance_file_is_what_the_python_mirror_uploads(app_binary, tmp_path):
+    """host-only: `rtpt_app --instances file` (a general instance list in place of main.cpp:728-741's identity) hands
+    rtpt_scene_upload the transforms of the file, bit for bit, and bounds its strips' history bands with the instanced box"""
+    from test_host_logic import Recorder
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE, PathTracingApplication
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripPlan, reprojection_rows
+    abi.load()
+    path, xf = _instance_file(tmp_path)
+    W, H, N, R = 320, 180, 5, 3
+    keys = ["", "E", "D", "Q"]
+    dump = tmp_path / "scene.bin"
+    out = subprocess.run([app_binary, "--plan-only", "--width", str(W), "--height", str(H), "--iterations", str(N), "--ranks", str(R),
+                          "--frames", str(len(keys)), "--script", ",".join(keys), "--dump-scene", str(dump), "--instances", str(path)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    raw = np.fromfile(dump, np.uint8)
+    nv, nt, ni = raw[:12].view(np.uint32)
+    assert (nt, ni) == (32, 3)
+    o = 12 + 12 * nv + 12 * nt
+    assert np.array_equal(bits(raw[o:o + 48 * ni].view(np.float32).reshape(-1, 12)), bits(xf))
+    plan = json.loads(out.stdout)
+    app = PathTracingApplication(Recorder(), W, H, N)
+    app.loadMesh(DEFAULT_SCENE)
+    app.buildAccelerationStructure(xf)
+    for f, k in enumerate(keys):
+        app.updateScene(tuple(k))
+        needs = [list(reprojection_rows(app.ubo, W, H, StripPlan.bounds(H, R, r), app.sceneBounds, app.z_near)) for r in range(R)]
+        assert plan["frames"][f]["needs"] == needs, (f, k)
+        app.frameCount += 1
+    bad = subprocess.run([app_binary, "--plan-only", "--instances", str(path), "--lattice", "2x2x2"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "exclude" in bad.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 3])
+def test_cpp_host_with_an_instance_file_equals_the_python_host(app_binary, hip_lib, tmp_path, ranks):
+    """rotated, scaled and translated instances of the Cornell box (96 triangles: BVH traversal over fan pairs) through the
+    C++ host, one context and three in-process strips with a moving camera, against the Python host, bit for bit"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    path, xf = _instance_file(tmp_path)
+    W, H, SEG, N = 192, 120, 4, 5
+    keys = ["", "", "E", "D", "J"]
+    pfm = tmp_path / "out.pfm"
+    cmd = [app_binary, "--width", str(W), "--height", str(H), "--segments", str(SEG), "--iterations", str(N), "--frames", str(len(keys)),
+           "--script", ",".join(keys), "--dump", str(pfm), "--instances", str(path)]
+    if ranks > 1:
+        cmd += ["--ranks", str(ranks)]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    app = make_app(W, H, max_segments=SEG, iterations=N, instance_xforms=xf)
+    for k in keys:
+        app.drawScene(tuple(k))
+    want = app.backend.ctx.readback(hip_lib.PLANE_IMAGE)
+    assert np.array_equal(bits(read_pfm(pfm)), bits(np.ascontiguousarray(want[..., :3])))
+    assert json.loads(out.stdout.strip().splitlines()[-1])["rays"] == app.backend.ctx.raycount()
