@@ -329,7 +329,7 @@ __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
 //   * long segments (a 4K frame: 135 rows): three rows per step; the short-stride pair (1,2) two, its rings then admit four
 //     workgroups per CU (4K: 90.4 us against 95.6);
 //   * short segments (an 8-rank strip of the 4K frame: 19 rows at G = 3; 1080p: 34): FOUR rows per step — 16 waves per
-//     workgroup, still two workgroups per CU, a quarter fewer steps for the same fill.  Round 4, profiles/r04_chain_g_ab.csv:
+//     workgroup, still two workgroups per CU, a quarter fewer steps for the same fill.  Round 4, profiles/r04_chain_g_ab.txt:
 //     the 300-row strip 25.0 -> 21.9 us per pair, 1080p 32.9 -> 31.9, where the 4K frame loses (103 against 97.7).
 // RTPT_CHAIN_G1 (read by rtpt_create, FilterPolicy::chain_g_pin) pins 2, 3 or 4 for A/B runs and tests.
 static int chain_g(int k0, int levels, int n_strips, int rows, int n_cu, int pin) {

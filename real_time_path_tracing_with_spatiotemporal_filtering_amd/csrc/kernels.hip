@@ -252,7 +252,7 @@ constexpr uint32_t kSentinel = 0xFFFFFFFEu;
 #define RTPT_GRAD_NT_STORE 1
 #endif
 #ifndef RTPT_BVH_LEAF_RATIO
-#define RTPT_BVH_LEAF_RATIO 2  // 0: 2981 us, 1: 2734, 2: 2714, 3: 2728 for K2 on the 1.15M-triangle frame (profiles/r04_bvh_ab.csv)
+#define RTPT_BVH_LEAF_RATIO 2  // 0: 2981 us, 1: 2734, 2: 2714, 3: 2728 for K2 on the 1.15M-triangle frame (profiles/r04_bvh_ab.txt)
 #endif
 #ifndef RTPT_LEAF_BATCH
 #define RTPT_LEAF_BATCH 2  // 1: 3.72 ms, 2: 3.65 ms, 4: 4.79 ms (registers) on the 1.15M-triangle trace
