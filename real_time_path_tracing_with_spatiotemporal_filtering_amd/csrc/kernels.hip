@@ -1061,6 +1061,9 @@ void k_gbuffer_pathtrace(PathtraceArgs a, GbufferArgs g) {
     pathtrace_tile<BVH, true, true>(a);
   } else {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack[];
+#if RTPT_TILE_TIMELINE
+    TimelineScope tl_(0, (blockIdx.y - a.tiles_y) * gridDim.x + blockIdx.x);
+#endif
     gbuffer_tile<BVH>(g, blockIdx.x, blockIdx.y - a.tiles_y, stack, a.image, a.g.y0, a.g.y1);
   }
 }
@@ -1073,6 +1076,9 @@ void k_gbuffer_pathtrace_small(PathtraceArgs a, GbufferArgs g) {
     pathtrace_tile<0, true, true>(a);
   } else {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack[];
+#if RTPT_TILE_TIMELINE
+    TimelineScope tl_(0, (blockIdx.y - a.tiles_y) * gridDim.x + blockIdx.x);
+#endif
     gbuffer_tile<0>(g, blockIdx.x, blockIdx.y - a.tiles_y, stack, a.image, a.g.y0, a.g.y1);
   }
 }
