@@ -44,6 +44,7 @@ _INSTANCED = {}  # the configs[4] scene, built once per process
 # v_fma_f32 1.16), a transcendental (v_rcp / v_sqrt / v_rsq / v_exp) for 3.42 ns.  1,024 SIMDs.
 VALU_NS, TRANS_NS, N_SIMDS = 1.06, 3.42, 1024
 HOST_SECONDS = [0.0]
+LOCAL_SECONDS = [0.0]   # this rank's own K steps (its stream drained, before the ranks meet at the barrier): what --balance reads
 HIST_BYTES = [0]
 PRESENT_BYTES = [0]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -84,7 +85,8 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
                      lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
     app = make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"],
                    rank=rank, world=world, mode=halo, flags=args.flags,
-                   torch_planes=(dist is not None), frames_in_flight=in_flight, present=present, **extra)
+                   torch_planes=(dist is not None), frames_in_flight=in_flight, present=present,
+                   splits=getattr(args, "strip_rows", ()) if world > 1 else (), **extra)
     keys_of = (lambda f: (camera_keys[f % len(camera_keys)],)) if camera_keys else (lambda f: ())
     present_bytes = [0]
     frame_no = [0]
@@ -147,6 +149,9 @@ def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=T
     HIST_BYTES[0] = hist_bytes[0]
     PRESENT_BYTES[0] = present_bytes[0]
     HOST_SECONDS[0] = time.perf_counter() - t0  # time the host needed to submit the K steps (diagnostic)
+    for c in ctxs:
+        c.sync()
+    LOCAL_SECONDS[0] = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
     ctx.timing_enable(0)
@@ -322,6 +327,155 @@ def _cpu_baseline_child(wl, budget_s=12.0):
     }
 
 
+def _min_strip_rows(wl, args, world):
+    """rows every strip keeps when the boundaries move: the halo of the plan (exchange: the longest reach; redundant: their sum)"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripPlan
+    return max(1, StripPlan(wl["height"], world, 0, wl["iterations"], args.halo, args.flags & 0x9F0).halo)
+
+
+def _strip_app(wl, args, rank, world, rows, torch_planes, halo="redundant"):
+    """an application for rank `rank`'s strip of a `world`-rank job with the boundaries `rows`, for the balancing procedures'
+    own measurements: no present, redundant halo rows (no rank waits for another while the camera rests, so the ranks may
+    draw different numbers of frames)"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE, make_app
+    extra = {}
+    if wl.get("instanced"):
+        if "scene" not in _INSTANCED:
+            from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi, scenes
+            xyz, idx = abi.load_obj(DEFAULT_SCENE)
+            _INSTANCED["scene"] = scenes.instanced_cornell(xyz, idx)
+        vx, ti, xf, cam, zfar = _INSTANCED["scene"]
+        extra = dict(mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar, lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
+    return make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"], rank=rank, world=world,
+                    mode=halo, flags=args.flags, torch_planes=torch_planes, splits=rows if world > 1 else (), **extra)
+
+
+def ray_profile(app, y0, y1, band=8, settle=4):
+    """rays traced per row of rows [y0, y1) of this application's strip, one band of `band` rows per frame through the ray
+    counter's row window (rtpt_set_count_rows) — the frames differ in their random numbers, a band's sum hardly does"""
+    ctx = app.backend.ctx
+    for _ in range(settle):
+        app.drawScene(())
+    out = []
+    for a in range(y0, y1, band):
+        b = min(a + band, y1)
+        ctx.set_count_rows(a, b)
+        ctx.reset_counters()
+        app.drawScene(())
+        n = ctx.raycount()
+        out += [n / (b - a)] * (b - a)
+    ctx.set_count_rows(*app.plan.own)
+    ctx.reset_counters()
+    return out
+
+
+def _trace_share(kern):
+    """share of the per-frame kernel time that scales with the rays (the tracing launch) in a timing_collect() table"""
+    tot = sum(ms for ms, n in kern.values() if n)
+    tr = sum(ms for k, (ms, n) in kern.items() if n and k in ("k_pathtrace", "k_gbuffer_pathtrace", "k_pathtrace_queue"))
+    return min(0.95, max(0.05, tr / tot)) if tot > 0 else 0.5
+
+
+def balance_live(wl, args, rank, world, torch, dist):
+    """--balance: every rank measures the rays per row of its own strip, the ranks gather the profile, cut it into equal
+    parts, and then ROUNDS times run a short batch of frames, gather their own times and let them correct the profile
+    (strips.StripBalancer).  Every rank computes the same rows from the same gathered numbers.  Nothing of this enters the
+    timed region."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripBalancer, StripPlan
+    H = wl["height"]
+    dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+
+    def gather(values, n):
+        mine = torch.zeros(n, dtype=torch.float64, device=dev)
+        mine[:len(values)] = torch.tensor(values, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return [t.cpu().tolist() for t in every]
+
+    rows = args.strip_rows or tuple(StripPlan.bounds(H, world, r)[0] for r in range(world)) + (H,)
+    app = _strip_app(wl, args, rank, world, rows, torch_planes=True)
+    mine = ray_profile(app, *app.plan.own)
+    app.backend.ctx.timing_enable(1)
+    for _ in range(8):
+        app.drawScene(())
+    share = _trace_share(app.backend.ctx.timing_collect())
+    app.backend.close()
+    tallest = max(b - a for a, b in zip(rows, rows[1:]))
+    parts = gather(mine + [share], tallest + 1)
+    profile = []
+    for r in range(world):
+        profile += parts[r][:rows[r + 1] - rows[r]]
+    share = sum(parts[r][rows[r + 1] - rows[r]] for r in range(world)) / world
+    mean = sum(profile) / H
+    bal = StripBalancer(H, world, _min_strip_rows(wl, args, world), profile, floor=mean * (1.0 - share) / share)
+    rows = bal.splits()
+    steps = max(8, min(args.steps, 40))
+    # a strip's time is not additive in its rows (a launch of 4 140 tiles takes a third generation of workgroups that one of
+    # 4 080 does not), so the rounds wander around the optimum: the job runs with the best boundaries it has SEEN
+    best = None
+    for i in range(max(1, args.balance)):
+        args.strip_rows = rows
+        run_gpu(wl, args, rank, world, steps, min(args.warmup, 5), torch, dist, collect_kernels=False)
+        times = [t[0] for t in gather([LOCAL_SECONDS[0]], 1)]
+        if best is None or max(times) < best[0]:
+            best = (max(times), rows)
+        bal.update(rows, times)
+        rows = bal.splits()
+    return best[1]
+
+
+def emulate_balance(wl, args, torch):
+    """--emulate-balance N[:ROUNDS] on one GPU: what --balance does on N, with the strips run one after the other.  Round 0 is
+    the equal division; round 1 the cut of the measured ray profile; the later rounds correct it with the strips' times.
+    `plain` repeats the rounds without the profile (strips.balanced_splits: a strip's time spread evenly over its rows)."""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripBalancer, StripPlan, balanced_splits
+    spec = args.emulate_balance.split(":")
+    n, rounds = int(spec[0]), int(spec[1]) if len(spec) > 1 else 3
+    H = wl["height"]
+    args.halo = "redundant"
+    equal = tuple(StripPlan.bounds(H, n, r)[0] for r in range(n)) + (H,)
+    min_rows = _min_strip_rows(wl, args, n)
+    out = {"emulated_balance": n, "workload": args.workload, "steps": args.steps, "min_rows": min_rows, "rounds": [], "plain": []}
+
+    def measure(rows, into):
+        args.strip_rows = rows
+        ms = []
+        for r in range(n):
+            e, _, _, _, _ = run_gpu(wl, args, r, n, args.steps, args.warmup, torch, None, collect_kernels=False,
+                                    in_flight=args.frames_in_flight)
+            ms.append(round(e / args.steps * 1e3, 4))
+        into.append({"strip_rows": list(rows), "ms_per_strip": ms, "slowest": max(ms), "mean": round(sum(ms) / n, 4)})
+        print(f"# rows {list(rows)} ms {ms} slowest {max(ms)}", file=sys.stderr, flush=True)
+        return ms
+
+    full = _strip_app(wl, args, 0, 1, (), torch_planes=False)
+    profile = ray_profile(full, 0, H)
+    full.backend.ctx.timing_enable(1)
+    for _ in range(8):
+        full.drawScene(())
+    share = _trace_share(full.backend.ctx.timing_collect())
+    full.backend.close()
+    out["trace_share_of_kernel_time"] = round(share, 3)
+    out["rays_per_row_by_16_rows"] = [round(sum(profile[y:y + 16]) / len(profile[y:y + 16]), 1) for y in range(0, H, 16)]
+    bal = StripBalancer(H, n, min_rows, profile, floor=sum(profile) / H * (1.0 - share) / share)
+    ms = measure(equal, out["rounds"])
+    rows = bal.splits()
+    for i in range(rounds):
+        ms = measure(rows, out["rounds"])
+        if i + 1 < rounds:
+            bal.update(rows, ms)
+            rows = bal.splits()
+    best = min(out["rounds"], key=lambda r: r["slowest"])
+    out["best"] = {"strip_rows": best["strip_rows"], "slowest": best["slowest"],
+                   "speedup_of_the_slowest_strip_vs_equal_strips": round(out["rounds"][0]["slowest"] / best["slowest"], 3)}
+    if args.emulate_balance_plain:
+        rows, ms = equal, out["rounds"][0]["ms_per_strip"]
+        for i in range(rounds):
+            rows = balanced_splits(rows, ms, min_rows)
+            ms = measure(rows, out["plain"])
+    _RESULT_LINE.append(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -336,6 +490,19 @@ def main():
     ap.add_argument("--emulate-strip", default=None, metavar="R/N",
                     help="diagnostic: this single process runs rank R's strip of an N-rank job (redundant halo, no "
                          "communication is needed while the camera rests) and prints its per-frame time")
+    ap.add_argument("--splits", default=None, metavar="0,A,B,...,H",
+                    help="unequal strips: world + 1 ascending rows (strips.StripPlan.splits); with --emulate-strip R/N the rows of "
+                         "the N-rank job whose rank R this process runs")
+    ap.add_argument("--balance", type=int, default=0, metavar="ROUNDS",
+                    help="several ranks: before the measured run, measure the rays per row (every rank its own strip), cut that "
+                         "profile into equal parts and correct it ROUNDS times with the ranks' own frame times "
+                         "(strips.StripBalancer); the line reports the rows under strip_rows.  Off by default: equal strips")
+    ap.add_argument("--emulate-balance", default=None, metavar="N[:ROUNDS]",
+                    help="diagnostic on ONE GPU: run every strip of an N-rank job alone, one after the other (redundant halo), "
+                         "balance the boundaries from the measured times and repeat ROUNDS times (default 3); prints the "
+                         "slowest strip of every round")
+    ap.add_argument("--emulate-balance-plain", action="store_true",
+                    help="with --emulate-balance: also run the rounds of the profile-free procedure (strips.balanced_splits)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single GPU: every rank uses device 0 and torch.distributed runs "
                          "on gloo (RCCL refuses two ranks on one device); exercises strips, halo exchange and the "
@@ -390,12 +557,19 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
+    args.strip_rows = tuple(int(v) for v in args.splits.split(",")) if args.splits else ()
+    if args.emulate_balance:
+        emulate_balance(wl, args, torch)
+        return
+    if world > 1 and args.balance > 0:
+        args.strip_rows = balance_live(wl, args, rank, world, torch, dist)
     if args.emulate_strip:
         r, n = map(int, args.emulate_strip.split("/"))
         args.halo = "redundant"
         elapsed, rays, kern, plan, timed_frames = run_gpu(wl, args, r, n, args.steps, args.warmup, torch, None,
                                                           in_flight=args.frames_in_flight)
-        _RESULT_LINE.append(json.dumps({"emulated_strip": args.emulate_strip, "rows_owned": plan.own, "rows_stored": plan.stored,
+        _RESULT_LINE.append(json.dumps({"emulated_strip": args.emulate_strip, "strip_rows": list(plan.splits) or None,
+                          "rows_owned": plan.own, "rows_stored": plan.stored,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "rays_per_frame": rays / args.steps,
                           "kernels": kernel_report(kern, wl, plan, timed_frames)}))
         return
@@ -450,6 +624,8 @@ def main():
                        "present": (args.present or "none") + (" gathered on rank 0" if world > 1 and args.present else ""),
                        "frames_in_flight": args.frames_in_flight},
             "rays_per_frame": round(rays / args.steps, 1),
+            # unequal strips (--splits / --balance): the rows of the job that was measured; null = equal strips
+            "strip_rows": list(plan.splits) or None,
             "history_exchange_bytes_per_frame_rank0": round(HIST_BYTES[0] / args.steps, 1),
             "present_gather_bytes_per_frame_rank0": round(PRESENT_BYTES[0] / args.steps, 1),
             # achieved / frac: ALGORITHMIC bytes of the operator one launch computes / the launch time measured
@@ -505,7 +681,8 @@ def main():
             try:   # every rank checks EVERY rank's plan, so a leg is skipped by all of them or by none
                 for r in range(world):
                     for k in range(1, wl["iterations"] + 1):
-                        StripPlan(wl["height"], world, r, wl["iterations"], kw.get("halo", args.halo), args.flags & 0x9F0).exchange_rows(k)
+                        StripPlan(wl["height"], world, r, wl["iterations"], kw.get("halo", args.halo), args.flags & 0x9F0,
+                                  args.strip_rows).exchange_rows(k)
             except ValueError as ex:   # strips shorter than the exchange halo
                 if rank == 0:
                     result.setdefault("also", {})[name] = {"skipped": str(ex)}

@@ -596,7 +596,7 @@ class PathTracingApplication:
             return
         H, R = self.plan.height, self.plan.world
         bounds = self._world_bounds()
-        needs = [reprojection_rows(self.ubo, self.render_width, H, StripPlan.bounds(H, R, r), bounds, self.z_near)
+        needs = [reprojection_rows(self.ubo, self.render_width, H, self.plan.rows_of(r), bounds, self.z_near)
                  for r in range(R)]
         full = be.history_full()
         self.history_bytes_sent = exchange_history(self.plan, needs, lambda a, b: be.color_rows(abi.PLANE_PREVIOUS, a, b),
@@ -616,7 +616,7 @@ class PathTracingApplication:
             return
         from .strips import exchange_history
         H, R = self.plan.height, self.plan.world
-        plans = [StripPlan(H, R, r, self.plan.iterations, self.plan.mode, self.plan.ext_flags) for r in range(R)]
+        plans = [StripPlan(H, R, r, self.plan.iterations, self.plan.mode, self.plan.ext_flags, self.plan.splits) for r in range(R)]
         bounds = self._world_bounds()
         needs = [reprojection_rows(self.ubo, self.render_width, H, p.stored, bounds, self.z_near) for p in plans]
         ids, mom = be.guides_full()
@@ -649,10 +649,10 @@ class PathTracingApplication:
 
 def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode="exchange", flags=0,
              torch_planes=None, debug_mask=0, scene=DEFAULT_SCENE, instance_xforms=None, group=None, mesh=None,
-             frames_in_flight=1, samples_per_pixel=1, **app_kw):
+             frames_in_flight=1, samples_per_pixel=1, splits=(), **app_kw):
     """createBuffers + loadMesh + buildAccelerationStructure for one rank.  `mesh` = (xyz, idx) replaces
-    the OBJ (synthetic scenes of scenes.py)."""
-    plan = StripPlan(height, world, rank, iterations, mode, flags & abi.FLAG_EXT_MASK)
+    the OBJ (synthetic scenes of scenes.py); `splits` = unequal strips (strips.StripPlan.splits, the same on every rank)."""
+    plan = StripPlan(height, world, rank, iterations, mode, flags & abi.FLAG_EXT_MASK, tuple(splits) if world > 1 else ())
     if torch_planes is None:
         torch_planes = world > 1  # halo exchange and the history all-gather move rows of torch-owned planes
     def one():

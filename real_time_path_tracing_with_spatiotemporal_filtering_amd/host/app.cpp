@@ -145,6 +145,8 @@ void PathTracingApplication::createBuffers() {
       rs.plan.iterations = opt_.maxWaveletIteration;
       rs.plan.exchange = opt_.exchange_halo;
       rs.plan.ext_flags = opt_.flags & 0x9F0u;
+      rs.plan.splits = opt_.splits;
+      rs.plan.validate();
       const Rows st = rs.plan.stored(), own = rs.plan.own();
       cfg.row_begin = static_cast<uint32_t>(st.first);
       cfg.row_end = static_cast<uint32_t>(st.second);
@@ -314,8 +316,8 @@ void PathTracingApplication::prepareHistory() {
   const size_t row_bytes = static_cast<size_t>(opt_.width) * 16;
   std::vector<Rows> needs;
   for (int r = 0; r < opt_.ranks; r++)
-    needs.push_back(reprojection_rows(ubo, static_cast<int>(opt_.width), H, StripPlan::bounds(H, opt_.ranks, r), sceneMin_, sceneMax_, 0.1f));
-  const auto table = history_exchange_plan(H, opt_.ranks, needs);
+    needs.push_back(reprojection_rows(ubo, static_cast<int>(opt_.width), H, StripPlan::bounds(H, opt_.ranks, r, opt_.splits), sceneMin_, sceneMax_, 0.1f));
+  const auto table = history_exchange_plan(H, opt_.ranks, needs, opt_.splits);
   transport_->begin(stream_);
   for (auto& rs : ranks_) {
     if (!rs.history) rs.history = host_device_alloc(static_cast<size_t>(H) * row_bytes);
@@ -349,7 +351,7 @@ void PathTracingApplication::prepareHistory() {
 void PathTracingApplication::exchangeBands(const std::vector<Rows>& needs, rtpt_plane plane, size_t px_bytes, void* RankState::*dst) {
   const int H = static_cast<int>(opt_.height);
   const size_t row_bytes = static_cast<size_t>(opt_.width) * px_bytes;
-  const auto table = history_exchange_plan(H, opt_.ranks, needs);
+  const auto table = history_exchange_plan(H, opt_.ranks, needs, opt_.splits);
   transport_->begin(stream_);
   for (auto& rs : ranks_) {
     if (!(rs.*dst)) rs.*dst = host_device_alloc(static_cast<size_t>(H) * row_bytes);
@@ -533,7 +535,7 @@ void PathTracingApplication::presentFrame() {
     const Rows own = rs.plan.own();
     if (rs.plan.rank == 0) {
       for (int r = 1; r < opt_.ranks; r++) {
-        const Rows o = StripPlan::bounds(static_cast<int>(H), opt_.ranks, r);
+        const Rows o = StripPlan::bounds(static_cast<int>(H), opt_.ranks, r, opt_.splits);
         presentTransport_->recv(0, static_cast<char*>(rs.swap[idx]) + static_cast<size_t>(o.first) * row_bytes, r,
                                 static_cast<size_t>(o.second - o.first) * row_bytes);
       }
@@ -636,18 +638,32 @@ std::string PathTracingApplication::planJson(int frames, const std::vector<std::
   auto rows = [](Rows r) { return "[" + std::to_string(r.first) + ", " + std::to_string(r.second) + "]"; };
   for (int r = 0; r < R; r++) {
     StripPlan p;
-    p.height = H; p.world = R; p.rank = r; p.iterations = N; p.exchange = opt_.exchange_halo; p.ext_flags = opt_.flags & 0x9F0u;
+    p.height = H; p.world = R; p.rank = r; p.iterations = N; p.exchange = opt_.exchange_halo; p.ext_flags = opt_.flags & 0x9F0u; p.splits = opt_.splits;
+    p.validate();
     out += std::string(r ? ", " : "") + "{\"own\": " + rows(p.own()) + ", \"stored\": " + rows(p.stored()) + ", \"raytrace\": " +
            rows(p.raytrace_rows()) + ", \"filter\": [";
     for (int k = 1; k <= N; k++) out += std::string(k > 1 ? ", " : "") + rows(p.filter_rows(k));
     out += "]}";
   }
-  out += "], \"frames\": [";
+  out += "], \"splits\": [";
+  for (int r = 0; r <= R; r++) out += std::string(r ? ", " : "") + std::to_string(r < R ? StripPlan::bounds(H, R, r, opt_.splits).first : H);
+  out += "]";
+  if (!opt_.balance_cost.empty()) {
+    std::vector<int> cur;
+    for (int r = 0; r <= R; r++) cur.push_back(r < R ? StripPlan::bounds(H, R, r, opt_.splits).first : H);
+    StripPlan p0;
+    p0.height = H; p0.world = R; p0.iterations = N; p0.exchange = opt_.exchange_halo; p0.ext_flags = opt_.flags & 0x9F0u;
+    const std::vector<int> b = balanced_splits(cur, opt_.balance_cost, std::max(1, p0.halo()));
+    out += ", \"balanced\": [";
+    for (size_t i = 0; i < b.size(); i++) out += std::string(i ? ", " : "") + std::to_string(b[i]);
+    out += "]";
+  }
+  out += ", \"frames\": [";
   for (int f = 0; f < frames; f++) {
     updateScene(static_cast<size_t>(f) < script.size() ? script[static_cast<size_t>(f)] : std::string());
     out += std::string(f ? ", " : "") + "{\"moved\": " + (frameCount > 0 && !cameraStatic() ? "true" : "false") + ", \"needs\": [";
     for (int r = 0; r < R; r++)
-      out += std::string(r ? ", " : "") + rows(reprojection_rows(ubo, static_cast<int>(opt_.width), H, StripPlan::bounds(H, R, r), sceneMin_, sceneMax_, 0.1f));
+      out += std::string(r ? ", " : "") + rows(reprojection_rows(ubo, static_cast<int>(opt_.width), H, StripPlan::bounds(H, R, r, opt_.splits), sceneMin_, sceneMax_, 0.1f));
     out += "]}";
     frameCount++;
   }

@@ -35,6 +35,8 @@ struct Options {
                                         // -1 with ranks > 1: every strip is a context of THIS process on one GPU
                                         // (rehearsal / tests: a message is a device-to-device copy)
   bool exchange_halo = false;           // true: k rows per neighbour travel before iteration k; false: redundant rows
+  std::vector<int> splits;              // unequal strips: ranks + 1 ascending rows 0 .. height (empty: equal; strips.hpp)
+  std::vector<double> balance_cost;     // --plan-only: the ranks' frame times; the plan also prints balanced_splits of them
   std::string rccl_id_file;             // rendezvous file for the ncclUniqueId (rank >= 0)
   uint64_t rccl_nonce = 0;              // same on every rank of one launch, different between launches (strips.hpp)
   int rccl_timeout_s = 120;             // rendezvous + communicator bring-up watchdog

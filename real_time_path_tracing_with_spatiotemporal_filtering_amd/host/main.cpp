@@ -20,7 +20,7 @@ static void usage(const char* argv0) {
       "          [--scene file.obj] [--script \"keys0,keys1,...\"] [--dump out.pfm] [--exact-filter]\n"
       "          [--tessellate n] [--lattice NXxNYxNZ [--pitch P] | --instances file] [--dump-scene out.bin]\n"
       "          [--frames-in-flight 1|2]\n"
-      "          [--ranks R [--rank r --rccl-id-file F [--rccl-nonce N] [--rccl-timeout S]] [--halo redundant|exchange] [--device D]]\n"
+      "          [--ranks R [--rank r --rccl-id-file F [--rccl-nonce N] [--rccl-timeout S]] [--halo redundant|exchange] [--splits 0,a,b,..,H] [--device D]]\n"
       "          [--present none|rgba8|f32 [--dump-present out.raw]]\n"
       "          [--plan-only   (print the strip plan and the history bands of the scripted frames as JSON; needs no GPU)]\n"
       "  --ranks R splits the frame into R row strips: with --rank r this process is rank r on its own GPU and talks RCCL\n"
@@ -81,6 +81,19 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--ranks")) opt.ranks = std::atoi(need("--ranks"));
     else if (!std::strcmp(argv[i], "--rank")) opt.rank = std::atoi(need("--rank"));
     else if (!std::strcmp(argv[i], "--halo")) opt.exchange_halo = !std::strcmp(need("--halo"), "exchange");
+    else if (!std::strcmp(argv[i], "--splits") || !std::strcmp(argv[i], "--balance")) {
+      // --splits 0,300,...,H: unequal strips; --balance t0,t1,...: (with --plan-only) the ranks' frame times, the plan then
+      // also prints the boundaries balanced_splits derives from them
+      const bool sp = !std::strcmp(argv[i], "--splits");
+      const char* v = need(argv[i]);
+      for (const char* q = v; *q;) {
+        char* e = nullptr;
+        const double x = std::strtod(q, &e);
+        if (e == q) { std::fprintf(stderr, "%s takes comma-separated numbers\n", sp ? "--splits" : "--balance"); return 2; }
+        if (sp) opt.splits.push_back(static_cast<int>(x)); else opt.balance_cost.push_back(x);
+        q = *e == ',' ? e + 1 : e;
+      }
+    }
     else if (!std::strcmp(argv[i], "--rccl-id-file")) opt.rccl_id_file = need("--rccl-id-file");
     else if (!std::strcmp(argv[i], "--device")) opt.device = std::atoi(need("--device"));
     else if (!std::strcmp(argv[i], "--rccl-nonce")) opt.rccl_nonce = std::strtoull(need("--rccl-nonce"), nullptr, 0);

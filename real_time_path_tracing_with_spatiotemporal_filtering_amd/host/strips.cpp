@@ -21,6 +21,37 @@
 namespace rtpt_host {
 
 // ---------------------------------------------------------------------------------------------------- plan
+void StripPlan::validate() const {
+  if (splits.empty()) return;
+  bool ok = static_cast<int>(splits.size()) == world + 1 && splits.front() == 0 && splits.back() == height;
+  for (size_t i = 0; ok && i + 1 < splits.size(); i++) ok = splits[i + 1] > splits[i];
+  if (!ok) throw std::runtime_error("splits must be " + std::to_string(world + 1) + " ascending rows from 0 to " + std::to_string(height));
+}
+std::vector<int> balanced_splits(const std::vector<int>& sp, const std::vector<double>& cost, int min_rows) {
+  const int world = static_cast<int>(sp.size()) - 1;
+  bool ok = world >= 1 && static_cast<int>(cost.size()) == world;
+  for (int i = 0; ok && i < world; i++) ok = sp[static_cast<size_t>(i) + 1] > sp[static_cast<size_t>(i)] && cost[static_cast<size_t>(i)] > 0.0;
+  if (!ok) throw std::runtime_error("balanced_splits: world + 1 ascending rows and one positive cost per rank");
+  if (static_cast<int64_t>(world) * min_rows > sp.back() - sp.front()) throw std::runtime_error("balanced_splits: min_rows does not fit the frame");
+  double total = 0.0;
+  for (double c : cost) total += c;
+  std::vector<int> out{sp.front()};
+  int r = 0;
+  double acc = 0.0;  // cost of the rows above sp[r]
+  for (int j = 1; j < world; j++) {
+    const double target = total * j / world;
+    while (r < world - 1 && acc + cost[static_cast<size_t>(r)] < target) {
+      acc += cost[static_cast<size_t>(r)];
+      r++;
+    }
+    const double y = sp[static_cast<size_t>(r)] + (target - acc) * (sp[static_cast<size_t>(r) + 1] - sp[static_cast<size_t>(r)]) / cost[static_cast<size_t>(r)];
+    out.push_back(static_cast<int>(y + 0.5));
+  }
+  out.push_back(sp.back());
+  for (int j = 1; j < world; j++) out[static_cast<size_t>(j)] = std::max(out[static_cast<size_t>(j)], out[static_cast<size_t>(j) - 1] + min_rows);
+  for (int j = world - 1; j >= 1; j--) out[static_cast<size_t>(j)] = std::min(out[static_cast<size_t>(j)], out[static_cast<size_t>(j) + 1] - min_rows);
+  return out;
+}
 int StripPlan::halo() const {
   if (world == 1) return 0;
   int h = 0;
@@ -48,7 +79,7 @@ std::vector<StripPlan::Exchange> StripPlan::exchange_rows(int k) const {
   const Rows o = own();
   const int r = reach(k) + (k == 1 ? svgf_pad() : 0);  // iteration 1's variance taps look 3 traced rows further (strips.py)
   auto check = [&](int peer) {
-    const Rows p = bounds(height, world, peer);
+    const Rows p = rows_of(peer);
     if (p.second - p.first < r || o.second - o.first < r)
       throw std::runtime_error("strip shorter than the " + std::to_string(r) + "-row halo of iteration " + std::to_string(k));
   };
@@ -135,13 +166,13 @@ Rows reprojection_rows(const rtpt_ubo& ubo, int width, int height, Rows rows, co
   return {std::max(0, std::min(n0, height)), std::max(0, std::min(n1, height))};
 }
 
-std::vector<std::vector<HistoryOp>> history_exchange_plan(int height, int world, const std::vector<Rows>& needs) {
+std::vector<std::vector<HistoryOp>> history_exchange_plan(int height, int world, const std::vector<Rows>& needs, const std::vector<int>& splits) {
   std::vector<std::vector<HistoryOp>> table(static_cast<size_t>(world));
   for (int r = 0; r < world; r++) {
-    const Rows own_r = StripPlan::bounds(height, world, r);
+    const Rows own_r = StripPlan::bounds(height, world, r, splits);
     for (int q = 0; q < world; q++) {
       if (q == r) continue;
-      const Rows own_q = StripPlan::bounds(height, world, q);
+      const Rows own_q = StripPlan::bounds(height, world, q, splits);
       const int s0 = std::max(own_r.first, needs[q].first), s1 = std::min(own_r.second, needs[q].second);
       if (s1 > s0) table[r].push_back({q, true, {s0, s1}});
       const int g0 = std::max(own_q.first, needs[r].first), g1 = std::min(own_q.second, needs[r].second);

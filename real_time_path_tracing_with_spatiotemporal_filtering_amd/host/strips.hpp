@@ -27,11 +27,17 @@ struct StripPlan {
   int height = 0, world = 1, rank = 0, iterations = 0;
   bool exchange = false;  // halo mode: exchange | redundant
   uint32_t ext_flags = 0; // RTPT_FLAG_EXT_*: the tap-shape modes change how far iteration k reaches
+  std::vector<int> splits;  // empty = equal strips; else world + 1 ascending rows 0 .. height, rank r owns [splits[r], splits[r + 1])
+                            // (strips.py StripPlan.splits; rtpt_app --splits; balanced_splits below moves them)
 
-  static Rows bounds(int height, int world, int rank) {
+  static Rows bounds(int height, int world, int rank, const std::vector<int>& splits = {}) {
+    if (!splits.empty()) return {splits[static_cast<size_t>(rank)], splits[static_cast<size_t>(rank) + 1]};
     return {static_cast<int>(static_cast<int64_t>(rank) * height / world), static_cast<int>(static_cast<int64_t>(rank + 1) * height / world)};
   }
-  Rows own() const { return bounds(height, world, rank); }
+  Rows rows_of(int r) const { return bounds(height, world, r, splits); }
+  Rows own() const { return rows_of(rank); }
+  // throws std::runtime_error unless splits is empty or world + 1 ascending rows from 0 to height
+  void validate() const;
   // rows above/below a pixel that iteration k reads: k for the reference's 3x3 linear-stride taps
   // (temporalFiltering.comp.glsl:135); radius 2 with EXT_GAUSS5, stride 2^(k-1) with EXT_POW2_STRIDE (strips.py: reach)
   int reach(int k) const {
@@ -66,7 +72,13 @@ struct HistoryOp {
   Rows rows;
 };
 // per rank: what it sends of its own strip / receives of the peers' strips so that it holds needs[rank]
-std::vector<std::vector<HistoryOp>> history_exchange_plan(int height, int world, const std::vector<Rows>& needs);
+std::vector<std::vector<HistoryOp>> history_exchange_plan(int height, int world, const std::vector<Rows>& needs, const std::vector<int>& splits = {});
+
+// new strip boundaries from the ranks' measured frame times (strips.py balanced_splits: the same operations in the same
+// order, so both hosts arrive at the same rows): cost[r] = what rank r spent on its rows, spread evenly over them; the
+// boundaries cut the cumulative cost into equal parts; every strip keeps at least min_rows rows.  Apply again to the
+// times measured with the new boundaries — equal times are the fixed point.
+std::vector<int> balanced_splits(const std::vector<int>& splits, const std::vector<double>& cost, int min_rows = 1);
 
 // ---- transports: how rows move between ranks -----------------------------------------------------------------------
 // One message = `bytes` bytes from a device pointer of rank `src` to a device pointer of rank `dst`.  All messages of

@@ -15,6 +15,11 @@ rows of the current colour plane from each neighbour before iteration k:
 
 Both produce the identical frame; the choice is a latency/compute trade (messages are k*W*16 B,
 i.e. latency-bound).
+
+The strips need not be equally tall: ``splits`` (world + 1 ascending row numbers, 0 ... H) replaces the equal division
+where the rows of a frame do not cost the same (the 1.15 M-triangle lattice: paths in the middle of the frame bounce twice
+as often as at its top and bottom; equal strips leave the job at 4.9x of one GPU on eight).  ``balanced_splits`` moves the
+boundaries from the ranks' measured frame times; any division reproduces the single-GPU image bit for bit.
 """
 from __future__ import annotations
 
@@ -29,6 +34,7 @@ class StripPlan:
     iterations: int          # maxWaveletIteration (main.cpp:55)
     mode: str = "exchange"   # "exchange" | "redundant"
     ext_flags: int = 0       # RTPT_FLAG_EXT_* (extension modes change how far the taps of iteration k reach)
+    splits: tuple = ()       # () = equal strips; else world + 1 ascending rows, splits[r] .. splits[r + 1] is rank r's strip
 
     def reach(self, k: int) -> int:
         """rows above/below a pixel that iteration k reads: k for the reference's 3x3 linear-stride taps
@@ -50,15 +56,26 @@ class StripPlan:
             raise ValueError("rank out of range")
         if self.world > self.height:
             raise ValueError("more ranks than rows")
+        if self.splits:
+            sp = tuple(int(v) for v in self.splits)
+            object.__setattr__(self, "splits", sp)
+            if len(sp) != self.world + 1 or sp[0] != 0 or sp[-1] != self.height or any(b <= a for a, b in zip(sp, sp[1:])):
+                raise ValueError(f"splits must be {self.world + 1} ascending rows from 0 to {self.height}, every strip at least one row: {sp}")
 
     # ---- ownership
     @staticmethod
-    def bounds(height: int, world: int, rank: int):
+    def bounds(height: int, world: int, rank: int, splits=()):
+        if splits:
+            return int(splits[rank]), int(splits[rank + 1])
         return (rank * height) // world, ((rank + 1) * height) // world
+
+    def rows_of(self, rank: int):
+        """rows [a, b) rank `rank` owns."""
+        return self.bounds(self.height, self.world, rank, self.splits)
 
     @property
     def own(self):
-        return self.bounds(self.height, self.world, self.rank)
+        return self.rows_of(self.rank)
 
     @property
     def halo(self) -> int:
@@ -116,16 +133,115 @@ class StripPlan:
         up, down = self.neighbours()
         r = self.reach(k) + (self.svgf_pad if k == 1 else 0)   # iteration 1's variance taps look 3 traced rows further
         if up is not None:
-            u0, u1 = self.bounds(self.height, self.world, up)
+            u0, u1 = self.rows_of(up)
             if u1 - u0 < r or o1 - o0 < r:
                 raise ValueError(f"strip shorter than the {r}-row halo of iteration {k}")
             out.append((up, (o0, o0 + r), (o0 - r, o0)))
         if down is not None:
-            d0, d1 = self.bounds(self.height, self.world, down)
+            d0, d1 = self.rows_of(down)
             if d1 - d0 < r or o1 - o0 < r:
                 raise ValueError(f"strip shorter than the {r}-row halo of iteration {k}")
             out.append((down, (o1 - r, o1), (o1, o1 + r)))
         return out
+
+
+def balanced_splits(splits, cost, min_rows: int = 1):
+    """New strip boundaries from the ranks' measured frame times: ``cost[r]`` is what rank r spent on rows
+    [splits[r], splits[r + 1]) (any unit), taken as spread evenly over those rows; the new boundaries cut the resulting
+    piecewise-linear cumulative cost into equal parts.  A strip's time also holds work that does not scale with its rows
+    (the halo rows of the redundant mode, launches), so one application does not land exactly on equal times: apply it
+    again to the times measured with the new boundaries — equal times are its fixed point; two or three rounds settle
+    within a row or two.  Every strip keeps at least ``min_rows`` rows (the exchange mode needs as many as the longest
+    reach).  Pure arithmetic on floats and ints, mirrored by host/strips.cpp balanced_splits (same operations in the
+    same order, so the two hosts agree on the rows)."""
+    sp = [int(v) for v in splits]
+    world = len(sp) - 1
+    if world < 1 or len(cost) != world or any(b <= a for a, b in zip(sp, sp[1:])):
+        raise ValueError("splits must be world + 1 ascending rows and cost one value per rank")
+    if any(not (c > 0.0) for c in cost):
+        raise ValueError("every rank's cost must be positive")
+    height = sp[-1] - sp[0]
+    if world * min_rows > height:
+        raise ValueError("min_rows does not fit the frame")
+    total = 0.0
+    for c in cost:
+        total += float(c)
+    new = [sp[0]]
+    r, acc = 0, 0.0   # acc = cost of the rows above splits[r]
+    for j in range(1, world):
+        target = total * j / world
+        while r < world - 1 and acc + float(cost[r]) < target:
+            acc += float(cost[r])
+            r += 1
+        y = sp[r] + (target - acc) * (sp[r + 1] - sp[r]) / float(cost[r])
+        new.append(int(y + 0.5))
+    new.append(sp[-1])
+    for j in range(1, world):
+        new[j] = max(new[j], new[j - 1] + min_rows)
+    for j in range(world - 1, 0, -1):
+        new[j] = min(new[j], new[j + 1] - min_rows)
+    return tuple(new)
+
+
+class StripBalancer:
+    """Strip boundaries from a per-row cost profile that the ranks' measured frame times keep correcting.
+
+    ``balanced_splits`` spreads a strip's time evenly over its rows.  Where the cost of a row changes faster than a strip is
+    tall — the lattice of configs[4] puts a layer of boxes every ~216 rows of the 4K frame, a strip of an 8-rank job is 270 —
+    that model moves a boundary by 18 rows and finds 0.1 ms behind it (profiles/r04_instanced_balanced_strips.json): the cut
+    oscillates.  Here the shape inside a strip comes from a profile (``profile[y]``: rays traced in row y, measured with the
+    ray counter's row window, rtpt_set_count_rows; ``floor`` = what a row costs besides its rays, in the same unit), and
+    ``update`` rescales the rows of every strip so that they add up to what the strip was measured to take (iterative
+    proportional fitting: the profile keeps its shape inside a strip, the measurements set its level strip by strip).
+    Plain float arithmetic in a fixed order: every rank computes the same rows from the same gathered numbers."""
+
+    def __init__(self, height: int, world: int, min_rows: int = 1, profile=None, floor: float = 0.0):
+        if world < 1 or world * min_rows > height:
+            raise ValueError("min_rows does not fit the frame")
+        self.height, self.world, self.min_rows = int(height), int(world), int(min_rows)
+        if profile is None:
+            self.density = [1.0] * self.height
+        else:
+            if len(profile) != self.height:
+                raise ValueError("one profile value per row")
+            self.density = [float(v) + float(floor) for v in profile]
+            if any(not (v > 0.0) for v in self.density):
+                raise ValueError("every row must cost something (raise `floor`)")
+
+    def update(self, splits, cost):
+        """the ranks' measured times for the strips `splits`: rows [splits[r], splits[r + 1]) took cost[r]"""
+        sp = [int(v) for v in splits]
+        if len(sp) != self.world + 1 or len(cost) != self.world or sp[0] != 0 or sp[-1] != self.height or \
+                any(b <= a for a, b in zip(sp, sp[1:])) or any(not (c > 0.0) for c in cost):
+            raise ValueError("splits must be world + 1 ascending rows from 0 to height and cost one positive value per rank")
+        d = self.density
+        for r in range(self.world):
+            s = 0.0
+            for y in range(sp[r], sp[r + 1]):
+                s += d[y]
+            f = float(cost[r]) / s
+            for y in range(sp[r], sp[r + 1]):
+                d[y] *= f
+
+    def splits(self):
+        """world + 1 rows cutting the profile's cumulative cost into equal parts (each cut at the nearer row)"""
+        d, world = self.density, self.world
+        total = 0.0
+        for v in d:
+            total += v
+        new, y, acc = [0], 0, 0.0
+        for j in range(1, world):
+            target = total * j / world
+            while y < self.height - 1 and acc + d[y] <= target:
+                acc += d[y]
+                y += 1
+            new.append(y + 1 if target - acc > 0.5 * d[y] else y)
+        new.append(self.height)
+        for j in range(1, world):
+            new[j] = max(new[j], new[j - 1] + self.min_rows)
+        for j in range(world - 1, 0, -1):
+            new[j] = min(new[j], new[j + 1] - self.min_rows)
+        return tuple(new)
 
 
 def _post(sends, recvs, group=None):
@@ -227,12 +343,12 @@ def reprojection_rows(ubo, width: int, height: int, rows, bounds, z_near: float 
     return max(0, min(n0, height)), max(0, min(n1, height))
 
 
-def history_exchange_plan(height: int, world: int, needs):
+def history_exchange_plan(height: int, world: int, needs, splits=()):
     """needs[q] = (a, b): previous-frame rows rank q's final pass can fetch.  Returns, per rank r,
     [(peer, 'send' | 'recv', (y0, y1))] — r sends the part of ITS OWN rows that peer needs, receives the part of the
     peer's rows it needs itself.  Every rank computes the same table from the same camera matrices: no negotiation."""
     table = [[] for _ in range(world)]
-    own = [StripPlan.bounds(height, world, r) for r in range(world)]
+    own = [StripPlan.bounds(height, world, r, splits) for r in range(world)]
     for r in range(world):
         for q in range(world):
             if q == r:
@@ -255,7 +371,7 @@ def exchange_history(plan: StripPlan, needs, prev_rows_view, full, group=None) -
     if b > a:
         full[a:b].copy_(prev_rows_view(a, b))
     sends, recvs, sent = [], [], 0
-    for peer, what, (y0, y1) in history_exchange_plan(plan.height, plan.world, needs)[r]:
+    for peer, what, (y0, y1) in history_exchange_plan(plan.height, plan.world, needs, plan.splits)[r]:
         if what == "send":
             t = prev_rows_view(y0, y1)
             sent += t.numel() * t.element_size()
@@ -284,7 +400,7 @@ def gather_frame(plan: StripPlan, mine, full, root: int = 0, group=None) -> int:
         recvs = []
         for r in range(plan.world):
             if r != root:
-                a, b = StripPlan.bounds(plan.height, plan.world, r)
+                a, b = plan.rows_of(r)
                 recvs.append((full[a:b], r))
         _post([], recvs, group)
         return sum(t.numel() * t.element_size() for t, _ in recvs)

@@ -56,6 +56,28 @@ def test_default_line_carries_the_stress_configuration_and_both_cpu_baselines(hi
     assert "cornell-1080p-1spp-4seg-5atrous" in d["also"]
 
 
+def test_balanced_strips_render_the_same_frames(hip_lib):
+    """--balance (the ranks gather their own frame times and re-cut the strips, strips.balanced_splits) and --splits: the job
+    reports its rows, they are a valid division of the frame, and the frames are the ones equal strips render (ray count).
+    --emulate-balance runs the same procedure with the strips of an N-rank job one after the other on this GPU."""
+    base = [sys.executable, "bench.py", "--workload", "1080p", "--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--no-secondary",
+            "--prewarm-seconds", "0"]
+    one = _run(base)
+    run2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(_port())] + base[1:] + ["--gpus", "2", "--rehearse-on-one-gpu"]
+    two = _run(run2 + ["--balance", "2"])
+    rows = two["strip_rows"]
+    assert rows[0] == 0 and rows[-1] == 1080 and len(rows) == 3 and 15 <= rows[1] <= 1065
+    assert two["rays_per_frame"] == one["rays_per_frame"]
+    fixed = _run(run2 + ["--splits", "0,700,1080"])
+    assert fixed["strip_rows"] == [0, 700, 1080] and fixed["rays_per_frame"] == one["rays_per_frame"]
+    em = _run(base + ["--emulate-balance", "3:1"])
+    assert em["emulated_balance"] == 3 and len(em["rounds"]) == 2
+    for r in em["rounds"]:
+        assert r["strip_rows"][0] == 0 and r["strip_rows"][-1] == 1080 and len(r["ms_per_strip"]) == 3 and r["slowest"] == max(r["ms_per_strip"])
+    assert em["rounds"][0]["strip_rows"] == [0, 360, 720, 1080]
+
+
 @pytest.mark.parametrize("halo", ["redundant", "exchange"])
 def test_two_rank_rehearsal_counts_the_same_rays(hip_lib, halo):
     one = _run([sys.executable, "bench.py", "--workload", "1080p", "--steps", "6", "--warmup", "1", "--no-cpu-baseline",

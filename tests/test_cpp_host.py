@@ -61,19 +61,21 @@ def test_cpp_host_equals_python_host(app_binary, hip_lib, tmp_path, in_flight):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks,halo", [(2, "redundant"), (2, "exchange"), (3, "exchange"), (4, "redundant")])
-def test_cpp_host_strips_equal_python_single_context(app_binary, hip_lib, tmp_path, ranks, halo):
+@pytest.mark.parametrize("ranks,halo,splits", [(2, "redundant", ""), (2, "exchange", ""), (3, "exchange", ""), (4, "redundant", ""),
+                                               (3, "exchange", "0,20,88,121"), (4, "redundant", "0,40,49,100,121")])
+def test_cpp_host_strips_equal_python_single_context(app_binary, hip_lib, tmp_path, ranks, halo, splits):
     """--ranks R without --rank: R strip contexts in one process on one GPU, the transport's messages are device copies
     (with --rank each strip is a process on its own GPU and the same messages are ncclSend/ncclRecv).  Halo rows per
     iteration (exchange) or redundant rows, and the previous frame's bands under vertical camera moves (E, Q): the
-    assembled frame must equal the single-context Python host's, bit for bit, and so must the ray count."""
+    assembled frame must equal the single-context Python host's, bit for bit, and so must the ray count.  `splits`: strips of
+    different heights (--splits)."""
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
     W, H, SEG, N = 160, 121, 3, 5
     keys = ["", "E", "J", "QA", "", "E"]
     pfm = tmp_path / "strips.pfm"
     out = subprocess.run([app_binary, "--width", str(W), "--height", str(H), "--segments", str(SEG), "--iterations", str(N),
                           "--frames", str(len(keys)), "--script", ",".join(keys), "--dump", str(pfm),
-                          "--ranks", str(ranks), "--halo", halo],
+                          "--ranks", str(ranks), "--halo", halo] + (["--splits", splits] if splits else []),
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     stats = json.loads(out.stdout.strip().splitlines()[-1])
@@ -171,8 +173,9 @@ def test_cpp_host_rccl_rendezvous_ignores_a_stale_id_and_never_hangs(app_binary,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks,halo,present", [(1, "redundant", "rgba8"), (3, "redundant", "rgba8"), (4, "exchange", "f32")])
-def test_cpp_host_presents_the_assembled_frame(app_binary, hip_lib, oracle, tmp_path, ranks, halo, present):
+@pytest.mark.parametrize("ranks,halo,present,splits", [(1, "redundant", "rgba8", ""), (3, "redundant", "rgba8", ""), (4, "exchange", "f32", ""),
+                                                       (3, "redundant", "rgba8", "0,61,80,121")])
+def test_cpp_host_presents_the_assembled_frame(app_binary, hip_lib, oracle, tmp_path, ranks, halo, present, splits):
     """--present: main.cpp:1338-1361 in the C++ host.  One context converts its frame with rtpt_present; with --ranks the
     presenting rank's swapchain image is assembled from every strip (converted rows, or float rows) on the present
     stream.  The last image equals the Python single-context frame (through the oracle's restatement of the blit)."""
@@ -183,7 +186,7 @@ def test_cpp_host_presents_the_assembled_frame(app_binary, hip_lib, oracle, tmp_
     cmd = [app_binary, "--width", str(W), "--height", str(H), "--segments", str(SEG), "--iterations", str(N), "--frames", str(len(keys)),
            "--script", ",".join(keys), "--present", present, "--dump-present", str(raw)]
     if ranks > 1:
-        cmd += ["--ranks", str(ranks), "--halo", halo]
+        cmd += ["--ranks", str(ranks), "--halo", halo] + (["--splits", splits] if splits else [])
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     app = make_app(W, H, max_segments=SEG, iterations=N)
@@ -216,8 +219,9 @@ def test_cpp_host_present_with_two_frames_in_flight_and_odd_sizes(app_binary, hi
     assert np.fromfile(raw, np.uint8).tobytes() == oracle.present_bgra8(want).tobytes()
 
 
-@pytest.mark.parametrize("halo,flags", [("redundant", 0), ("exchange", 0), ("redundant", 0x900), ("exchange", 0x960)])
-def test_cpp_strip_plan_and_history_bands_equal_the_python_mirror(app_binary, halo, flags):
+@pytest.mark.parametrize("halo,flags,splits", [("redundant", 0, ()), ("exchange", 0, ()), ("redundant", 0x900, ()), ("exchange", 0x960, ()),
+                                               ("redundant", 0, (0, 31, 120, 150, 217)), ("exchange", 0x900, (0, 80, 100, 190, 217))])
+def test_cpp_strip_plan_and_history_bands_equal_the_python_mirror(app_binary, halo, flags, splits):
     """host-only (no GPU): `rtpt_app --plan-only` prints the C++ host's strip plan and, per scripted frame, the
     previous-frame rows every rank's final pass can reach (host/strips.cpp); the Python mirror (strips.py), which the gloo
     tests exercise end to end, must produce the same rows — same ownership, same halos, same reprojection bound."""
@@ -229,12 +233,14 @@ def test_cpp_strip_plan_and_history_bands_equal_the_python_mirror(app_binary, ha
     W, H, N, R = 333, 217, 5, 4
     keys = ["", "E", "E", "D", "QS", "", "W"]
     out = subprocess.run([app_binary, "--plan-only", "--width", str(W), "--height", str(H), "--iterations", str(N), "--ranks", str(R),
-                          "--halo", halo, "--frames", str(len(keys)), "--script", ",".join(keys), "--flags", hex(flags)],
+                          "--halo", halo, "--frames", str(len(keys)), "--script", ",".join(keys), "--flags", hex(flags)] +
+                         (["--splits", ",".join(map(str, splits))] if splits else []),
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     plan = json.loads(out.stdout)
+    assert plan["splits"] == [StripPlan.bounds(H, R, r, splits)[0] for r in range(R)] + [H]
     for r, p in enumerate(plan["ranks"]):
-        sp = StripPlan(H, R, r, N, halo, flags)
+        sp = StripPlan(H, R, r, N, halo, flags, splits)
         assert tuple(p["own"]) == sp.own and tuple(p["stored"]) == sp.stored and tuple(p["raytrace"]) == sp.raytrace_rows()
         assert [tuple(x) for x in p["filter"]] == [sp.filter_rows(k) for k in range(1, N + 1)]
     app = PathTracingApplication(Recorder(), W, H, N)
@@ -243,12 +249,36 @@ def test_cpp_strip_plan_and_history_bands_equal_the_python_mirror(app_binary, ha
     moved_any = False
     for f, k in enumerate(keys):
         app.updateScene(tuple(k))
-        needs = [list(reprojection_rows(app.ubo, W, H, StripPlan.bounds(H, R, r), app.sceneBounds, app.z_near)) for r in range(R)]
+        needs = [list(reprojection_rows(app.ubo, W, H, StripPlan.bounds(H, R, r, splits), app.sceneBounds, app.z_near)) for r in range(R)]
         assert plan["frames"][f]["needs"] == needs, (f, k)
         assert plan["frames"][f]["moved"] == (f > 0 and not app._camera_static())
         moved_any |= plan["frames"][f]["moved"]
         app.frameCount += 1
     assert moved_any
+
+
+def test_cpp_balanced_splits_equal_the_python_mirror(app_binary):
+    """host-only: the boundaries the C++ host derives from the ranks' frame times (host/strips.cpp balanced_splits, printed by
+    --plan-only --balance) are the Python mirror's, for measured and for random times, from equal and from unequal strips"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripPlan, balanced_splits
+    rng = np.random.default_rng(11)
+    cases = [(2160, 8, 5, "redundant", (), [0.4063, 0.6799, 0.686, 0.5498, 0.5539, 0.6709, 0.6652, 0.3998])]
+    for _ in range(12):
+        H, R = int(rng.integers(200, 2200)), int(rng.integers(2, 9))
+        halo = ("redundant", "exchange")[int(rng.integers(0, 2))]
+        splits = ()
+        if rng.integers(0, 2):
+            cuts = sorted(int(v) for v in rng.choice(np.arange(1, H // 20), R - 1, replace=False) * 20)
+            splits = (0, *cuts, H)
+        cases.append((H, R, 5, halo, splits, [float(v) for v in rng.uniform(0.05, 3.0, R)]))
+    for H, R, N, halo, splits, cost in cases:
+        out = subprocess.run([app_binary, "--plan-only", "--width", "64", "--height", str(H), "--iterations", str(N), "--ranks", str(R),
+                              "--halo", halo, "--frames", "1", "--balance", ",".join(repr(c) for c in cost)] +
+                             (["--splits", ",".join(map(str, splits))] if splits else []), capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        cur = tuple(StripPlan.bounds(H, R, r, splits)[0] for r in range(R)) + (H,)
+        want = balanced_splits(cur, cost, max(1, StripPlan(H, R, 0, N, halo).halo))
+        assert tuple(json.loads(out.stdout)["balanced"]) == want, (H, R, halo, splits, cost)
 
 
 def _lattice_args(lattice, tess):

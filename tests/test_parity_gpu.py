@@ -561,6 +561,9 @@ def test_strips_equal_single_frame(hip_lib, oracle, cornell, mode):
     keys = [(), (), ("E",), ("Q", "A")]   # vertical camera moves: the reprojected pixel leaves the strip
     for R in (2, 3):
         _strips_vs_single(96, 72, 3, 5, R, mode, 0, keys)
+    # strips of different heights (StripPlan.splits; what strips.balanced_splits hands out)
+    _strips_vs_single(96, 72, 3, 5, 3, mode, 0, keys, splits=(0, 11, 50, 72))
+    _strips_vs_single(130, 121, 3, 5, 4, mode, 0x900, keys, splits=(0, 40, 49, 100, 121))
 
 
 def test_strips_seeded_sweep(hip_lib):

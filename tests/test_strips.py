@@ -224,6 +224,126 @@ W, H, SEG, N, FRAMES = 48, 40, 2, 5, 5
 KEYS = [(), ("J",), ("D",), ("E",), ()]   # light move, lateral and VERTICAL camera moves (history crosses strips), rest
 
 
+# ------------------------------------------------------------------------------ unequal strips
+@pytest.mark.parametrize("mode", ["exchange", "redundant"])
+def test_unequal_strips_cover_the_frame_and_keep_the_halo_rules(mode):
+    rng = np.random.default_rng(5)
+    for H, R, N in [(2160, 8, 5), (97, 3, 5), (800, 5, 9)]:
+        for _ in range(20):
+            cuts = sorted(rng.choice(np.arange(1, H // N), R - 1, replace=False) * N)   # every strip at least N rows
+            splits = (0, *map(int, cuts), H)
+            if min(b - a for a, b in zip(splits, splits[1:])) < N:
+                continue
+            plans = [StripPlan(H, R, r, N, mode, 0, splits) for r in range(R)]
+            rows = []
+            for r, p in enumerate(plans):
+                assert p.own == (splits[r], splits[r + 1]) == p.rows_of(r)
+                o0, o1 = p.own
+                s0, s1 = p.stored
+                assert 0 <= s0 <= o0 < o1 <= s1 <= H
+                rows += list(range(o0, o1))
+                prev = p.raytrace_rows()
+                for k in range(1, N + 1):
+                    f0, f1 = p.filter_rows(k)
+                    assert s0 <= max(0, f0 - k) and min(H, f1 + k) <= s1
+                    if mode == "redundant":
+                        assert prev[0] <= max(0, f0 - k) and min(H, f1 + k) <= prev[1]
+                        prev = (f0, f1)
+            assert rows == list(range(H))
+            if mode == "exchange":   # what one rank sends its neighbour is what the neighbour expects
+                for k in range(1, N + 1):
+                    ex = [p.exchange_rows(k) for p in plans]
+                    for r in range(R):
+                        for peer, send, recv in ex[r]:
+                            back = [e for e in ex[peer] if e[0] == r]
+                            assert len(back) == 1 and back[0][2] == send and back[0][1] == recv
+    for bad in [(0, 10, 10, 40), (0, 30, 20, 40), (1, 20, 30, 40), (0, 20, 30, 41), (0, 20, 40)]:
+        with pytest.raises(ValueError):
+            StripPlan(40, 3, 0, 5, "redundant", 0, bad)
+
+
+def test_balanced_splits_known_answers_and_fixed_point():
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import balanced_splits
+    eq = (0, 270, 540, 810, 1080, 1350, 1620, 1890, 2160)
+    assert balanced_splits(eq, [1.0] * 8) == eq and balanced_splits(eq, [0.37] * 8) == eq     # equal times: nothing moves
+    # the eight strips of the 1.15 M-triangle frame measured alone (profiles/r04_instanced_emulated_strips.json)
+    ms = [0.4063, 0.6799, 0.686, 0.5498, 0.5539, 0.6709, 0.6652, 0.3998]
+    assert balanced_splits(eq, ms) == (0, 338, 566, 793, 1072, 1353, 1585, 1818, 2160)
+    # two ranks, the lower half three times as dear: the cut moves to where the cumulative cost is half
+    assert balanced_splits((0, 50, 100), [1.0, 3.0]) == (0, 67, 100)
+    assert balanced_splits((0, 50, 100), [1.0, 3.0], min_rows=40) == (0, 60, 100)
+    assert balanced_splits((0, 50, 100), [1e-9, 1.0], min_rows=10) == (0, 75, 100)
+    for bad in [((0, 50, 100), [1.0]), ((0, 50, 100), [1.0, 0.0]), ((0, 50, 100), [1.0, float("nan")]), ((0, 60, 50), [1.0, 1.0])]:
+        with pytest.raises(ValueError):
+            balanced_splits(*bad)
+    with pytest.raises(ValueError):
+        balanced_splits((0, 50, 100), [1.0, 1.0], min_rows=51)
+
+
+def test_balanced_splits_settle_on_equal_times():
+    """a frame whose rows cost what a smooth profile says, plus a fixed cost per strip and the halo rows of the redundant mode:
+    three rounds bring the slowest strip within 2 % of the mean"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import balanced_splits
+    H, R, N = 2160, 8, 5
+    y = np.arange(H)
+    density = 1.0 + 0.8 * np.sin(np.pi * y / H) ** 2 + 0.3 * (y > 1500)
+    def times(splits):
+        out = []
+        for r in range(R):
+            t0, t1 = StripPlan(H, R, r, N, "redundant", 0, splits).raytrace_rows()
+            out.append(40.0 + float(density[t0:t1].sum()))
+        return out
+    splits = tuple(StripPlan.bounds(H, R, r)[0] for r in range(R)) + (H,)
+    first = times(splits)
+    assert max(first) / (sum(first) / R) > 1.15
+    for _ in range(3):
+        splits = balanced_splits(splits, times(splits), 15)
+    t = times(splits)
+    assert max(t) / (sum(t) / R) < 1.02 and max(t) < 0.9 * max(first)
+
+
+def test_strip_balancer_follows_a_profile_the_strips_cannot_resolve():
+    """rows whose cost changes faster than a strip is tall (a layer of boxes every 216 rows, strips of 270): spreading a strip's
+    time evenly over its rows stalls ~5 % above the mean; with the per-row ray profile (noisy: measured on other frames) and the
+    measured times correcting its level, the slowest strip comes within 2 %"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripBalancer, balanced_splits
+    H, R, N = 2160, 8, 5
+    y = np.arange(H)
+    density = 1.0 + 2.5 * (np.sin(2 * np.pi * y / 216.0) > 0.6) + 0.8 * np.sin(np.pi * y / H) ** 2
+    def times(splits):
+        out = []
+        for r in range(R):
+            t0, t1 = StripPlan(H, R, r, N, "redundant", 0, splits).raytrace_rows()
+            out.append(40.0 + float(density[t0:t1].sum()))
+        return out
+    def spread(splits):
+        t = times(splits)
+        return max(t) / (sum(t) / R)
+    equal = tuple(StripPlan.bounds(H, R, r)[0] for r in range(R)) + (H,)
+    plain = equal
+    for _ in range(4):
+        plain = balanced_splits(plain, times(plain), 15)
+    prof = density * (1 + 0.05 * np.random.default_rng(0).standard_normal(H))
+    bal = StripBalancer(H, R, 15, profile=prof, floor=0.1)
+    rows = bal.splits()
+    first = spread(rows)
+    for _ in range(3):
+        bal.update(rows, times(rows))
+        rows = bal.splits()
+        assert rows[0] == 0 and rows[-1] == H and min(b - a for a, b in zip(rows, rows[1:])) >= 15
+    assert spread(equal) > 1.2 and first < 1.08 and spread(rows) < 1.02 < spread(plain)
+    # without a profile it is the same model as balanced_splits, at whole rows
+    flat = StripBalancer(100, 2)
+    flat.update((0, 50, 100), [1.0, 3.0])
+    assert flat.splits() == (0, 67, 100) == balanced_splits((0, 50, 100), [1.0, 3.0])
+    assert StripBalancer(100, 4).splits() == (0, 25, 50, 75, 100)
+    for bad in [dict(height=10, world=3, min_rows=4), dict(height=10, world=2, profile=[1.0] * 9), dict(height=4, world=2, profile=[1, 0, 1, 1])]:
+        with pytest.raises(ValueError):
+            StripBalancer(**bad)
+    with pytest.raises(ValueError):
+        flat.update((0, 50, 100), [1.0, 0.0])
+
+
 def _model(f):
     """animated ubo.model for frame f (column-major): the scene bobs up and down and shears a little, so pixels
     reproject across strip borders while the camera rests"""
@@ -233,7 +353,7 @@ def _model(f):
     return np.ascontiguousarray(m.T).ravel()
 
 
-def _run_rank(rank, world, mode, port, out_dir, ext=0, in_flight=1, present=None, animate=False):
+def _run_rank(rank, world, mode, port, out_dir, ext=0, in_flight=1, present=None, animate=False, splits=()):
     import sys
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -241,7 +361,7 @@ def _run_rank(rank, world, mode, port, out_dir, ext=0, in_flight=1, present=None
     O.set_threads(2)
     if world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    plan = StripPlan(H, world, rank, N, mode, ext)
+    plan = StripPlan(H, world, rank, N, mode, ext, tuple(splits) if world > 1 else ())
     if in_flight == 2:
         from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import PipelinedBackend
         be = PipelinedBackend([OracleBackend(O, W, H, SEG, plan), OracleBackend(O, W, H, SEG, plan)])
@@ -262,7 +382,7 @@ def _run_rank(rank, world, mode, port, out_dir, ext=0, in_flight=1, present=None
             img = app.presented_image()
             shown.append(img.numpy().copy() if img is not None else last.final_image().copy())
     rays = sum(b.rays for b in be.be) if in_flight == 2 else be.rays
-    tag = ("p" if in_flight == 2 else "") + (present or "") + ("anim" if animate else "")
+    tag = ("p" if in_flight == 2 else "") + (present or "") + ("anim" if animate else "") + ("uneq" if splits else "")
     np.savez(os.path.join(out_dir, f"{mode}{ext}{tag}_{world}_{rank}.npz"), *frames, rays=np.array([rays]),
              **{f"shown_{i}": a for i, a in enumerate(shown)})
     if world > 1:
@@ -291,6 +411,25 @@ def test_gloo_ranks_reproduce_the_single_rank_frame(tmp_path, oracle, world, mod
         got = np.concatenate([p[f"arr_{f}"] for p in parts], axis=0)
         assert got.shape == want.shape == (H, W, 4)
         assert got.tobytes() == want.tobytes(), f"frame {f}: strips differ from the single-rank frame"
+    assert sum(int(p["rays"][0]) for p in parts) == int(ref["rays"][0])
+
+
+@pytest.mark.parametrize("world,mode,splits,present", [(3, "exchange", (0, 9, 27, 40), "f32"), (2, "redundant", (0, 29, 40), None)])
+def test_gloo_ranks_with_unequal_strips(tmp_path, oracle, world, mode, splits, present):
+    """strips of different heights (StripPlan.splits): halo exchange, the history bands of the frames in which the camera
+    moves, and the presenting rank's gather all follow the same rows"""
+    import torch.multiprocessing as mp
+    _run_rank(0, 1, mode, 0, str(tmp_path), 0, 1, present)
+    mp.spawn(_run_rank, args=(world, mode, _free_port(), str(tmp_path), 0, 1, present, False, splits), nprocs=world, join=True)
+    ref = np.load(tmp_path / f"{mode}0{present or ''}_1_0.npz")
+    parts = [np.load(tmp_path / f"{mode}0{present or ''}uneq_{world}_{r}.npz") for r in range(world)]
+    for f in range(FRAMES):
+        want = ref[f"arr_{f}"]
+        assert [p[f"arr_{f}"].shape[0] for p in parts] == [b - a for a, b in zip(splits, splits[1:])]
+        got = np.concatenate([p[f"arr_{f}"] for p in parts], axis=0)
+        assert got.tobytes() == want.tobytes(), f"frame {f}: unequal strips differ from the single-rank frame"
+        if present:
+            assert parts[0][f"shown_{f}"].tobytes() == ref[f"shown_{f}"].tobytes(), f"frame {f}: presented image"
     assert sum(int(p["rays"][0]) for p in parts) == int(ref["rays"][0])
 
 
