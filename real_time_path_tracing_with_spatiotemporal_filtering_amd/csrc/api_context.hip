@@ -335,9 +335,14 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
   if (const char* v = std::getenv("RTPT_HOST_REFIT")) c->host_refit = std::atoi(v) != 0;
   if (const char* v = std::getenv("RTPT_NO_TRACE_FUSION")) c->fuse_trace = std::atoi(v) == 0;
   if (const char* v = std::getenv("RTPT_TRACE_POOL")) c->trace_pool = std::atoi(v) != 0;
+  if (const char* v = std::getenv("RTPT_PT_WINDOW")) c->trace_window = static_cast<uint32_t>(std::max(0, std::atoi(v)));
   if (const char* v = std::getenv("RTPT_CHAIN_G1")) c->filter_policy.chain_g_pin = std::atoi(v);
   if (const char* v = std::getenv("RTPT_CHAIN_GENERIC")) c->filter_policy.chain_generic = std::atoi(v);
   if (const char* v = std::getenv("RTPT_CHAIN_WG_PER_CU")) c->filter_policy.chain_wg_per_cu = std::atoi(v);
+  if (const char* v = std::getenv("RTPT_CHAIN_SKEW")) {
+    c->filter_policy.chain_skew = c->filter_policy.chain_skew2 = std::atoi(v);
+    if (const char* comma = std::strchr(v, ',')) c->filter_policy.chain_skew2 = std::atoi(comma + 1);
+  }
   if (const char* v = std::getenv("RTPT_CHAIN_SW")) c->filter_policy.chain_sw = std::atoi(v);
   if (const char* v = std::getenv("RTPT_CHAIN_SW_G1")) c->filter_policy.chain_sw_g1 = std::atoi(v);
   if (const char* v = std::getenv("RTPT_CHAIN_SW_G3")) c->filter_policy.chain_sw_g3 = std::atoi(v);

@@ -141,6 +141,9 @@ struct rtpt_ctx {
   // K2 of scenes whose BVH is built over fan pairs as the path-pool kernel (kernels.hip: k_pathtrace_pool): RTPT_TRACE_POOL
   // (read at rtpt_create); path_pool = the workgroups' slabs, allocated on first use
   bool trace_pool = false;
+  // segments of a path the tile kernel runs before the survivors go through the queue kernels (kernels.hpp: pt_first_window is
+  // the default); RTPT_PT_WINDOW at rtpt_create, 0 = the default
+  uint32_t trace_window = 0;
   Buf path_pool;
   rt::FilterPolicy filter_policy;  // RTPT_CHAIN_* (read once, here: rtpt_create)
   // K3 iterations recorded by rtpt_temporal_filter and not launched yet (see filter_flush)

@@ -248,7 +248,9 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
     if (need && c->path_pool.bytes < need && (rc = alloc_buf(c->path_pool, need))) return rc;
     a.pool_slab = need ? c->path_pool.ptr : nullptr;
   }
-  if (a.compact && a.spp == 1 && a.max_segments > rt::pt_first_window(c->use_bvh) && !(c->cfg.flags & RTPT_FLAG_SINGLE_LAUNCH_PATHS)) {
+  const uint32_t window = c->trace_window ? c->trace_window : rt::pt_first_window(c->use_bvh);
+  a.first_window = window;
+  if (a.compact && a.spp == 1 && a.max_segments > window && !(c->cfg.flags & RTPT_FLAG_SINGLE_LAUNCH_PATHS)) {
     // a region holds the survivors of ceil(workgroups / kPathQueues) workgroups of 256 paths (kernels.hip); the
     // second buffer is only needed when a third segment window exists
     const size_t blocks = ((static_cast<size_t>(c->cfg.width) + 63) / 64) * ((c->rows() + 3) / 4);
@@ -256,7 +258,7 @@ int rtpt_raytrace(rtpt_ctx* c, const rtpt_push_constants* pc, uint32_t y0, uint3
     const size_t cap = region * rt::kPathQueues;
     if (!c->path_queue_count.ptr && (rc = alloc_buf(c->path_queue_count, 2 * rt::kPathQueues * sizeof(uint32_t)))) return rc;
     if (!c->path_queue[0].ptr && (rc = alloc_buf(c->path_queue[0], cap * 48))) return rc;
-    if (a.max_segments > 2u * rt::pt_first_window(c->use_bvh) && !c->path_queue[1].ptr && (rc = alloc_buf(c->path_queue[1], cap * 48))) return rc;
+    if (a.max_segments > 2u * window && !c->path_queue[1].ptr && (rc = alloc_buf(c->path_queue[1], cap * 48))) return rc;
     a.queue[0] = c->path_queue[0].ptr;
     a.queue[1] = c->path_queue[1].ptr;
     a.queue_count = static_cast<uint32_t*>(c->path_queue_count.ptr);

@@ -21,8 +21,20 @@
 #include "device_common.hpp"
 #include "lds_dma.hpp"
 
+#ifndef RTPT_TILE_TIMELINE
+#define RTPT_TILE_TIMELINE 0  // timeline build (scripts/tile_timeline.py): when the workgroups of the single-pass launches lived
+#endif
+
 namespace rt {
 namespace {
+
+#if RTPT_TILE_TIMELINE
+#define RTPT_SPAN_SLOTS 2  // k_atrous_comb_sh: an iteration k < N, the final pass
+#define RTPT_SPAN_READER rtpt_debug_comb_span
+#define RTPT_SPAN_DEVICE
+#include "experiments/span_instrumentation.inc"
+#undef RTPT_SPAN_DEVICE
+#endif
 
 // main.cpp:1338-1361 vkCmdBlitImage image (RGBA32F) -> swapchain image (B8G8R8A8_UNORM): the float -> UNORM
 // conversion clamps to [0,1] and quantises; defined here as trunc(x*255 + 0.5) with separate multiply and add (the
@@ -439,6 +451,9 @@ __attribute__((amdgpu_waves_per_eu(FINAL && NRM && R == 1 && !EXTA && !VAR && !E
 #endif
 void k_atrous_comb_sh(AtrousArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+#if RTPT_TILE_TIMELINE
+  SpanScope span_(FINAL ? 1u : 0u, false);
+#endif
   const int W = a.g.W, H = a.g.H, k = a.stride;  // a.stride == a.k (main.cpp:1259-1260, :135) unless POW2_STRIDE
   constexpr int rows = kShWaves * kCombM + 2 * R, cells = rows * CWp;  // block-shared rows
   const int NP = NRM ? 0 : static_cast<int>(a.n_tris) + 1;
@@ -763,6 +778,12 @@ __global__ __launch_bounds__(kThreads) void k_present(FrameGeom g, const float4*
 }
 
 }  // namespace
+
+#if RTPT_TILE_TIMELINE
+#define RTPT_SPAN_HOST
+#include "experiments/span_instrumentation.inc"
+#undef RTPT_SPAN_HOST
+#endif
 
 void launch_present(const FrameGeom& g, const float4* image, uint32_t* dst, hipStream_t s) {
   if (g.y1 <= g.y0) return;

@@ -31,8 +31,20 @@
 
 #include <type_traits>
 
+#ifndef RTPT_TILE_TIMELINE
+#define RTPT_TILE_TIMELINE 0  // timeline build (scripts/tile_timeline.py): when the workgroups of a launch lived, one workgroup's steps
+#endif
+
 namespace rt {
 namespace {
+
+#if RTPT_TILE_TIMELINE
+#define RTPT_SPAN_SLOTS 4  // pair (1,2), pair (3,4) / any other first stride, the same two as the FINAL pass of a frame
+#define RTPT_SPAN_READER rtpt_debug_chain_span
+#define RTPT_SPAN_DEVICE
+#include "experiments/span_instrumentation.inc"
+#undef RTPT_SPAN_DEVICE
+#endif
 
 #ifndef RTPT_CHAIN_G
 #define RTPT_CHAIN_G 3
@@ -48,6 +60,14 @@ constexpr int kChP = RTPT_CHAIN_P;  // steps between staging an input row and it
                                     // averaged): 1: 100.7 us, 2: 103.6, 3: 104.1 — with two workgroups per CU the other one's
                                     // arithmetic already covers the DMA flight, and every extra step costs G ring rows of LDS
 constexpr int kChCols = 128;        // columns a level computes at most: two waves per row
+constexpr int kChMaxSegs = 127;     // row segments a launch can give individual heights (ChainSegs; more: equal heights)
+
+// first row (relative to the launch's first row) of every row segment; start[n_segs] = the row count.  n = 0: equal segments
+// of AtrousArgs::seg_rows rows.
+struct ChainSegs {
+  uint16_t n;
+  uint16_t start[kChMaxSegs + 1];
+};
 
 __device__ __forceinline__ int posmod(int n, int r) {
   int m = n % r;
@@ -58,7 +78,7 @@ __device__ __forceinline__ int posmod(int n, int r) {
 // base plus an immediate: the generic form spends 40 of its 157 VALU per wave and step on tap addresses, and the kernel is
 // bound by VALU issue.  The shipping pairs (1,2) and (3,4) are instantiated with K0 = 1 and 3.
 template <int L, bool FINAL, bool EXACT, int G, int K0>
-__global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
+__global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a, ChainSegs sg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int W = a.g.W, H = a.g.H;
   const int lane = static_cast<int>(threadIdx.x);
@@ -96,11 +116,15 @@ __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
   const uint32_t per_xcd = (nb + 7u) >> 3;
   const uint32_t lb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
   if (lb >= nb) return;  // block-uniform, before any barrier
+#if RTPT_TILE_TIMELINE
+  SpanScope span_((a.k == 1 ? 0u : 1u) + (FINAL ? 2u : 0u), lb == nb / 2);
+#endif
   const int seg = static_cast<int>(lb / static_cast<uint32_t>(a.n_strips));
   const int strip = static_cast<int>(lb - static_cast<uint32_t>(seg) * static_cast<uint32_t>(a.n_strips));
   const int x0 = strip * bw;
-  const int ya = a.g.y0 + seg * a.seg_rows;
-  const int yb = ya + a.seg_rows < a.g.y1 ? ya + a.seg_rows : a.g.y1;
+  const int ya = a.g.y0 + (sg.n ? static_cast<int>(sg.start[seg]) : seg * a.seg_rows);
+  const int yb_ = sg.n ? a.g.y0 + static_cast<int>(sg.start[seg + 1]) : ya + a.seg_rows;
+  const int yb = yb_ < a.g.y1 ? yb_ : a.g.y1;
   if (ya >= yb) return;
   // rows every level must produce for this segment (frame clamp of the taps, :136), and the input rows to stage
   int lo[L], hi[L];
@@ -166,6 +190,9 @@ __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
   int slot_in = srow % R[0];  // ring slot of input row in_start + t*G + srow
 
   __syncthreads();  // pair table visible
+#if RTPT_TILE_TIMELINE
+  span_.mark(1);
+#endif
 
   const float h9 = 1.0f / 9.0f;  // :145
 #pragma unroll 1
@@ -311,6 +338,9 @@ __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
     } else
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#if RTPT_TILE_TIMELINE
+    span_.step();
+#endif
   }
 }
 
@@ -324,6 +354,12 @@ __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
 
 }  // namespace
 
+#if RTPT_TILE_TIMELINE
+#define RTPT_SPAN_HOST
+#include "experiments/span_instrumentation.inc"
+#undef RTPT_SPAN_HOST
+#endif
+
 // rows per level per step of a launch (G; a workgroup is 4 G waves of a pair).  A row segment pays 2 (s0 + s1) + 2 G rows of
 // pipeline fill and re-staging whatever its length, so what decides is how long the segments of a launch are:
 //   * long segments (a 4K frame: 135 rows): three rows per step; the short-stride pair (1,2) two, its rings then admit four
@@ -334,6 +370,10 @@ __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a) {
 // RTPT_CHAIN_G1 (read by rtpt_create, FilterPolicy::chain_g_pin) pins 2, 3 or 4 for A/B runs and tests.
 static int chain_g(int k0, int levels, int n_strips, int rows, int n_cu, int pin) {
   if (levels != 2 || kChG != 3) return kChG;
+  if (pin >= 12 && pin <= 14) {  // 12 / 13 / 14: pin the pair (1,2) alone to 2 / 3 / 4 (A/B)
+    if (k0 == 1) return pin - 10;
+    pin = 0;
+  }
   if (pin == 4 || ((pin == 2 || pin == 3) && k0 == 1)) return pin;
   const int strips = n_strips > 0 ? n_strips : 1;
   const int segs3 = (n_cu * 2) / strips;  // G = 3: two workgroups of 12 waves per CU
@@ -421,6 +461,58 @@ bool atrous_chain_supported(int k0, int levels, uint32_t n_tris) {
   return chain_lds(k0, levels, n_tris, levels == 2 && kChG == 3 ? 4 : kChG) <= 160 * 1024;  // the most rows per step chain_g() picks
 }
 
+// Heights of the row segments of a launch.  The workgroups of a chained launch all start within ~1.5 us and a CU hosts
+// per_cu of them, but they do not share it evenly: the issue arbiter serves the oldest wave first, so of the four
+// workgroups of a (1,2) launch on a CU the one dispatched first ends after 48 us, the others after 63, 79 and 92
+// (profiles/r04_frame_timeline_4k.txt, equal segments of 66 rows) — and what is left to the last one alone (8 waves on a
+// CU) runs at 1.0 us per step where four resident workgroups take 0.5 us per workgroup-step between them.  Equal work ends
+// unequally; unequal work can end together.  The dispatch order is known: physical block b runs on XCD b & 7 as that XCD's
+// (b >> 3)-th workgroup, the first n_cu / 8 of an XCD are the oldest on their CUs, the next n_cu / 8 the second oldest, ...;
+// with the (segment-major, strip-minor) list cut into one contiguous run per XCD that age is a property of the row
+// SEGMENT (up to the few workgroups where a segment straddles two ages).  A segment whose workgroups have mean age r (0 the
+// oldest) gets the weight 1 + skew (1 - 2 r / (per_cu - 1)) of the rows.
+// The count of segments is rounded down to a multiple of 8 so that every XCD's run holds whole segments (a segment split between
+// two XCDs is old on one and young on the other: 33 segments at 4K made the (1,2) launch 20 % slower instead of faster).
+static void chain_segments(ChainSegs& sg, AtrousArgs& a, int rows, int n_cu, int per_cu, int skew_pct, int fill_rows) {
+  sg.n = 0;
+  // built-in (profiles/r04_chain_segment_skew_ab.json): 35 % with two or three workgroups per CU — the (3,4) launch of a 4K frame
+  // 109.8 -> 103.7 us with every workgroup ending within 0.3 us of the others, 4K frame 0.737 -> 0.730 ms, a 270-row strip
+  // 0.1281 -> 0.1267; none with four (the (1,2) launch at 4K: 20-80 % all cost 1-5 us — eight segments fewer for the alignment
+  // leave 32 CUs with three workgroups, and its oldest workgroups still end 18 us before its youngest at 45 %)
+  if (skew_pct < 0) skew_pct = per_cu >= 4 ? 0 : 35;
+  if (per_cu < 2 || skew_pct == 0 || a.n_segs < 8 || rows > 65535) return;
+  const int n_segs = a.n_segs & ~7;
+  if (n_segs > kChMaxSegs) return;
+  const uint32_t nb = static_cast<uint32_t>(a.n_strips) * static_cast<uint32_t>(n_segs);
+  const uint32_t per_xcd = nb >> 3, cu_xcd = static_cast<uint32_t>((n_cu + 7) / 8);
+  if (per_xcd <= cu_xcd) return;  // a single workgroup per CU: nothing to share
+  const double skew = skew_pct / 100.0;
+  double w[kChMaxSegs], total = 0.0;
+  for (int sgi = 0; sgi < n_segs; sgi++) {
+    double age = 0.0;
+    for (int st = 0; st < a.n_strips; st++) {
+      const uint32_t lb = static_cast<uint32_t>(sgi) * static_cast<uint32_t>(a.n_strips) + static_cast<uint32_t>(st);
+      const uint32_t r = (lb % per_xcd) / cu_xcd;
+      age += r < static_cast<uint32_t>(per_cu - 1) ? r : static_cast<uint32_t>(per_cu - 1);
+    }
+    age /= a.n_strips;
+    w[sgi] = 1.0 + skew * (1.0 - 2.0 * age / (per_cu - 1));
+    if (w[sgi] < 0.2) w[sgi] = 0.2;
+    total += w[sgi];
+  }
+  // cumulative rounding; a segment shorter than the pipeline's fill would cost more than it balances: then equal heights
+  double acc = 0.0;
+  sg.start[0] = 0;
+  for (int sgi = 0; sgi < n_segs; sgi++) {
+    acc += w[sgi];
+    const int end = sgi + 1 == n_segs ? rows : static_cast<int>(acc / total * rows + 0.5);
+    if (end - static_cast<int>(sg.start[sgi]) < fill_rows / 2 + 1) return;
+    sg.start[sgi + 1] = static_cast<uint16_t>(end);
+  }
+  sg.n = static_cast<uint16_t>(n_segs);
+  a.n_segs = n_segs;
+}
+
 void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, const FilterPolicy& pol, hipStream_t s) {
   if (a0.g.y1 <= a0.g.y0) return;
   AtrousArgs a = a0;
@@ -460,6 +552,8 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, cons
   // segments leave empty — 1080p pair (1,2): 30 segments of 36 rows 34.5 us, 32 of 34 rows 33.4)
   a.seg_rows = seg_rows;
   a.n_segs = (rows + seg_rows - 1) / seg_rows;
+  ChainSegs sg;
+  chain_segments(sg, a, rows, n_cu, per_cu, sw ? 0 : (per_cu >= 4 ? pol.chain_skew : pol.chain_skew2), 2 * (levels * a.k + levels * (levels - 1) / 2) + 2 * g);
   const uint32_t nb = static_cast<uint32_t>(a.n_strips) * static_cast<uint32_t>(a.n_segs);
   const dim3 grid(((nb + 7u) / 8u) * 8u), block(64, waves);
 #if RTPT_AB_VARIANTS
@@ -483,14 +577,14 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, cons
   do {                                                                                             \
     if (a.exact) {                                                                                 \
       if (final_pass)                                                                              \
-        hipLaunchKernelGGL((k_atrous_chain<LV, true, true, GG, KK>), grid, block, lds, s, a);      \
+        hipLaunchKernelGGL((k_atrous_chain<LV, true, true, GG, KK>), grid, block, lds, s, a, sg);      \
       else                                                                                         \
-        hipLaunchKernelGGL((k_atrous_chain<LV, false, true, GG, KK>), grid, block, lds, s, a);     \
+        hipLaunchKernelGGL((k_atrous_chain<LV, false, true, GG, KK>), grid, block, lds, s, a, sg);     \
     } else {                                                                                       \
       if (final_pass)                                                                              \
-        hipLaunchKernelGGL((k_atrous_chain<LV, true, false, GG, KK>), grid, block, lds, s, a);     \
+        hipLaunchKernelGGL((k_atrous_chain<LV, true, false, GG, KK>), grid, block, lds, s, a, sg);     \
       else                                                                                         \
-        hipLaunchKernelGGL((k_atrous_chain<LV, false, false, GG, KK>), grid, block, lds, s, a);    \
+        hipLaunchKernelGGL((k_atrous_chain<LV, false, false, GG, KK>), grid, block, lds, s, a, sg);    \
     }                                                                                              \
   } while (0)
   // strides as compile-time constants for the pairs a default frame runs (N = 5: (1,2) and (3,4)); RTPT_CHAIN_GENERIC=1

@@ -1331,7 +1331,7 @@ void launch_pathtrace(const PathtraceArgs& a, const GbufferArgs* gb, hipStream_t
   b.multi_off = static_cast<uint32_t>(dyn / 4);
   const size_t dyn_queue = dyn;
   if (a.spp > 1) dyn += 4 * kPtThreads * 4;  // sum_r, sum_g, sum_b, rng_pix
-  const uint32_t phase0 = pt_first_window(a.scene.use_bvh != 0);
+  const uint32_t phase0 = a.first_window ? a.first_window : pt_first_window(a.scene.use_bvh != 0);
   const bool split = a.spp == 1 && a.compact && a.queue[0] && a.queue_count && a.max_segments > phase0 &&
                      (a.max_segments <= 2 * phase0 || a.queue[1]);
   b.seg_begin = 0;

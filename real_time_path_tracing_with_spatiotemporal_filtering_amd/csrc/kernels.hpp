@@ -133,6 +133,7 @@ struct PathtraceArgs {
   // long paths (spp == 1, max_segments > 4): a launch covers the segment window [seg_begin, seg_end) and hands the
   // unfinished paths to the next one through a queue of 48-byte records (set by launch_pathtrace)
   uint32_t seg_begin, seg_end;
+  uint32_t first_window;       // segments the tile kernel runs before it hands the survivors to the queue kernels (0: pt_first_window())
   void* q_out;                 // records written by this launch
   uint32_t* q_out_count;
   const void* q_in;            // records read by k_pathtrace_queue
@@ -293,6 +294,9 @@ struct FilterPolicy {
   int chain_wg_per_cu = 0;  // RTPT_CHAIN_WG_PER_CU: workgroups per CU the row segments are sized for
   int chain_sw = 0;         // RTPT_CHAIN_SW: the sliding-window form of the pair (round 3, slower)
   int chain_sw_g1 = 0, chain_sw_g3 = 0;  // RTPT_CHAIN_SW_G1 / _G3: its rows per step
+  // RTPT_CHAIN_SKEW: percent by which the row segments of a chained launch differ with the age of their workgroups on a CU
+  // (atrous_chain.hip: chain_segments), "a" or "a,b": a for four workgroups per CU, b for two or three; -1 = the built-in values
+  int chain_skew = -1, chain_skew2 = -1;
 };
 void launch_atrous_chain(const AtrousArgs& a, int levels, bool final_pass, const FilterPolicy& pol, hipStream_t s);
 bool atrous_chain_supported(int k0, int levels, uint32_t n_tris);
