@@ -343,6 +343,7 @@ int rtpt_create(const rtpt_config* cfg, rtpt_ctx** out) {
     c->filter_policy.chain_skew = c->filter_policy.chain_skew2 = std::atoi(v);
     if (const char* comma = std::strchr(v, ',')) c->filter_policy.chain_skew2 = std::atoi(comma + 1);
   }
+  if (const char* v = std::getenv("RTPT_CHAIN_BW")) c->filter_policy.chain_bw = std::atoi(v);
   if (const char* v = std::getenv("RTPT_CHAIN_SW")) c->filter_policy.chain_sw = std::atoi(v);
   if (const char* v = std::getenv("RTPT_CHAIN_SW_G1")) c->filter_policy.chain_sw_g1 = std::atoi(v);
   if (const char* v = std::getenv("RTPT_CHAIN_SW_G3")) c->filter_policy.chain_sw_g3 = std::atoi(v);

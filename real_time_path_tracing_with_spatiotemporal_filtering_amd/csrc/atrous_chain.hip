@@ -94,7 +94,7 @@ __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a, Chai
   R[0] += (kChP - 1) * G;
   lag[0] = s[0] + kChP * G;
   for (int l = 1; l < L; l++) lag[l] = lag[l - 1] + s[l] + G;
-  const int bw = kChCols - 2 * E[0];
+  const int bw = a.strip_w;  // <= kChCols - 2 * E[0]
   const int in_stride = kChCols + 2 * s[0];  // staged input columns
   // LDS: [id-pair weights][ring 0: colour cells, ids][ring 1: colour, ids]...
   uint32_t ring_col[L], ring_ids[L];
@@ -523,7 +523,9 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, cons
 #else
   const bool sw = false;
 #endif
-  const int bw = atrous_chain_strip_width(a.k, levels);
+  int bw = atrous_chain_strip_width(a.k, levels);
+  if (!sw && a.k == 1 && levels == 2 && pol.chain_bw >= 64 && pol.chain_bw < bw) bw = pol.chain_bw;  // A/B
+  a.strip_w = bw;
   a.n_strips = (a.g.W + bw - 1) / bw;
   const int g = chain_g(a.k, levels, a.n_strips, a.g.y1 - a.g.y0, a.n_cu > 0 ? a.n_cu : 256, pol.chain_g_pin);
 #if RTPT_AB_VARIANTS

@@ -155,6 +155,7 @@ struct AtrousArgs {
   int32_t n_cu;          // compute units of the context's device (persistent grid size)
   int32_t alpha_zero;    // 1: a k < N launch writes alpha 0 instead of the depth (last iteration of an even N)
   int32_t n_strips, n_segs, seg_rows;  // chained iterations (atrous_chain.hip): column strips x row segments (set by launch_atrous_chain)
+  int32_t strip_w;       // chained iterations: columns a strip stores (set by launch_atrous_chain; at most 128 - 2 * sum of the later strides)
   const float* pair_tab; // (n_tris+1)^2 id-pair normal weights, NULL when the scene is too large
   const float4* normals; // per-pixel (n.xyz, self weight) plane written by k_gbuffer for such scenes, NULL otherwise
   uint32_t n_tris;       // normal_tab has n_tris + 1 entries
@@ -297,6 +298,7 @@ struct FilterPolicy {
   // RTPT_CHAIN_SKEW: percent by which the row segments of a chained launch differ with the age of their workgroups on a CU
   // (atrous_chain.hip: chain_segments), "a" or "a,b": a for four workgroups per CU, b for two or three; -1 = the built-in values
   int chain_skew = -1, chain_skew2 = -1;
+  int chain_bw = 0;         // RTPT_CHAIN_BW: columns a strip of the pair (1,2) stores (A/B; 0 = the widest, 124)
 };
 void launch_atrous_chain(const AtrousArgs& a, int levels, bool final_pass, const FilterPolicy& pol, hipStream_t s);
 bool atrous_chain_supported(int k0, int levels, uint32_t n_tris);
