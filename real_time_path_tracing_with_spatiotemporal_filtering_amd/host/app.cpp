@@ -119,7 +119,12 @@ void PathTracingApplication::createBuffers() {
   if (multi()) {
     // one strip context per rank this process runs; all on one stream, which is also the stream the transport's
     // messages are ordered on (RCCL point-to-point calls or device-to-device copies)
-    if (opt_.frames_in_flight != 1) throw std::runtime_error("strips run one frame in flight");
+    // two frames in flight on strips: every rank builds even frames in one context and odd frames in another, the ranks'
+    // contexts of one parity share a stream; the finished strip is handed across like on one GPU (prepareHistory).  The
+    // guided extension modes would also need the bands of the other context's id / moment planes: not served (app.py: same)
+    if (opt_.frames_in_flight != 1 && opt_.frames_in_flight != 2) throw std::runtime_error("frames_in_flight must be 1 or 2");
+    if (opt_.frames_in_flight == 2 && (opt_.flags & (RTPT_FLAG_EXT_VARIANCE | RTPT_FLAG_EXT_DISOCCLUSION)))
+      throw std::runtime_error("two frames in flight on strips cannot serve RTPT_FLAG_EXT_DISOCCLUSION / _VARIANCE");
     const bool local = opt_.rank < 0;
     if (!local && opt_.rank >= opt_.ranks) throw std::runtime_error("rank out of range");
     int dev = opt_.device;
@@ -129,7 +134,8 @@ void PathTracingApplication::createBuffers() {
     }
     if (dev >= 0) host_set_device(dev);
     cfg.device = dev;
-    stream_ = host_stream_create();
+    for (int i = 0; i < opt_.frames_in_flight; i++) streams_[i] = host_stream_create();
+    stream_ = streams_[0];
     transport_ = local ? make_local_transport()
                        : make_rccl_transport(opt_.ranks, opt_.rank, opt_.rccl_id_file, opt_.rccl_nonce, opt_.rccl_timeout_s);
     if (opt_.present) {
@@ -150,9 +156,12 @@ void PathTracingApplication::createBuffers() {
       const Rows st = rs.plan.stored(), own = rs.plan.own();
       cfg.row_begin = static_cast<uint32_t>(st.first);
       cfg.row_end = static_cast<uint32_t>(st.second);
-      check(rtpt_create(&cfg, &rs.ctx), "createBuffers");
-      check(rtpt_set_stream(rs.ctx, stream_), "rtpt_set_stream");
-      check(rtpt_set_count_rows(rs.ctx, static_cast<uint32_t>(own.first), static_cast<uint32_t>(own.second)), "rtpt_set_count_rows");
+      for (int i = 0; i < opt_.frames_in_flight; i++) {
+        check(rtpt_create(&cfg, &rs.ctxs[i]), "createBuffers");
+        check(rtpt_set_stream(rs.ctxs[i], streams_[i]), "rtpt_set_stream");
+        check(rtpt_set_count_rows(rs.ctxs[i], static_cast<uint32_t>(own.first), static_cast<uint32_t>(own.second)), "rtpt_set_count_rows");
+      }
+      rs.ctx = rs.last = rs.ctxs[0];
       ranks_.push_back(rs);
     }
     ctx_ = last_ = ranks_[0].ctx;
@@ -176,12 +185,13 @@ void PathTracingApplication::buildAccelerationStructure() {
   const float* xf = instanceXforms_.empty() ? nullptr : instanceXforms_.data();
   const uint32_t n_inst = static_cast<uint32_t>(instanceXforms_.size() / 12);
   if (multi()) {
-    for (auto& rs : ranks_) {
-      check(rtpt_scene_upload(rs.ctx, objVertices.data(), static_cast<uint32_t>(objVertices.size() / 3), objIndices.data(),
-                              static_cast<uint32_t>(objIndices.size() / 3), xf, n_inst),
-            "buildAccelerationStructure");
-      materials(rs.ctx);
-    }
+    for (auto& rs : ranks_)
+      for (int i = 0; i < opt_.frames_in_flight; i++) {
+        check(rtpt_scene_upload(rs.ctxs[i], objVertices.data(), static_cast<uint32_t>(objVertices.size() / 3), objIndices.data(),
+                                static_cast<uint32_t>(objIndices.size() / 3), xf, n_inst),
+              "buildAccelerationStructure");
+        materials(rs.ctxs[i]);
+      }
     return;
   }
   for (int i = 0; i < opt_.frames_in_flight; i++) {
@@ -308,8 +318,17 @@ void PathTracingApplication::exchangeHaloPlane(int k, rtpt_plane in_plane, size_
 // the previous-frame rows its pixels can reach (reprojection_rows: the same numbers on every rank, no negotiation) and
 // the ranks swap exactly those bands of their finished strips.
 void PathTracingApplication::prepareHistory() {
+  const bool handed = opt_.frames_in_flight == 2 && frameCount > 0;  // the previous frame rests in the rank's OTHER context
+  if (handed)  // ... which finished (or is finishing) it on the other stream
+    for (auto& rs : ranks_) check(rtpt_stream_wait(rs.ctx, rs.last), "rtpt_stream_wait");
   if (frameCount == 0 || cameraStatic()) {
-    for (auto& rs : ranks_) check(rtpt_set_external_history(rs.ctx, nullptr, 0, 0), "rtpt_set_external_history");
+    for (auto& rs : ranks_) {
+      void* prev = nullptr;
+      const Rows st = rs.plan.stored();
+      if (handed) check(rtpt_plane_ptr(rs.last, RTPT_PLANE_PREVIOUS, &prev), "rtpt_plane_ptr");
+      check(rtpt_set_external_history(rs.ctx, prev, handed ? static_cast<uint32_t>(st.first) : 0u, handed ? static_cast<uint32_t>(st.second) : 0u),
+            "rtpt_set_external_history");
+    }
     return;
   }
   const int H = static_cast<int>(opt_.height);
@@ -322,7 +341,7 @@ void PathTracingApplication::prepareHistory() {
   for (auto& rs : ranks_) {
     if (!rs.history) rs.history = host_device_alloc(static_cast<size_t>(H) * row_bytes);
     void* prev = nullptr;
-    check(rtpt_plane_ptr(rs.ctx, RTPT_PLANE_PREVIOUS, &prev), "rtpt_plane_ptr");
+    check(rtpt_plane_ptr(rs.last, RTPT_PLANE_PREVIOUS, &prev), "rtpt_plane_ptr");  // rs.last == rs.ctx with one frame in flight
     const int row0 = rs.plan.stored().first;
     auto prev_rows = [&](int y) { return static_cast<char*>(prev) + static_cast<size_t>(y - row0) * row_bytes; };
     auto hist_rows = [&](int y) { return static_cast<char*>(rs.history) + static_cast<size_t>(y) * row_bytes; };
@@ -485,6 +504,12 @@ void PathTracingApplication::copyImageToSwapChainsCurrentImage() {
   if (multi()) {
     for (auto& rs : ranks_) check(rtpt_end_frame(rs.ctx), "copyImageToSwapChainsCurrentImage");
     if (opt_.present) presentFrame();
+    const int next = static_cast<int>((frameCount + 1) % static_cast<uint32_t>(opt_.frames_in_flight));
+    for (auto& rs : ranks_) {
+      rs.last = rs.ctx;
+      rs.ctx = rs.ctxs[next];
+    }
+    stream_ = streams_[next];
     return;
   }
   check(rtpt_end_frame(ctx_), "copyImageToSwapChainsCurrentImage");  // history hand-over, :1364-1372
@@ -563,7 +588,8 @@ std::vector<unsigned char> PathTracingApplication::readPresented() {
   for (auto& rs : ranks_)
     if (rs.plan.rank == 0 && rs.swap[idx]) {
       out.resize(W * H * (opt_.present == 1 ? 4 : 16));
-      host_stream_sync(stream_);
+      for (void* st : streams_)
+        if (st) host_stream_sync(st);
       host_stream_sync(presentStream_);
       host_device_to_host(out.data(), rs.swap[idx], out.size(), presentStream_);
     }
@@ -583,7 +609,11 @@ void PathTracingApplication::drawScene(const std::string& keys) {
 
 void PathTracingApplication::freeRessources() {
   for (auto& rs : ranks_) {
-    if (rs.ctx) rtpt_destroy(rs.ctx);
+    for (rtpt_ctx*& c : rs.ctxs) {
+      if (c) rtpt_destroy(c);
+      c = nullptr;
+    }
+    rs.ctx = rs.last = nullptr;
     if (rs.history) host_device_free(rs.history);
     if (rs.guide_ids) host_device_free(rs.guide_ids);
     if (rs.guide_moments) host_device_free(rs.guide_moments);
@@ -607,7 +637,10 @@ void PathTracingApplication::freeRessources() {
     transport_ = nullptr;
     delete presentTransport_;
     presentTransport_ = nullptr;
-    if (stream_) host_stream_destroy(stream_);
+    for (void*& st : streams_) {
+      if (st) host_stream_destroy(st);
+      st = nullptr;
+    }
     if (presentStream_) host_stream_destroy(presentStream_);
     stream_ = presentStream_ = nullptr;
     ctx_ = last_ = nullptr;
@@ -677,7 +710,9 @@ uint64_t PathTracingApplication::bytesSent() const {
 
 void PathTracingApplication::sync() {
   if (multi()) {
-    for (auto& rs : ranks_) check(rtpt_sync(rs.ctx), "rtpt_sync");
+    for (auto& rs : ranks_)
+      for (rtpt_ctx* c : rs.ctxs)
+        if (c) check(rtpt_sync(c), "rtpt_sync");
     if (presentStream_) host_stream_sync(presentStream_);
     return;
   }
@@ -692,7 +727,7 @@ std::vector<float> PathTracingApplication::readImage() {
     for (auto& rs : ranks_) {
       const Rows st = rs.plan.stored(), own = rs.plan.own();
       std::vector<float> strip(static_cast<size_t>(st.second - st.first) * row_floats);
-      check(rtpt_readback(rs.ctx, RTPT_PLANE_PREVIOUS, strip.data(), strip.size() * sizeof(float)), "rtpt_readback");
+      check(rtpt_readback(rs.last, RTPT_PLANE_PREVIOUS, strip.data(), strip.size() * sizeof(float)), "rtpt_readback");
       std::memcpy(img.data() + static_cast<size_t>(own.first) * row_floats, strip.data() + static_cast<size_t>(own.first - st.first) * row_floats,
                   static_cast<size_t>(own.second - own.first) * row_floats * sizeof(float));
     }
@@ -706,11 +741,13 @@ std::vector<float> PathTracingApplication::readImage() {
 uint64_t PathTracingApplication::rayCount() {
   uint64_t total = 0;
   if (multi()) {
-    for (auto& rs : ranks_) {
-      uint64_t n = 0;
-      check(rtpt_readback(rs.ctx, RTPT_PLANE_RAYCOUNT, &n, sizeof n), "rtpt_readback");
-      total += n;
-    }
+    for (auto& rs : ranks_)
+      for (rtpt_ctx* c : rs.ctxs)
+        if (c) {
+          uint64_t n = 0;
+          check(rtpt_readback(c, RTPT_PLANE_RAYCOUNT, &n, sizeof n), "rtpt_readback");
+          total += n;
+        }
     return total;
   }
   for (int i = 0; i < opt_.frames_in_flight; i++) {

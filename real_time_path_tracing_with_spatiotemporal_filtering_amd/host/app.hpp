@@ -104,7 +104,9 @@ class PathTracingApplication {
   // strips: the ranks this process runs (all of them in local mode, one with RCCL), sharing stream_
   struct RankState {
     StripPlan plan;
-    rtpt_ctx* ctx = nullptr;
+    rtpt_ctx* ctx = nullptr;                    // the context of the frame being built
+    rtpt_ctx* ctxs[2] = {nullptr, nullptr};     // frames_in_flight 2: even / odd frames (ctx alternates between them)
+    rtpt_ctx* last = nullptr;                   // the context that finished the previous frame (== ctx with one frame in flight)
     void* history = nullptr;  // full-frame device buffer the previous frame's bands are gathered into (lazily allocated)
     void* guide_ids = nullptr;      // extension modes: the previous frame's id plane ([H, W] u32) ...
     void* guide_moments = nullptr;  // ... and moment plane ([H, W] float4), bands gathered like the history
@@ -120,7 +122,8 @@ class PathTracingApplication {
   void* presentImage(RankState* rs, int idx); // allocate on first use
   std::vector<RankState> ranks_;
   Transport* transport_ = nullptr;
-  void* stream_ = nullptr;
+  void* stream_ = nullptr;                    // the stream of the frame being built
+  void* streams_[2] = {nullptr, nullptr};     // strips with two frames in flight: one stream per frame parity, shared by the ranks
   double sceneMin_[3] = {0, 0, 0}, sceneMax_[3] = {0, 0, 0};  // world-space bounds of the POSED, INSTANCED scene
   std::vector<float> instanceXforms_;          // 3x4 row-major per instance; empty: one identity instance (main.cpp:728-741)
   float zFar_ = 10.0f;                         // main.cpp:483
