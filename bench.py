@@ -415,7 +415,8 @@ def balance_live(wl, args, rank, world, torch, dist):
     best = None
     for i in range(max(1, args.balance)):
         args.strip_rows = rows
-        run_gpu(wl, args, rank, world, steps, min(args.warmup, 5), torch, dist, collect_kernels=False)
+        # redundant halo rows and no present whatever the job will use: a rank's own time must not contain waiting for others
+        run_gpu(wl, args, rank, world, steps, min(args.warmup, 5), torch, dist, collect_kernels=False, halo="redundant", present=None)
         times = [t[0] for t in gather([LOCAL_SECONDS[0]], 1)]
         if best is None or max(times) < best[0]:
             best = (max(times), rows)

@@ -220,6 +220,7 @@ class PipelinedBackend:
         self.width, self.height = self.be[0].width, self.be[0].height
         self.frame = 0           # frames ended
         self._ext_by_app = False  # the application registered an all-gathered history (multi-rank, moving camera)
+        self._guides_by_app = False  # ... or the gathered bands of the previous frame's id / moment planes (extension flags)
 
     # the backend of the frame being built / of the last finished frame
     @property
@@ -258,7 +259,7 @@ class PipelinedBackend:
 
     def temporal_filter(self, pc, ubo, y0, y1):
         k, n = pc.waveletIteration, pc.maxWaveletIteration
-        if k == 1 and self.frame > 0 and getattr(self.cur, "guided", False):
+        if k == 1 and self.frame > 0 and getattr(self.cur, "guided", False) and not self._guides_by_app:
             # the moment accumulation (this iteration) and the disocclusion test (the final one) read the previous frame's id /
             # moment planes, which live in the other backend
             self._wait_prev()
@@ -274,6 +275,7 @@ class PipelinedBackend:
         self.cur.end_frame()
         self.frame += 1
         self._ext_by_app = False
+        self._guides_by_app = False
 
     def sync(self):
         for b in self.be:
@@ -288,6 +290,23 @@ class PipelinedBackend:
 
     def history_full(self):
         return self.cur.history_full()
+
+    # strips + extension flags, camera moved: the previous frame's id / moment planes rest in the other backend, the gathered
+    # bands go to the backend of the frame being built (app._prepare_guides)
+    def guide_rows(self, plane, y0, y1):
+        if plane in (abi.PLANE_PREV_VIS_ID, abi.PLANE_MOMENTS_PREV):   # what the previous frame left
+            self._wait_prev()
+            return self.prev.guide_rows(plane, y0, y1)
+        return self.cur.guide_rows(plane, y0, y1)   # planes of the frame being built (the variance that travels with the halo rows)
+
+    def guides_full(self):
+        return self.cur.guides_full()
+
+    def use_external_guides(self, on, rows=None, moments=True):
+        self._guides_by_app = bool(on)
+        if on:
+            self.cur.use_external_guides(True, rows, moments)
+        # off: temporal_filter hands the other backend's strip-local planes across (frame > 0)
 
     def use_external_history(self, on, rows=None):
         self._ext_by_app = bool(on)
@@ -659,9 +678,6 @@ def make_app(width, height, max_segments=4, iterations=5, rank=0, world=1, mode=
         return HipBackend(width, height, plan, max_segments=max_segments, flags=flags, torch_planes=torch_planes,
                           debug_mask=debug_mask, samples_per_pixel=samples_per_pixel)
     if frames_in_flight == 2:
-        if world > 1 and flags & (abi.FLAG_EXT_DISOCCLUSION | abi.FLAG_EXT_VARIANCE):
-            raise ValueError("two frames in flight on strips cannot serve RTPT_FLAG_EXT_DISOCCLUSION / _VARIANCE yet "
-                             "(the bands of the previous id / moment planes would have to come from the other context of every rank)")
         be = PipelinedBackend([one(), one()])
     elif frames_in_flight == 1:
         be = one()

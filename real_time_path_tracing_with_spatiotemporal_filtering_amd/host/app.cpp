@@ -120,11 +120,10 @@ void PathTracingApplication::createBuffers() {
     // one strip context per rank this process runs; all on one stream, which is also the stream the transport's
     // messages are ordered on (RCCL point-to-point calls or device-to-device copies)
     // two frames in flight on strips: every rank builds even frames in one context and odd frames in another, the ranks'
-    // contexts of one parity share a stream; the finished strip is handed across like on one GPU (prepareHistory).  The
-    // guided extension modes would also need the bands of the other context's id / moment planes: not served (app.py: same)
+    // contexts of one parity share a stream; the finished strip — and, with the guided extension modes, its id / moment
+    // planes — are handed across like on one GPU, or as bands of the ranks' other contexts when the camera moved
+    // (prepareHistory, prepareGuides)
     if (opt_.frames_in_flight != 1 && opt_.frames_in_flight != 2) throw std::runtime_error("frames_in_flight must be 1 or 2");
-    if (opt_.frames_in_flight == 2 && (opt_.flags & (RTPT_FLAG_EXT_VARIANCE | RTPT_FLAG_EXT_DISOCCLUSION)))
-      throw std::runtime_error("two frames in flight on strips cannot serve RTPT_FLAG_EXT_DISOCCLUSION / _VARIANCE");
     const bool local = opt_.rank < 0;
     if (!local && opt_.rank >= opt_.ranks) throw std::runtime_error("rank out of range");
     int dev = opt_.device;
@@ -375,7 +374,7 @@ void PathTracingApplication::exchangeBands(const std::vector<Rows>& needs, rtpt_
   for (auto& rs : ranks_) {
     if (!(rs.*dst)) rs.*dst = host_device_alloc(static_cast<size_t>(H) * row_bytes);
     void* src = nullptr;
-    check(rtpt_plane_ptr(rs.ctx, plane, &src), "rtpt_plane_ptr");
+    check(rtpt_plane_ptr(rs.last, plane, &src), "rtpt_plane_ptr");  // rs.last == rs.ctx with one frame in flight
     const int row0 = rs.plan.stored().first;
     auto src_rows = [&](int y) { return static_cast<char*>(src) + static_cast<size_t>(y - row0) * row_bytes; };
     auto dst_rows = [&](int y) { return static_cast<char*>(rs.*dst) + static_cast<size_t>(y) * row_bytes; };
@@ -399,12 +398,24 @@ void PathTracingApplication::exchangeBands(const std::vector<Rows>& needs, rtpt_
 // rows; when the camera (or the model) moved, the rows a rank's stored pixels can reach beyond that are gathered from their
 // owners — the history image's bound and plan — into buffers registered with rtpt_set_external_guides.
 void PathTracingApplication::prepareGuides() {
+  const bool handed = opt_.frames_in_flight == 2 && frameCount > 0;  // the previous frame's planes rest in the rank's OTHER context
+  const bool variance = (opt_.flags & RTPT_FLAG_EXT_VARIANCE) != 0;
+  if (handed)
+    for (auto& rs : ranks_) check(rtpt_stream_wait(rs.ctx, rs.last), "rtpt_stream_wait");
   if (frameCount == 0 || cameraStatic()) {
-    for (auto& rs : ranks_) check(rtpt_set_external_guides(rs.ctx, nullptr, nullptr, 0, 0), "rtpt_set_external_guides");
+    for (auto& rs : ranks_) {
+      void *ids = nullptr, *mom = nullptr;
+      const Rows st = rs.plan.stored();
+      if (handed) {
+        check(rtpt_plane_ptr(rs.last, RTPT_PLANE_PREV_VIS_ID, &ids), "rtpt_plane_ptr");
+        if (variance) check(rtpt_plane_ptr(rs.last, RTPT_PLANE_MOMENTS_PREV, &mom), "rtpt_plane_ptr");
+      }
+      check(rtpt_set_external_guides(rs.ctx, ids, mom, handed ? static_cast<uint32_t>(st.first) : 0u, handed ? static_cast<uint32_t>(st.second) : 0u),
+            "rtpt_set_external_guides");
+    }
     return;
   }
   const int H = static_cast<int>(opt_.height);
-  const bool variance = (opt_.flags & RTPT_FLAG_EXT_VARIANCE) != 0;
   std::vector<Rows> needs;
   for (int r = 0; r < opt_.ranks; r++) {
     StripPlan p = ranks_[0].plan;

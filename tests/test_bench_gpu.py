@@ -90,12 +90,14 @@ def test_two_rank_rehearsal_counts_the_same_rays(hip_lib, halo):
     assert two["rays_per_frame"] == one["rays_per_frame"]
 
 
-@pytest.mark.parametrize("mode,flags", [("redundant", 0), ("exchange", 0), ("redundant", 0x100), ("redundant", 0x81), ("exchange", 0x100)])
-def test_gloo_ranks_on_one_gpu_reproduce_the_single_context_frames(hip_lib, tmp_path, mode, flags):
+@pytest.mark.parametrize("mode,flags,in_flight", [("redundant", 0, 1), ("exchange", 0, 1), ("redundant", 0x100, 1), ("redundant", 0x81, 1),
+                                                  ("exchange", 0x100, 1), ("redundant", 0, 2), ("exchange", 0x100, 2), ("redundant", 0x981, 2)])
+def test_gloo_ranks_on_one_gpu_reproduce_the_single_context_frames(hip_lib, tmp_path, mode, flags, in_flight):
     """the Python host's multi-rank path on DEVICE memory — halo rows, the history bands bounded by the reprojection
     reach, and (extension flags 0x100 variance, 0x80 disocclusion) the previous frame's id / moment bands — with three
     ranks on GPU 0 and gloo as the carrier, vertical camera moves in the script: every rank's rows of every frame equal
-    the single-context frames bit for bit, and only bands travelled (not whole frames)"""
+    the single-context frames bit for bit, and only bands travelled (not whole frames).  in_flight 2: app.PipelinedBackend on
+    every rank (the previous frame, and with the flags its id / moment planes, rest in the rank's other context)"""
     import numpy as np
     W, H, keys = 144, 150, ",E,J,QA,,E"
     args = [str(tmp_path), mode, hex(flags), keys, str(W), str(H)]
@@ -104,7 +106,7 @@ def test_gloo_ranks_on_one_gpu_reproduce_the_single_context_frames(hip_lib, tmp_
     out = subprocess.run([sys.executable, worker] + args, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
-                          "127.0.0.1", "--master-port", str(_port()), worker] + args,
+                          "127.0.0.1", "--master-port", str(_port()), worker] + args + ["", str(in_flight)],
                          cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     ref = np.load(tmp_path / "w1_r0.npz")
