@@ -67,22 +67,28 @@ REQUIRED_PER_PX = {"k_atrous": 36, "k_atrous_final": 68, "k_atrous_chain": 36}
 REQUIRED_PER_PX_NRM = {"k_atrous": 48, "k_atrous_final": 84, "k_atrous_chain": 48}
 
 
+def _scene_kwargs(wl):
+    """make_app's scene arguments for a workload: the OBJ as it is, or BASELINE configs[4]'s lattice of tessellated instances
+    (built once per process)"""
+    if not wl.get("instanced"):
+        return {}
+    if "scene" not in _INSTANCED:
+        from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi, scenes
+        from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE
+        xyz, idx = abi.load_obj(DEFAULT_SCENE)
+        _INSTANCED["scene"] = scenes.instanced_cornell(xyz, idx)
+    vx, ti, xf, cam, zfar = _INSTANCED["scene"]
+    return dict(mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar, lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
+
+
 def run_gpu(wl, args, rank, world, steps, warmup, torch, dist, collect_kernels=True, in_flight=1, halo=None, present="default",
             camera_keys=None):
     """one measured run; halo / present / camera_keys override the command line (the `also` legs of a multi-rank run)"""
     halo = halo or args.halo
     present = args.present if present == "default" else present
     camera_keys = args.camera_keys if camera_keys is None else camera_keys
-    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE, make_app
-    extra = {}
-    if wl.get("instanced"):
-        if "scene" not in _INSTANCED:
-            from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi, scenes
-            xyz, idx = abi.load_obj(DEFAULT_SCENE)
-            _INSTANCED["scene"] = scenes.instanced_cornell(xyz, idx)
-        vx, ti, xf, cam, zfar = _INSTANCED["scene"]
-        extra = dict(mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar,
-                     lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    extra = _scene_kwargs(wl)
     app = make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"],
                    rank=rank, world=world, mode=halo, flags=args.flags,
                    torch_planes=(dist is not None), frames_in_flight=in_flight, present=present,
@@ -337,15 +343,8 @@ def _strip_app(wl, args, rank, world, rows, torch_planes, halo="redundant"):
     """an application for rank `rank`'s strip of a `world`-rank job with the boundaries `rows`, for the balancing procedures'
     own measurements: no present, redundant halo rows (no rank waits for another while the camera rests, so the ranks may
     draw different numbers of frames)"""
-    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import DEFAULT_SCENE, make_app
-    extra = {}
-    if wl.get("instanced"):
-        if "scene" not in _INSTANCED:
-            from real_time_path_tracing_with_spatiotemporal_filtering_amd import abi, scenes
-            xyz, idx = abi.load_obj(DEFAULT_SCENE)
-            _INSTANCED["scene"] = scenes.instanced_cornell(xyz, idx)
-        vx, ti, xf, cam, zfar = _INSTANCED["scene"]
-        extra = dict(mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar, lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+    extra = _scene_kwargs(wl)
     return make_app(wl["width"], wl["height"], max_segments=wl["max_segments"], iterations=wl["iterations"], rank=rank, world=world,
                     mode=halo, flags=args.flags, torch_planes=torch_planes, splits=rows if world > 1 else (), **extra)
 
