@@ -369,6 +369,7 @@ __global__ __launch_bounds__(128 * L * G) void k_atrous_chain(AtrousArgs a, Chai
 //     the 300-row strip 25.0 -> 21.9 us per pair, 1080p 32.9 -> 31.9, where the 4K frame loses (103 against 97.7).
 // RTPT_CHAIN_G1 (read by rtpt_create, FilterPolicy::chain_g_pin) pins 2, 3 or 4 for A/B runs and tests.
 static int chain_g(int k0, int levels, int n_strips, int rows, int n_cu, int pin) {
+  if (levels == 3) return 2;  // two waves per row and level: three levels fit a workgroup of 1 024 threads with two rows per step only
   if (levels != 2 || kChG != 3) return kChG;
   if (pin >= 12 && pin <= 14) {  // 12 / 13 / 14: pin the pair (1,2) alone to 2 / 3 / 4 (A/B)
     if (k0 == 1) return pin - 10;
@@ -448,17 +449,21 @@ hipError_t prepare_device_atrous_chain() {
   RTPT_SW_ATTR(2) RTPT_SW_ATTR(3) RTPT_SW_ATTR(4) RTPT_SW_ATTR(6)
 #undef RTPT_SW_ATTR
 #endif
-  if (e == hipSuccess) e = (chain_attrs<3, kChG, 0>());
+  if (e == hipSuccess) e = (chain_attrs<3, 2, 0>());
+  if (e == hipSuccess) e = (chain_attrs<3, 2, 1>());                 // (1,2,3)
+  if (e == hipSuccess) e = (chain_attrs<2, kChG, 4>());              // (4,5), the pair that may end a frame of N = 5 in its FINAL pass
+  if (e == hipSuccess && kChG == 3) e = (chain_attrs<2, 4, 4>());
   return e;
 }
 
 // true when `levels` consecutive iterations from stride k0 can run as one chain on this scene
 bool atrous_chain_supported(int k0, int levels, uint32_t n_tris) {
   if (levels < 2 || levels > 3 || k0 < 1) return false;
-  if (128 * levels * kChG > 1024) return false;  // two waves per row and level: the workgroup must fit 1024 threads
+  const int g_max = levels == 3 ? 2 : (levels == 2 && kChG == 3 ? 4 : kChG);  // the most rows per step chain_g() picks
+  if (128 * levels * (levels == 3 ? 2 : kChG) > 1024) return false;  // two waves per row and level: the workgroup must fit 1024 threads
   if (n_tris + 1 > 64) return false;  // id-pair table in LDS (the per-pixel-normal variant is not chained)
   if (atrous_chain_strip_width(k0, levels) < 64) return false;
-  return chain_lds(k0, levels, n_tris, levels == 2 && kChG == 3 ? 4 : kChG) <= 160 * 1024;  // the most rows per step chain_g() picks
+  return chain_lds(k0, levels, n_tris, g_max) <= 160 * 1024;
 }
 
 // Heights of the row segments of a launch.  The workgroups of a chained launch all start within ~1.5 us and a CU hosts
@@ -597,8 +602,12 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, cons
       RTPT_LAUNCH_CHAIN(2, 4, 1);
     else if (a.k == 3 && !generic)
       RTPT_LAUNCH_CHAIN(2, 4, 3);
+    else if (a.k == 4 && !generic)
+      RTPT_LAUNCH_CHAIN(2, 4, 4);
     else
       RTPT_LAUNCH_CHAIN(2, 4, 0);
+  } else if (levels == 2 && a.k == 4 && !generic && g == kChG) {
+    RTPT_LAUNCH_CHAIN(2, kChG, 4);
   } else if (levels == 2 && a.k == 1 && !generic) {
     if (g == 2 && kChG == 3)
       RTPT_LAUNCH_CHAIN(2, 2, 1);
@@ -610,8 +619,10 @@ void launch_atrous_chain(const AtrousArgs& a0, int levels, bool final_pass, cons
     RTPT_LAUNCH_CHAIN(2, 2, 0);
   else if (levels == 2)
     RTPT_LAUNCH_CHAIN(2, kChG, 0);
+  else if (a.k == 1 && !generic)
+    RTPT_LAUNCH_CHAIN(3, 2, 1);
   else
-    RTPT_LAUNCH_CHAIN(3, kChG, 0);
+    RTPT_LAUNCH_CHAIN(3, 2, 0);
 #undef RTPT_LAUNCH_CHAIN
 }
 
