@@ -561,8 +561,9 @@ def main():
     if args.emulate_balance:
         emulate_balance(wl, args, torch)
         return
-    if world > 1 and args.balance > 0:
-        args.strip_rows = balance_live(wl, args, rank, world, torch, dist)
+    if dist is not None and args.balance > 0:   # (with --force-dist also on one rank: the procedure's collectives over RCCL)
+        rows = balance_live(wl, args, rank, world, torch, dist)
+        args.strip_rows = rows if world > 1 else ()
     if args.emulate_strip:
         r, n = map(int, args.emulate_strip.split("/"))
         args.halo = "redundant"

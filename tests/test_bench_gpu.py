@@ -78,6 +78,17 @@ def test_balanced_strips_render_the_same_frames(hip_lib):
     assert em["rounds"][0]["strip_rows"] == [0, 360, 720, 1080]
 
 
+def test_one_rank_over_rccl(hip_lib):
+    """what a one-GPU box can show of the RCCL path: bench.py under torchrun with ONE rank and --force-dist initialises the
+    nccl (= RCCL) process group on the device, binds torch-owned planes, runs the barrier / all_reduce timing protocol and,
+    with --balance, the balancing procedure's all_gather — same frames as the plain run"""
+    base = ["bench.py", "--workload", "1080p", "--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--prewarm-seconds", "0"]
+    one = _run([sys.executable] + base)
+    rccl = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                 "--master-port", str(_port())] + base + ["--gpus", "1", "--force-dist", "--balance", "1"])
+    assert rccl["n_gpus"] == 1 and rccl["rays_per_frame"] == one["rays_per_frame"] and rccl["strip_rows"] is None
+
+
 @pytest.mark.parametrize("halo", ["redundant", "exchange"])
 def test_two_rank_rehearsal_counts_the_same_rays(hip_lib, halo):
     one = _run([sys.executable, "bench.py", "--workload", "1080p", "--steps", "6", "--warmup", "1", "--no-cpu-baseline",
