@@ -174,11 +174,13 @@ def test_million_triangle_4k_eight_strips_equal_single_frame(hip_lib, oracle, co
                       lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0), splits=splits)
 
 
-def test_million_triangle_4k_cpp_host_on_eight_strips_equals_python_host(hip_lib, oracle, cornell, tmp_path):
+@pytest.mark.parametrize("strips", [["--ranks", "8"], ["--ranks", "4", "--frames-in-flight", "2", "--splits", "0,600,1080,1500,2160"]])
+def test_million_triangle_4k_cpp_host_on_eight_strips_equals_python_host(hip_lib, oracle, cornell, tmp_path, strips):
     """The same configuration driven by the C++ host (north_star: "the host stays C++"): `rtpt_app --lattice 10x10x10
     --tessellate 6 --ranks 8` builds the scene itself (host/scene_gen.cpp), runs eight in-process strip contexts with
     redundant halo rows and, in the frames where the camera moved, swaps the history bands bounded with the posed, instanced
-    scene box (host/strips.cpp: reprojection_rows) — against the Python host's single context, bit for bit."""
+    scene box (host/strips.cpp: reprojection_rows) — against the Python host's single context, bit for bit.  Second case: four
+    strips of unequal height with two frames in flight (the bands then come from the ranks' other contexts)."""
     import json
     import subprocess
     from test_cpp_host import APP, PKG, read_pfm
@@ -186,7 +188,7 @@ def test_million_triangle_4k_cpp_host_on_eight_strips_equals_python_host(hip_lib
     keys = ["", "E", "A"]
     pfm = tmp_path / "out.pfm"
     out = subprocess.run([APP, "--width", str(W4K), "--height", str(H4K), "--segments", "8", "--iterations", "5", "--frames", str(len(keys)),
-                          "--script", ",".join(keys), "--dump", str(pfm), "--lattice", "10x10x10", "--tessellate", "6", "--ranks", "8"],
+                          "--script", ",".join(keys), "--dump", str(pfm), "--lattice", "10x10x10", "--tessellate", "6"] + strips,
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     stats = json.loads(out.stdout.strip().splitlines()[-1])
