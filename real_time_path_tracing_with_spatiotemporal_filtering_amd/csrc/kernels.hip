@@ -200,13 +200,28 @@ __device__ __forceinline__ void closest_hit_brute(const SceneView& sc, f3 o, f3 
   }
 }
 
-// Primary rays of one wave (64 pixels of row y, columns [x0, x0+63]) can only hit triangles whose padded
-// screen bounds meet that span.  Lane i classifies triangle i (n <= 64) and the ballot is the
+// Pixels of a 64 x 4 tile a wave starts on: not row w of the tile but the 16 x 4 block of columns [16 w, 16 w + 16).  Rays that
+// start through neighbouring pixels walk the same BVH nodes, and a block's rays diverge later than a row's (node-loop lane
+// utilisation of the primary rays 0.66 -> 0.77, profiles/r04_wave_block_ab.txt); on small scenes the block's padded
+// screen rectangle meets fewer triangle bounds than a 64-pixel span's.  1: blocks, 0: rows (A/B builds).
+#ifndef RTPT_WAVE_BLOCK
+#define RTPT_WAVE_BLOCK 1
+#endif
+constexpr int kWaveW = RTPT_WAVE_BLOCK ? 16 : 64, kWaveH = RTPT_WAVE_BLOCK ? 4 : 1;  // a wave's footprint in its tile
+__device__ __forceinline__ uint32_t tile_pixel(int wave, uint32_t lane) {  // index (row << 6 | column) within the tile
+  if (RTPT_WAVE_BLOCK) return ((lane >> 4) << 6) | (static_cast<uint32_t>(wave) << 4) | (lane & 15u);
+  return (static_cast<uint32_t>(wave) << 6) | lane;
+}
+// first column / row of wave `wave`'s footprint, relative to its tile
+__device__ __forceinline__ int wave_x0(int wave) { return RTPT_WAVE_BLOCK ? 16 * wave : 0; }
+__device__ __forceinline__ int wave_y0(int wave) { return RTPT_WAVE_BLOCK ? 0 : wave; }
+// Primary rays of one wave (the kWaveW x kWaveH pixels from (x0, y0)) can only hit triangles whose padded
+// screen bounds meet that rectangle.  Lane i classifies triangle i (n <= 64) and the ballot is the
 // candidate set; must be called with the whole wave converged (before any early return).
-__device__ __forceinline__ unsigned long long span_candidates(const TriBounds* bounds, uint32_t n, int x0, int y) {
+__device__ __forceinline__ unsigned long long span_candidates(const TriBounds* bounds, uint32_t n, int x0, int y0) {
   const uint32_t lane = threadIdx.x & 63u;
   const TriBounds b = bounds[lane < n ? lane : 0u];
-  const bool overlap = lane < n && !(b.x0 > x0 + 63 || b.x1 < x0 || b.y0 > y || b.y1 < y);
+  const bool overlap = lane < n && !(b.x0 > x0 + kWaveW - 1 || b.x1 < x0 || b.y0 > y0 + kWaveH - 1 || b.y1 < y0);
   return __ballot(overlap);
 }
 
@@ -661,10 +676,13 @@ template <int BVH>
 __device__ __forceinline__ void gbuffer_tile(const GbufferArgs& a, uint32_t bx, uint32_t by, uint32_t* stack, float4* alpha_image = nullptr, int ay0 = 0,
                                              int ay1 = 0) {
   const int tid = threadIdx.y * kBlockX + threadIdx.x;
-  const int x = static_cast<int>(bx) * kBlockX + static_cast<int>(threadIdx.x);
-  const int y = a.g.y0 + static_cast<int>(by) * kBlockY + static_cast<int>(threadIdx.y);
+  const uint32_t tp = tile_pixel(static_cast<int>(threadIdx.y), threadIdx.x);
+  const int x = static_cast<int>(bx) * kBlockX + static_cast<int>(tp & 63u);
+  const int y = a.g.y0 + static_cast<int>(by) * kBlockY + static_cast<int>(tp >> 6);
   unsigned long long cand = 0;
-  if (!BVH && a.cull) cand = span_candidates(a.bounds, a.scene.n_tris, static_cast<int>(bx) * kBlockX, __builtin_amdgcn_readfirstlane(y));
+  if (!BVH && a.cull)
+    cand = span_candidates(a.bounds, a.scene.n_tris, static_cast<int>(bx) * kBlockX + wave_x0(static_cast<int>(threadIdx.y)),
+                           a.g.y0 + static_cast<int>(by) * kBlockY + wave_y0(static_cast<int>(threadIdx.y)));
   if (x >= a.g.W || y >= a.g.y1) return;
   gbuffer_pixel<BVH>(a, x, y, cand, stack, tid, kThreads, alpha_image, ay0, ay1);
 }
@@ -888,24 +906,25 @@ __device__ __forceinline__ void pathtrace_tile(const PathtraceArgs& a) {
   const f3 light_c = ld3(a.light_c);
   unsigned int rays = 0;
   unsigned long long cand = 0;  // candidate triangles of this wave's (jittered) primary rays
-  if (!BVH && a.cull) cand = span_candidates(a.bounds, a.scene.n_tris, tile_x0, tile_y0 + wave);
+  if (!BVH && a.cull) cand = span_candidates(a.bounds, a.scene.n_tris, tile_x0 + wave_x0(wave), tile_y0 + wave_y0(wave));
 
   // per-thread path registers
-  uint32_t pix = static_cast<uint32_t>(tid), rng = 0;
+  const uint32_t pix0 = tile_pixel(wave, lane);  // the pixel this thread starts on
+  uint32_t pix = pix0, rng = 0;
   f3 o{0.f, 0.f, 0.f}, d{0.f, 0.f, -1.f}, acc{1.f, 1.f, 1.f};
   {
-    const int x = tile_x0 + static_cast<int>(lane), y = tile_y0 + wave;
+    const int x = tile_x0 + static_cast<int>(pix0 & 63u), y = tile_y0 + static_cast<int>(pix0 >> 6);
     rng = exact::rng_seed(static_cast<uint32_t>(x), static_cast<uint32_t>(y), a.frame, a.batch);  // :297
     if (a.spp > 1) sum_r[tid] = sum_g[tid] = sum_b[tid] = 0.0f;
   }
   for (uint32_t smp = 0; smp < a.spp; smp++) {
-    // ---- primary rays: thread tid <-> pixel tid (mapping restored at the start of every sample)
+    // ---- primary rays: thread <-> its starting pixel pix0 (mapping restored at the start of every sample)
     if (smp > 0) {
       __syncthreads();
-      pix = static_cast<uint32_t>(tid);
-      rng = rng_pix[tid];  // the pixel's RNG state after its previous sample (stored at path end)
+      pix = pix0;
+      rng = rng_pix[pix0];  // the pixel's RNG state after its previous sample (stored at path end)
     }
-    const int px0 = tile_x0 + static_cast<int>(lane), py0 = tile_y0 + wave;
+    const int px0 = tile_x0 + static_cast<int>(pix0 & 63u), py0 = tile_y0 + static_cast<int>(pix0 >> 6);
     bool alive = (px0 < a.g.W) && (py0 < a.g.y1);
     if (alive) {
       float u1 = glsl_max(1e-38f, exact::rng_next(rng));  // :87 Box-Muller
