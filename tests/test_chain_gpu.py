@@ -86,6 +86,52 @@ def test_rows_per_step_of_a_pair(hip_lib, monkeypatch, g, generic):
                     assert np.array_equal(pa, pb)
 
 
+@pytest.mark.parametrize("env", [{"RTPT_CHAIN_SKEW": "0"}, {"RTPT_CHAIN_SKEW": "80,60"}, {"RTPT_CHAIN_BW": "120"}, {"RTPT_CHAIN_BW": "96", "RTPT_CHAIN_SKEW": "45,45"},
+                                 {"RTPT_CHAIN_G1": "14"}, {"RTPT_CHAIN_WG_PER_CU": "1"}, {"RTPT_CHAIN_WG_PER_CU": "3", "RTPT_CHAIN_SKEW": "50"}])
+def test_chain_geometry_switches_do_not_change_the_frames(hip_lib, monkeypatch, env):
+    """how a chained launch cuts the frame — row segments sized by the age of their workgroups (RTPT_CHAIN_SKEW; the default is
+    a skew too), the strip width of the pair (1,2), rows per step of that pair alone, workgroups per CU — is speed only: every
+    cut gives the bits of the separate passes, on frames tall enough for several segments per XCD and on ragged ones"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    keys = [(), ("J",), ("D", "E")]
+    for (w, h) in ((130, 33), (333, 700), (1000, 800), (2000, 1100)):
+        for n in (3, 5):
+            a, _ = _frames(hip_lib, w, h, n, 0, keys)
+            b, _ = _frames(hip_lib, w, h, n, hip_lib.FLAG_NO_FILTER_FUSION, keys)
+            for f, ((ia, pa), (ib, pb)) in enumerate(zip(a, b)):
+                assert np.array_equal(bits(ia), bits(ib)), (env, w, h, n, f)
+                assert np.array_equal(pa, pb)
+
+
+@pytest.mark.parametrize("window", [1, 2, 3])
+def test_segment_window_of_the_tile_kernel(hip_lib, oracle, cornell, monkeypatch, window):
+    """RTPT_PT_WINDOW: the tile kernel hands its survivors to the queue kernels after `window` segments instead of 4 (brute
+    force) / 8 (BVH) — same traced and filtered frames, same ray count, on the Cornell box and on a BVH scene"""
+    from real_time_path_tracing_with_spatiotemporal_filtering_amd import scenes
+    xyz, idx, _ = cornell
+    vx, ti, xf, cam, zfar = scenes.instanced_cornell(xyz, idx, lattice=(2, 2, 2), tess=2)
+    lattice = dict(mesh=(vx, ti), instance_xforms=xf, cameraOrigin=cam, z_far=zfar, lightPos=(1.0, float(cam[1]), float(cam[2]) - 8.0))
+    keys = [(), ("J",), ("E",)]
+    def run(**kw):
+        from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
+        app = make_app(200, 150, max_segments=8, iterations=3, **kw)
+        out = []
+        for k in keys:
+            app.drawScene(k)
+            out.append(app.backend.ctx.readback(hip_lib.PLANE_PREVIOUS))
+        rays = app.backend.ctx.raycount()
+        app.backend.close()
+        return out, rays
+    want = [run(), run(**lattice)]
+    monkeypatch.setenv("RTPT_PT_WINDOW", str(window))
+    got = [run(), run(**lattice)]
+    for (fa, ra), (fb, rb) in zip(want, got):
+        assert ra == rb
+        for a, b in zip(fa, fb):
+            assert np.array_equal(bits(a), bits(b))
+
+
 @pytest.mark.parametrize("exact", [0, 1])
 def test_chain_equals_separate_passes_4k(hip_lib, exact):
     """BASELINE configs[2] at its size: 3840x2160, 4 segments, N = 5, three frames"""
