@@ -20,6 +20,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -526,6 +527,9 @@ def main():
                          "frame is already whole), rgba8 on several (a frame that is never assembled cannot be presented)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--secondary-timeout", type=float, default=300.0,
+                    help="several ranks: seconds the legs behind the headline measurement may take before rank 0 prints the line "
+                         "without them and every rank exits (a watchdog against a message that never arrives)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -659,6 +663,10 @@ def main():
         if pt:
             result["pathtrace_kernel_mray_s"] = round(rays / args.steps / (pt["avg_us"] * 1e-6) / 1e6, 1)
 
+    # Several ranks: the legs behind the headline measurement exercise point-to-point messages (halo rows, history bands, the
+    # float gather) that a one-GPU box can only rehearse over gloo.  If one of them never comes back on the real
+    # interconnect, rank 0 still prints the line it has (with a note under `also`), and every rank leaves.
+    watchdog = _arm_watchdog(result, rank, args.secondary_timeout) if dist is not None and world > 1 and not args.no_secondary else None
     if not args.no_secondary and args.frames_in_flight == 1:
         # the same workload with two frames in flight (app.PipelinedBackend): throughput only, the per-kernel
         # durations above come from the serial run because overlapping frames stretch every kernel
@@ -730,6 +738,8 @@ def main():
         result.setdefault("also", {})["instanced-4k-1spp-8seg-5atrous"] = inst
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.workload)
+    if watchdog is not None:
+        watchdog.cancel()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -737,11 +747,27 @@ def main():
         _RESULT_LINE.append(json.dumps(result))
 
 
+def _arm_watchdog(result, rank, seconds):
+    def fire():
+        try:
+            if rank == 0 and result is not None:
+                result.setdefault("also", {})["_watchdog"] = (f"the legs behind the headline measurement did not finish within {seconds:g} s; "
+                                                             "this line was printed without the missing ones")
+                os.write(_STDOUT_FD[0] if _STDOUT_FD else 1, (json.dumps(result) + "\n").encode())
+        finally:
+            os._exit(0)
+    t = threading.Timer(seconds + (0.0 if rank == 0 else 2.0), fire)   # rank 0 first: its line is what matters
+    t.daemon = True
+    t.start()
+    return t
+
+
 def _main_with_clean_stdout():
     """stdout carries exactly one JSON line: RCCL prints a version banner to fd 1 when its first communicator
     comes up, so fd 1 points at stderr while the benchmark runs and is restored for the result line."""
     sys.stdout.flush()
     saved = os.dup(1)
+    _STDOUT_FD.append(saved)
     os.dup2(2, 1)
     try:
         main()
@@ -754,6 +780,7 @@ def _main_with_clean_stdout():
 
 
 _RESULT_LINE = []
+_STDOUT_FD = []   # the real stdout while fd 1 points at stderr (_main_with_clean_stdout)
 
 if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-baseline-child":
