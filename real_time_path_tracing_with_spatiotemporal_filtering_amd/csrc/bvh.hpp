@@ -11,8 +11,10 @@
 namespace rt {
 
 constexpr uint32_t kBvhEmpty = 0xFFFFFFFFu;
+// Triangles per leaf: 2 (one fan pair, or two single triangles) since the end of round 4 — K0 + K1 + K2 on the 1.15 M-triangle
+// frame 2 852 us with 4, 2 825 with 2 (profiles/r04_bvh_bins_ab.txt): a leaf is then ONE 80-byte record and its test has no loop.
 #ifndef RTPT_BVH_MAX_LEAF
-#define RTPT_BVH_MAX_LEAF 4
+#define RTPT_BVH_MAX_LEAF 2
 #endif
 #ifndef RTPT_BVH_MIN_LEAF
 #define RTPT_BVH_MIN_LEAF 1

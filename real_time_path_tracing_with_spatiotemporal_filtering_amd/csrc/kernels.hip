@@ -348,7 +348,8 @@ __device__ __forceinline__ void closest_hit_bvh(const SceneView& sc, f3 o, f3 d,
   auto test_leaf = [&](uint32_t ref) {
     const uint32_t first = (ref & ~kLeafBit) >> 2, cnt = (ref & 3u) + 1u;
     if (PAIRS) {
-      for (uint32_t j = 0; j < cnt; j += 2) {
+      // (with kBvhMaxLeaf <= 2 a leaf is one pair: the loop is a single pass the compiler sees)
+      for (uint32_t j = 0; j < (kBvhMaxLeaf <= 2 ? 1u : cnt); j += 2) {
 #if RTPT_BVH_COUNT
         RTPT_COUNT_TRIP(2);
         my_leaves++;
