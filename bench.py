@@ -667,41 +667,53 @@ def main():
     # float gather) that a one-GPU box can only rehearse over gloo.  If one of them never comes back on the real
     # interconnect, rank 0 still prints the line it has (with a note under `also`), and every rank leaves.
     watchdog = _arm_watchdog(result, rank, args.secondary_timeout) if dist is not None and world > 1 and not args.no_secondary else None
-    if not args.no_secondary and args.frames_in_flight == 1:
-        # the same workload with two frames in flight (app.PipelinedBackend): throughput only, the per-kernel
-        # durations above come from the serial run because overlapping frames stretch every kernel
-        e3, r3, _, _, _ = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist, collect_kernels=False,
-                                  in_flight=2)
-        if rank == 0:
-            result.setdefault("also", {})["two_frames_in_flight"] = {
-                "value": round(r3 / e3 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e3 / args.steps * 1e3, 4),
-                "fps": round(args.steps / e3, 1)}
-    if world > 1 and not args.no_secondary:
-        # the legs a scaling run must see (every rank takes part): the frame left distributed, the float gather, the RCCL
-        # halo exchange (k rows per neighbour per iteration instead of redundant rows), and a camera that moves every
-        # frame (history bands travel between strips).  Same steps/warm-up, throughput only.
-        legs = [("without_output_gather", dict(present=None)),
-                ("with_f32_gather", dict(present="f32")),
-                ("halo_exchange" if args.halo != "exchange" else "halo_redundant",
-                 dict(halo="exchange" if args.halo != "exchange" else "redundant")),
-                ("moving_camera", dict(camera_keys=args.camera_keys or "EQ"))]
-        from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripPlan
-        for name, kw in legs:
-            try:   # every rank checks EVERY rank's plan, so a leg is skipped by all of them or by none
-                for r in range(world):
-                    for k in range(1, wl["iterations"] + 1):
-                        StripPlan(wl["height"], world, r, wl["iterations"], kw.get("halo", args.halo), args.flags & 0x9F0,
-                                  args.strip_rows).exchange_rows(k)
-            except ValueError as ex:   # strips shorter than the exchange halo
-                if rank == 0:
-                    result.setdefault("also", {})[name] = {"skipped": str(ex)}
-                continue
-            e5, r5, _, _, _ = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist, collect_kernels=False, **kw)
+    try:
+        if not args.no_secondary and args.frames_in_flight == 1:
+            # the same workload with two frames in flight (app.PipelinedBackend): throughput only, the per-kernel
+            # durations above come from the serial run because overlapping frames stretch every kernel
+            e3, r3, _, _, _ = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist, collect_kernels=False,
+                                      in_flight=2)
             if rank == 0:
-                result.setdefault("also", {})[name] = {
-                    "value": round(r5 / e5 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e5 / args.steps * 1e3, 4),
-                    "history_exchange_bytes_per_frame_rank0": round(HIST_BYTES[0] / args.steps, 1),
-                    "present_gather_bytes_per_frame_rank0": round(PRESENT_BYTES[0] / args.steps, 1)}
+                result.setdefault("also", {})["two_frames_in_flight"] = {
+                    "value": round(r3 / e3 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e3 / args.steps * 1e3, 4),
+                    "fps": round(args.steps / e3, 1)}
+        if world > 1 and not args.no_secondary:
+            # the legs a scaling run must see (every rank takes part): the frame left distributed, the float gather, the RCCL
+            # halo exchange (k rows per neighbour per iteration instead of redundant rows), and a camera that moves every
+            # frame (history bands travel between strips).  Same steps/warm-up, throughput only.
+            legs = [("without_output_gather", dict(present=None)),
+                    ("with_f32_gather", dict(present="f32")),
+                    ("halo_exchange" if args.halo != "exchange" else "halo_redundant",
+                     dict(halo="exchange" if args.halo != "exchange" else "redundant")),
+                    ("moving_camera", dict(camera_keys=args.camera_keys or "EQ"))]
+            from real_time_path_tracing_with_spatiotemporal_filtering_amd.strips import StripPlan
+            for name, kw in legs:
+                try:   # every rank checks EVERY rank's plan, so a leg is skipped by all of them or by none
+                    for r in range(world):
+                        for k in range(1, wl["iterations"] + 1):
+                            StripPlan(wl["height"], world, r, wl["iterations"], kw.get("halo", args.halo), args.flags & 0x9F0,
+                                      args.strip_rows).exchange_rows(k)
+                except ValueError as ex:   # strips shorter than the exchange halo
+                    if rank == 0:
+                        result.setdefault("also", {})[name] = {"skipped": str(ex)}
+                    continue
+                e5, r5, _, _, _ = run_gpu(wl, args, rank, world, args.steps, args.warmup, torch, dist, collect_kernels=False, **kw)
+                if rank == 0:
+                    result.setdefault("also", {})[name] = {
+                        "value": round(r5 / e5 / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(e5 / args.steps * 1e3, 4),
+                        "history_exchange_bytes_per_frame_rank0": round(HIST_BYTES[0] / args.steps, 1),
+                        "present_gather_bytes_per_frame_rank0": round(PRESENT_BYTES[0] / args.steps, 1)}
+    except Exception as ex:   # noqa: BLE001
+        # several ranks: the legs behind the headline are best effort — a rank whose peer has left (its watchdog fired) or whose
+        # message failed must not turn the finished headline measurement into a failed run
+        if watchdog is None:
+            raise
+        watchdog.cancel()
+        print(f"rank {rank}: secondary legs abandoned: {ex!r}", file=sys.stderr, flush=True)
+        if rank == 0:
+            result.setdefault("also", {})["_error"] = f"secondary legs abandoned: {ex!r}"
+            os.write(_STDOUT_FD[0] if _STDOUT_FD else 1, (json.dumps(result) + "\n").encode())
+        os._exit(0)
     if world == 1 and rank == 0 and not args.no_secondary and args.present is None:
         e6, r6, k6, p6, tf6 = run_gpu(wl, args, 0, 1, args.steps, args.warmup, torch, None, present="rgba8")
         result.setdefault("also", {})["with_present_rgba8"] = {

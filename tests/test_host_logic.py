@@ -175,3 +175,24 @@ def test_posed_scene_bounds_and_static_test_follow_the_model_matrix():
     assert app._camera_static()
     a, b = reprojection_rows(app.ubo, 64, 48, (10, 20), app._world_bounds())
     assert a <= 10 and b >= 20 and (b - a) < 48
+
+
+def test_bench_watchdog():
+    """bench.py's guard on the secondary legs of a multi-rank run (a message that never arrives on an interconnect this code
+    has not met): after the timeout rank 0 writes the headline line it holds, with a note, to the real stdout and the process
+    exits 0 without running on; the other ranks leave silently a moment later"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import bench, time\n"
+            "bench._STDOUT_FD.append(1)\n"
+            "bench._arm_watchdog({'metric': 'm', 'value': 1.0}, %d, 0.05)\n"
+            "time.sleep(20)\n"
+            "print('not reached')\n")
+    out = subprocess.run([sys.executable, "-c", code % 0], cwd=ROOT, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "not reached" not in out.stdout
+    line = json.loads(out.stdout.strip())
+    assert line["metric"] == "m" and "did not finish" in line["also"]["_watchdog"]
+    out = subprocess.run([sys.executable, "-c", code % 1], cwd=ROOT, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout == ""
