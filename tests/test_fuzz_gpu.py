@@ -2,6 +2,8 @@
 flags, extension flags, key scripts): every case runs a few frames through the C ABI and is compared with the oracle —
 traced colour, ids, ray count and reprojected pixels bit for bit, the final image bit for bit with the exact filter
 and within FILTER_TOL otherwise."""
+import os
+
 import numpy as np
 import pytest
 
@@ -29,7 +31,8 @@ def _cases(n, seed):
         yield i, w, h, seg, n_it, flags, script
 
 
-@pytest.mark.parametrize("seed", [1, 2])
+# RTPT_FUZZ_SEEDS=3,4,...: a longer sweep than the two seeds of every run (used at the end of a round's kernel changes)
+@pytest.mark.parametrize("seed", [int(v) for v in os.environ.get("RTPT_FUZZ_SEEDS", "1,2").split(",")])
 def test_seeded_configuration_sweep(hip_lib, oracle, cornell, seed):
     from real_time_path_tracing_with_spatiotemporal_filtering_amd.app import make_app
     moves = {"S": (2, +0.1), "W": (2, -0.1), "A": (0, -0.1), "D": (0, +0.1), "E": (1, +0.1), "Q": (1, -0.1)}
